@@ -1,0 +1,56 @@
+"""Oracle (test infrastructure): import the reference's own model files in THIS container.
+
+Only ``tests/golden/make_golden.py`` uses this, and only where ``/root/reference`` exists
+(never on the GPU box).  Technique recorded in SURVEY.md §8c: the package ``__init__`` files
+import datasets/LLM code that cannot load here, so ``src``, ``src.nn``, ``src.nn.models`` and
+``src.nn.gnn`` are pre-registered as bare namespace modules, and the two absent third-party
+packages are represented by ``oracle.pyg_restate`` (``PNAConv``/``BatchNorm``/``Linear`` — parity
+unpinned) plus a type-annotation-only ``StypeWiseFeatureEncoder`` name.  The reference's
+``fused.py``, ``tabgnn.py``, ``pna.py`` and ``decoder.py`` then execute unmodified.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+REF = os.environ.get("TABGNN_REFERENCE_ROOT", "/root/reference")
+
+
+def _ns(name, path=None):
+    m = types.ModuleType(name)
+    if path is not None:
+        m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def load_reference():
+    """Returns a dict of the reference classes on the path (real reference code objects)."""
+    if not os.path.isdir(REF):
+        raise FileNotFoundError(f"{REF} not present (reference never travels to the GPU box)")
+    from . import pyg_restate as R
+
+    tg = _ns("torch_geometric"); tgn = _ns("torch_geometric.nn")
+    tgn.PNAConv, tgn.BatchNorm, tgn.Linear = R.PNAConv, R.BatchNorm, R.Linear
+    tg.nn = tgn
+    dense = _ns("torch_geometric.nn.dense"); lin = _ns("torch_geometric.nn.dense.linear"); lin.Linear = R.Linear
+    tgn.dense = dense; dense.linear = lin
+    inits = _ns("torch_geometric.nn.inits")
+    inits.reset = lambda m: [c.reset_parameters() for c in m.modules() if hasattr(c, "reset_parameters") and c is not m]
+    typing_ = _ns("torch_geometric.typing")
+    for n in ("Adj", "OptPairTensor", "OptTensor", "Size"):
+        setattr(typing_, n, object)
+    _ns("torch_frame"); _ns("torch_frame.nn"); _ns("torch_frame.nn.encoder")
+    se = _ns("torch_frame.nn.encoder.stypewise_encoder"); se.StypeWiseFeatureEncoder = object
+
+    _ns("src", f"{REF}/src"); _ns("src.nn", f"{REF}/src/nn")
+    _ns("src.nn.models", f"{REF}/src/nn/models"); _ns("src.nn.gnn", f"{REF}/src/nn/gnn")
+    fused = importlib.import_module("src.nn.models.fused")
+    tabgnn = importlib.import_module("src.nn.models.tabgnn")
+    pna = importlib.import_module("src.nn.gnn.pna")
+    dec = importlib.import_module("src.nn.gnn.decoder")
+    return {"TABGNNFused": fused.TABGNNFused, "FTTransformerPNAFusedLayer": fused.FTTransformerPNAFusedLayer,
+            "TABGNN": tabgnn.TABGNN, "PNAConvHetero": pna.PNAConvHetero,
+            "ClassifierHead": dec.ClassifierHead, "NodeClassificationHead": dec.NodeClassificationHead}
