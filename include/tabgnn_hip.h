@@ -1,0 +1,155 @@
+/* tabgnn_hip.h — C ABI of libtabgnn_hip.so: the MI355X (gfx950) kernels behind the fused
+ * tabular-transformer + PNA hot path of Atahanak/models-for-relational-multimodal-data.
+ *
+ * The reference has no FFI on this path: everything sits behind Python nn.Module.forward() surfaces
+ * (SURVEY.md §8b).  This header is therefore the boundary a torch-free host would bind; the Python host in
+ * models-for-relational-multimodal-data_amd/tabgnn_amd binds it with ctypes (INTEGRATION.md shows the stub).
+ * Every entry point cites the reference call it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked host; no torch types; no allocation inside;
+ *   - `dt`: 0 = float32 activations, 1 = bfloat16 activations; parameters/statistics are always float32;
+ *   - `stream` is a hipStream_t; kernels are launched on it and never synchronise;
+ *   - return 0 on success, non-zero on error (tg_last_error() has the message); nothing aborts;
+ *   - indices are int32 on the device (tg_ids_to_i32 converts and range-checks torch's int64);
+ *   - feature widths (C, F) must be multiples of 8 (16-byte vector access).
+ */
+#ifndef TABGNN_HIP_H_
+#define TABGNN_HIP_H_
+#include <stdint.h>
+
+#define TABGNN_HIP_ABI_VERSION 1
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ---------------------------------------------------------------------------------- */
+const char* tg_last_error(void);
+int tg_abi_version(void);
+int tg_device_check(void); /* 0 when device 0 is a gfx950 */
+
+/* ---- index structure (edge_index of the sampled subgraph; produced at
+ *      src/datasets/ibm_transactions_for_aml.py:170-173, consumed at src/nn/models/fused.py:252-254) ---- */
+int tg_ids_to_i32(const int64_t* ids, int64_t M, int32_t N, int32_t* out, int32_t* err_flag, void* stream);
+int64_t tg_csr_workspace_ints(int64_t M, int32_t N);
+/* stable counting sort of M keys in [0,N): rowptr[N+1], perm[M] (positions in input order inside a segment) */
+int tg_csr_build(const int32_t* key, int64_t M, int32_t N, int32_t* rowptr, int32_t* perm, int32_t* work,
+                 void* stream);
+
+/* ---- stype encoders (torch_frame fork EmbeddingEncoder/LinearEncoder/TimestampEncoder/ProjectionEncoder;
+ *      src/datasets/ibm_transactions_for_aml.py:283-294,313-319; utils.py:357-359) -------------------- */
+typedef struct {
+  int32_t kind;    /* 0 numerical, 1 categorical, 2 timestamp, 3 relation */
+  int32_t out_col; /* column position in the output */
+  int32_t src_col; /* column inside its stype tensor */
+  int32_t rows;    /* categorical: table rows = cardinality + 1 (row 0 = padding / NaN) */
+  int32_t tab_off; /* categorical: first row of the column's table in the concatenated table */
+  int32_t acc_off; /* backward: float offset of the column's accumulators; -1 = global atomics (big table) */
+  int32_t ts_slot; /* timestamp: index among the timestamp columns of this launch */
+  int32_t pad;
+} tg_enc_col;
+typedef struct {
+  int32_t ncol, nts;
+  tg_enc_col col[16];
+} tg_enc_desc; /* HOST struct, passed by pointer, copied into the kernel arguments */
+typedef struct {
+  const float* num; int32_t nn;        /* [R, nn] */
+  const int64_t* cat; int32_t nc;      /* [R, nc] */
+  const int64_t* ts; int32_t nt;       /* [R, nt, 7] (year, month, day, dayofweek, hour, minute, second) */
+  const float* rel; int32_t nr;        /* [R, nr] */
+  const float *num_mean, *num_std, *num_w, *num_b; /* [nn] [nn] [nn,C] [nn,C] */
+  const float* cat_table;              /* [sum rows, C] */
+  const float *ts_min_year, *ts_w, *ts_b; /* [nt] [nt,7,8,C] [nt,C] */
+  const float *rel_w, *rel_b;          /* [nr,C] */
+} tg_enc_ptrs; /* HOST struct of device pointers */
+int tg_encode_max_cols(void);
+int tg_encode_small_table_rows(void);
+int tg_encode_bwd_blocks(void);
+int tg_encode_fwd(const void* desc, const void* ptrs, void* out /*[R,ncols,C]*/, int64_t R, int32_t ncols, int32_t C,
+                  int32_t dt, void* stream);
+int tg_encode_bwd(const void* desc, const void* ptrs, const void* g /*[R,ncols,C]*/, int64_t R, int32_t ncols,
+                  int32_t C, int32_t acc_floats, float* dflat, float* partials, float* big_table_grad, int32_t dt,
+                  void* stream);
+
+/* ---- column self-attention core (torch nn.MultiheadAttention inside nn.TransformerEncoderLayer;
+ *      src/nn/models/fused.py:83-92,160,164,187-196,249; src/nn/models/tabgnn.py:199-208,219) ---------- */
+int tg_attn_fwd(const void* qkv /*[R,S,3C]*/, void* out /*[R,S,C]*/, float* lse /*[R,H,S]*/, int64_t R, int32_t S,
+                int32_t C, int32_t H, float p_drop, uint64_t seed, uint32_t rstream, int32_t dt, void* stream);
+int tg_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t R, int32_t S,
+                int32_t C, int32_t H, float p_drop, uint64_t seed, uint32_t rstream, int32_t dt, void* stream);
+
+/* ---- LayerNorm with fused pre-add and residual combine:
+ *      out = alpha*res + beta_c*LN(a + dropout(b + bias_b))      (norm1/norm2 of the encoder layer; tab_norm
+ *      fused.py:160,164,249 / tabgnn.py:219; fuse[0], fuse_norm fused.py:224,258) -------------------------- */
+int tg_ln_partials_floats(int64_t M, int32_t C);
+int tg_ln_fwd(const void* a, const void* b, const float* bias_b, const float* gamma, const float* beta,
+              const void* res, void* out, float* stats /*[M,2]*/, int64_t M, int32_t C, float eps, float alpha,
+              float beta_c, float p_drop, uint64_t seed, uint32_t rstream, int32_t dt, void* stream);
+int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* gamma, const float* stats,
+              const void* dout, void* da, void* db, void* dres, float* dparams /*[3C]: dgamma,dbeta,dbias_b*/,
+              float* partials, int64_t M, int32_t C, float alpha, float beta_c, float p_drop, uint64_t seed,
+              uint32_t rstream, int32_t dt, void* stream);
+
+/* ---- BatchNorm1d (+ReLU) with residual combine: out = alpha*res + beta_c*relu(BN(x))
+ *      (torch_geometric BatchNorm -> BatchNorm1d; fused.py:214,252; tabgnn.py:172,188) ------------------- */
+int tg_bn_partials_floats(int64_t N, int32_t F);
+int tg_bn_act_res_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, float* mean, float* rstd, void* out, float* partials, int64_t N, int32_t F,
+                      int32_t training, float momentum, float eps, int32_t relu, float alpha, float beta_c, int32_t dt,
+                      void* stream);
+int tg_bn_act_res_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* mean,
+                      const float* rstd, void* dx, void* dres, float* dparams /*[2F]: dbeta,dgamma*/, float* partials,
+                      int64_t N, int32_t F, int32_t training, int32_t relu, float alpha, float beta_c, int32_t dt,
+                      void* stream);
+
+/* ---- activation + dropout after a Linear (encoder FFN; fuse MLP fused.py:224-231; heads decoder.py:14-15)
+ *      act: 0 none, 1 relu, 2 leaky_relu(0.01) ------------------------------------------------------------ */
+int tg_act_dropout_fwd(const void* x, void* y, int64_t n, int32_t act, float p_drop, uint64_t seed, uint32_t rstream,
+                       int32_t dt, void* stream);
+int tg_act_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t act, float p_drop, uint64_t seed,
+                       uint32_t rstream, int32_t dt, void* stream);
+int tg_axpby(const void* a, const void* b, void* y, int64_t n, float alpha, float beta, int32_t dt, void* stream);
+/* CLS merge of the fused layer, fused.py:259-260 */
+int tg_cls_merge_fwd(const void* xtab /*[B,S,C]*/, const void* xf /*[B,D]*/, void* out, int64_t B, int32_t S,
+                     int32_t C, int32_t D, int32_t dt, void* stream);
+
+/* ---- PNA message passing (torch_geometric 2.5.3 PNAConv as configured at fused.py:200-207) -------------- */
+/* out[r] = [A[ia[r]] | B[ib[r]] | C[ic[r]]]  (index NULL = identity; optional ReLU on A,B parts):
+ * PNAConv.message input [x_i,x_j,e]; edge update fused.py:254; fuse input fused.py:257; decoder.py:18-19 */
+int tg_gather_concat3(const void* a, const int32_t* ia, int64_t sa, int32_t wa, int32_t relu_a, const void* b,
+                      const int32_t* ib, int64_t sb, int32_t wb, int32_t relu_b, const void* c, const int32_t* ic,
+                      int64_t sc, int32_t wc, void* out, int64_t rows, int32_t dt, void* stream);
+/* backward of the two gathered parts as a deterministic segmented sum over CSR(s) */
+int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA, int32_t offB,
+                    const int32_t* rpB, const int32_t* pmB, int32_t seedB, const void* relu_src, void* dx, int32_t N,
+                    int32_t F, int32_t dt, void* stream);
+/* mean|max|min|std of messages h[E,F] per destination -> agg[N,4F]  (PNAConv.aggregate, "the SpMM") */
+int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const int32_t* perm, void* agg, int32_t N, int32_t F,
+                         int32_t dt, void* stream);
+int tg_pna_aggregate_bwd(const void* h, const void* agg, const void* dagg, const int32_t* rowptr, const int32_t* perm,
+                         void* dh, int32_t N, int32_t F, int32_t dt, void* stream);
+/* degree scalers applied after the post GEMM: out = xw + G0 + amp*G1 + att*G2 (DegreeScalerAggregation) */
+int tg_pna_scale_combine_fwd(const void* xw, const void* G /*[N,3F]*/, const int32_t* rowptr, const float* avg_log,
+                             void* out, int32_t N, int32_t F, int32_t dt, void* stream);
+int tg_pna_scale_combine_bwd(const void* gout, const int32_t* rowptr, const float* avg_log, void* dG, int32_t N,
+                             int32_t F, int32_t dt, void* stream);
+/* seed-endpoint pooling of the fused layer, fused.py:261-268 (unique / index_add_ / bincount / mean) */
+int tg_seed_pool_fwd(const void* x, const void* xf, const int32_t* rowptr, const int32_t* perm, void* out, int32_t N,
+                     int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);
+int tg_seed_pool_bwd(const void* g, const int32_t* tei, const int32_t* rowptr, void* dx, void* dxf, int32_t N,
+                     int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);
+
+/* ---- train-step tail (main.py:70-75,335-336) ------------------------------------------------------------ */
+int tg_weighted_ce_fwd(const void* logits, const int64_t* y, const float* w, int64_t B, int32_t K,
+                       float* lossden /*[2]*/, float* partials /*[512]*/, int32_t dt, void* stream);
+int tg_weighted_ce_bwd(const void* logits, const int64_t* y, const float* w, const float* lossden, const float* gloss,
+                       int64_t B, int32_t K, void* dlogits, int32_t dt, void* stream);
+int tg_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
+                 float eps, int32_t t, float grad_scale, int32_t zero_grad, void* stream);
+int tg_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TABGNN_HIP_H_ */

@@ -1,0 +1,137 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the fused
+// tabular-transformer + PNA hot path.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tg {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+#define TG_CHECK(cond, ...)                         \
+  do {                                              \
+    if (!(cond)) {                                  \
+      tg::set_error(__VA_ARGS__);                   \
+      return 1;                                     \
+    }                                               \
+  } while (0)
+#define TG_LAUNCH_CHECK()                                                   \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      tg::set_error("%s:%d launch failed: %s", __FILE__, __LINE__,          \
+                    hipGetErrorString(e__));                                \
+      return 2;                                                             \
+    }                                                                       \
+  } while (0)
+
+enum DType : int { F32 = 0, BF16 = 1 };
+
+// ---------------------------------------------------------------- bf16 storage type
+struct bf16_t {
+  unsigned short v;
+};
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  // round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T x);
+template <> __device__ __forceinline__ float to_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t x) { return bf2f(x.v); }
+template <typename T> __device__ __forceinline__ T from_f(float x);
+template <> __device__ __forceinline__ float from_f<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float x) { return bf16_t{f2bf(x)}; }
+
+// 16-byte vector access: 4 floats or 8 bf16 per lane (guide: 16 B/lane is the coalescing sweet spot)
+template <typename T> struct V16;
+template <> struct V16<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const float* p, float (&o)[4]) {
+    float4 r = *reinterpret_cast<const float4*>(p);
+    o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct V16<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&o)[8]) {
+    uint4 r = *reinterpret_cast<const uint4*>(p);
+    unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(w[i] << 16);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&o)[8]) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(o[2 * i]) | ((unsigned)f2bf(o[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// generic small-vector access (VEC elements, VEC*sizeof(T) in {4,8,16} bytes)
+template <typename T, int VEC> __device__ __forceinline__ void loadv(const T* p, float (&o)[VEC]) {
+  if constexpr (VEC == V16<T>::N) {
+    V16<T>::load(p, o);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o[i] = to_f<T>(p[i]);
+  }
+}
+template <typename T, int VEC> __device__ __forceinline__ void storev(T* p, const float (&o)[VEC]) {
+  if constexpr (VEC == V16<T>::N) {
+    V16<T>::store(p, o);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) p[i] = from_f<T>(o[i]);
+  }
+}
+
+// ---------------------------------------------------------------- counter-based dropout RNG
+// keep(seed, stream, idx): one 32-bit hash per element; recomputed in backward from the same
+// (seed, stream) so no mask is ever stored.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned stream, unsigned long long idx) {
+  unsigned lo = (unsigned)idx, hi = (unsigned)(idx >> 32);
+  unsigned k = mix32((unsigned)seed ^ (stream * 0x9E3779B9U) ^ mix32(hi + (unsigned)(seed >> 32) + 0x85ebca6bU));
+  return mix32(lo ^ k);
+}
+// returns the multiplicative factor: 0 or 1/(1-p)
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned stream, unsigned long long idx,
+                                            unsigned thresh, float inv_keep) {
+  return rng_u32(seed, stream, idx) >= thresh ? inv_keep : 0.f;
+}
+inline unsigned drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (unsigned)t;
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+template <int WIDTH> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WIDTH> __device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline int grid_cap(long long blocks, int cap = 256 * 8) { return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks)); }
+
+}  // namespace tg

@@ -1,0 +1,666 @@
+// Normalisation / elementwise epilogues of the hot path, fused the way the reference composes them:
+//   * LayerNorm with the residual + dropout(bias + GEMM-out) pre-add of torch's post-norm encoder layer
+//     (norm1/norm2, src/nn/models/fused.py:83-92) and with the residual combine that follows tab_norm /
+//     fuse_norm (fused.py:160,164,249,258; tabgnn.py:219):  out = alpha*res + beta*LN(a + drop(b + bias_b))
+//   * BatchNorm1d + ReLU + residual average of the PNA branch (fused.py:252):  out = alpha*res + beta*relu(BN(c))
+//   * activation + dropout after a Linear (FFN, fuse MLP, heads).
+// All HBM-bound: one read of each input, one write of the output, 16-byte accesses, statistics in fp32.
+#include "common.hpp"
+#include "../../include/tabgnn_hip.h"
+
+namespace tg {
+
+constexpr int LN_BLOCK = 256;
+
+// ------------------------------------------------------------------ LayerNorm forward
+template <typename T, int VEC, int VPL>
+__global__ void __launch_bounds__(LN_BLOCK) k_ln_fwd(const T* __restrict__ a, const T* __restrict__ b,
+                                                      const float* __restrict__ bias_b, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const T* __restrict__ res,
+                                                      T* __restrict__ out, float* __restrict__ stats, long long M, int C,
+                                                      int lpr, float eps, float alpha, float beta_c, unsigned thresh,
+                                                      float inv_keep, unsigned long long seed, unsigned rstream) {
+  const int groups = LN_BLOCK / lpr;
+  const int gl = threadIdx.x % lpr;
+  long long row = (long long)blockIdx.x * groups + threadIdx.x / lpr;
+  const long long rstride = (long long)gridDim.x * groups;
+  const int nvec = C / VEC;
+  for (; row < M; row += rstride) {  // lpr divides 64, M rows: whole groups iterate together
+    float x[VPL][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      int vi = gl + k * lpr;
+      if (vi < nvec) {
+        int c = vi * VEC;
+        loadv<T, VEC>(a + row * C + c, x[k]);
+        if (b) {
+          float t[VEC];
+          loadv<T, VEC>(b + row * C + c, t);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float u = t[j] + (bias_b ? bias_b[c + j] : 0.f);
+            if (thresh) u *= drop_scale(seed, rstream, (unsigned long long)(row * C + c + j), thresh, inv_keep);
+            x[k][j] += u;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s += x[k][j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) x[k][j] = 0.f;
+      }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    float mu = s / (float)C;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      int vi = gl + k * lpr;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { float d = x[k][j] - mu; v += d * d; }
+      }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    float rstd = rsqrtf(v / (float)C + eps);
+    if (gl == 0 && stats) { stats[2 * row] = mu; stats[2 * row + 1] = rstd; }
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      int vi = gl + k * lpr;
+      if (vi < nvec) {
+        int c = vi * VEC;
+        float y[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) y[j] = beta_c * ((x[k][j] - mu) * rstd * gamma[c + j] + beta[c + j]);
+        if (res) {
+          float r[VEC];
+          loadv<T, VEC>(res + row * C + c, r);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) y[j] += alpha * r[j];
+        }
+        storev<T, VEC>(out + row * C + c, y);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm backward
+// da = dpre; db = dpre * dropmask; dres = alpha*dout; partials[blk][3][C] = (dgamma, dbeta, dbias_b)
+template <typename T, int VEC, int VPL>
+__global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, const T* __restrict__ b,
+                                                      const float* __restrict__ bias_b, const float* __restrict__ gamma,
+                                                      const float* __restrict__ stats, const T* __restrict__ dout,
+                                                      T* __restrict__ da, T* __restrict__ db, T* __restrict__ dres,
+                                                      float* __restrict__ partials, long long M, int C, int lpr,
+                                                      float alpha, float beta_c, unsigned thresh, float inv_keep,
+                                                      unsigned long long seed, unsigned rstream) {
+  extern __shared__ float red[];  // [groups][3][C]
+  const int groups = LN_BLOCK / lpr;
+  const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
+  long long row = (long long)blockIdx.x * groups + gi;
+  const long long rstride = (long long)gridDim.x * groups;
+  const int nvec = C / VEC;
+  float dg[VPL][VEC], dbt[VPL][VEC], dbs[VPL][VEC];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { dg[k][j] = 0.f; dbt[k][j] = 0.f; dbs[k][j] = 0.f; }
+  for (; row < M; row += rstride) {
+    float mu = stats[2 * row], rstd = stats[2 * row + 1];
+    float xh[VPL][VEC], gx[VPL][VEC], msk[VPL][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      int vi = gl + k * lpr;
+      if (vi < nvec) {
+        int c = vi * VEC;
+        float x[VEC], g[VEC];
+        loadv<T, VEC>(a + row * C + c, x);
+        if (b) {
+          float t[VEC];
+          loadv<T, VEC>(b + row * C + c, t);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float m = thresh ? drop_scale(seed, rstream, (unsigned long long)(row * C + c + j), thresh, inv_keep) : 1.f;
+            msk[k][j] = m;
+            x[j] += (t[j] + (bias_b ? bias_b[c + j] : 0.f)) * m;
+          }
+        }
+        loadv<T, VEC>(dout + row * C + c, g);
+        if (dres) {
+          float r[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) r[j] = alpha * g[j];
+          storev<T, VEC>(dres + row * C + c, r);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float gj = g[j] * beta_c;
+          xh[k][j] = (x[j] - mu) * rstd;
+          dg[k][j] += gj * xh[k][j];
+          dbt[k][j] += gj;
+          gx[k][j] = gj * gamma[c + j];
+          s1 += gx[k][j];
+          s2 += gx[k][j] * xh[k][j];
+        }
+      }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      int vi = gl + k * lpr;
+      if (vi < nvec) {
+        int c = vi * VEC;
+        float d[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d[j] = rstd * (gx[k][j] - m1 - xh[k][j] * m2);
+        storev<T, VEC>(da + row * C + c, d);
+        if (b) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { d[j] *= msk[k][j]; dbs[k][j] += d[j]; }
+          storev<T, VEC>(db + row * C + c, d);
+        }
+      }
+    }
+  }
+  // block reduction of the three column sums (fixed order -> deterministic)
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    int vi = gl + k * lpr;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        int c = vi * VEC + j;
+        red[(gi * 3 + 0) * C + c] = dg[k][j];
+        red[(gi * 3 + 1) * C + c] = dbt[k][j];
+        red[(gi * 3 + 2) * C + c] = dbs[k][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += LN_BLOCK) {
+    float t = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) t += red[g2 * 3 * C + i];
+    partials[(long long)blockIdx.x * 3 * C + i] = t;
+  }
+}
+
+// out[i] = sum_blk partials[blk][i]   (i < width)
+__global__ void k_reduce_partials(const float* __restrict__ partials, int nblk, int width, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= width) return;
+  float t = 0.f;
+  for (int bIdx = 0; bIdx < nblk; ++bIdx) t += partials[(long long)bIdx * width + i];
+  out[i] = t;
+}
+
+// ------------------------------------------------------------------ BatchNorm (+ReLU, + residual average)
+// column statistics: each lane owns VEC channels, rows strided over lane groups and blocks
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_col_stats(const T* __restrict__ x, const T* __restrict__ y2,
+                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                    const T* __restrict__ gate, float* __restrict__ partials,
+                                                    long long N, int F, int mode) {
+  // mode 0: partial (sum x, sum x^2).   mode 1 (backward): with dz = x (upstream, already scaled) gated by
+  // gate>0 (if gate), xhat = (y2-mean)*rstd: partial (sum dz, sum dz*xhat)
+  extern __shared__ float red[];  // [groups][2][F]
+  const int lpr = F / VEC, groups = 256 / lpr;
+  const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  const int c = gl * VEC;
+  if (gi < groups) {
+    for (long long r = (long long)blockIdx.x * groups + gi; r < N; r += (long long)gridDim.x * groups) {
+      float v[VEC];
+      loadv<T, VEC>(x + r * F + c, v);
+      if (mode == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+      } else {
+        float u[VEC];
+        loadv<T, VEC>(y2 + r * F + c, u);
+        if (gate) {
+          float gt[VEC];
+          loadv<T, VEC>(gate + r * F + c, gt);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) v[j] = gt[j] > 0.f ? v[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { s1[j] += v[j]; s2[j] += v[j] * (u[j] - mean[c + j]) * rstd[c + j]; }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[(gi * 2 + 0) * F + c + j] = s1[j]; red[(gi * 2 + 1) * F + c + j] = s2[j]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * F; i += 256) {
+    float t = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) t += red[g2 * 2 * F + i];
+    partials[(long long)blockIdx.x * 2 * F + i] = t;
+  }
+}
+
+__global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, long long N, int F, float eps,
+                              float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                              float* __restrict__ running_mean, float* __restrict__ running_var) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= F) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int bIdx = 0; bIdx < nblk; ++bIdx) { s1 += partials[(long long)bIdx * 2 * F + c]; s2 += partials[(long long)bIdx * 2 * F + F + c]; }
+  float mu = s1 / (float)N;
+  float var = fmaxf(s2 / (float)N - mu * mu, 0.f);
+  mean[c] = mu;
+  rstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    float unb = N > 1 ? var * ((float)N / (float)(N - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+  }
+}
+
+__global__ void k_bn_eval_stats(const float* __restrict__ running_mean, const float* __restrict__ running_var, int F,
+                                float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= F) return;
+  mean[c] = running_mean[c];
+  rstd[c] = rsqrtf(running_var[c] + eps);
+}
+
+// out = alpha*res + beta_c*act(BN(x));  bn_out (optional) keeps BN(x) for the ReLU gate of the backward
+template <typename T, int VEC>
+__global__ void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, T* __restrict__ out, long long N, int F, int relu,
+                           float alpha, float beta_c) {
+  const int vpr = F / VEC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = N * vpr;
+  for (; i < total; i += stride) {
+    long long r = i / vpr;
+    int c = (int)(i % vpr) * VEC;
+    float v[VEC];
+    loadv<T, VEC>(x + r * F + c, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float y = (v[j] - mean[c + j]) * rstd[c + j] * gamma[c + j] + beta[c + j];
+      if (relu) y = fmaxf(y, 0.f);
+      v[j] = beta_c * y;
+    }
+    if (res) {
+      float t[VEC];
+      loadv<T, VEC>(res + r * F + c, t);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] += alpha * t[j];
+    }
+    storev<T, VEC>(out + r * F + c, v);
+  }
+}
+
+// backward apply.  dz = beta_c*dout gated by BN(x)>0;  training: dx = gamma*rstd*(dz - sum_dz/N - xhat*sum_dzxhat/N)
+// eval: dx = gamma*rstd*dz.  dres = alpha*dout.
+template <typename T, int VEC>
+__global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ sums /*[2][F]*/,
+                               T* __restrict__ dx, T* __restrict__ dres, long long N, int F, int relu, int training,
+                               float alpha, float beta_c) {
+  const int vpr = F / VEC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = N * vpr;
+  float invN = 1.f / (float)N;
+  for (; i < total; i += stride) {
+    long long r = i / vpr;
+    int c = (int)(i % vpr) * VEC;
+    float v[VEC], g[VEC], o[VEC];
+    loadv<T, VEC>(x + r * F + c, v);
+    loadv<T, VEC>(dout + r * F + c, g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float xh = (v[j] - mean[c + j]) * rstd[c + j];
+      float y = xh * gamma[c + j] + beta[c + j];
+      float dz = (relu && !(y > 0.f)) ? 0.f : beta_c * g[j];
+      float t = training ? dz - sums[c + j] * invN - xh * sums[F + c + j] * invN : dz;
+      o[j] = gamma[c + j] * rstd[c + j] * t;
+    }
+    storev<T, VEC>(dx + r * F + c, o);
+    if (dres) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = alpha * g[j];
+      storev<T, VEC>(dres + r * F + c, o);
+    }
+  }
+}
+
+// column sums for the BN backward need the gated dz: computed on the fly from (x, dout)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_bn_bwd_stats(const T* __restrict__ x, const T* __restrict__ dout,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ partials, long long N, int F, int relu,
+                                                       float beta_c) {
+  extern __shared__ float red[];
+  const int lpr = F / VEC, groups = 256 / lpr;
+  const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
+  const int c = gl * VEC;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  if (gi < groups) {
+    for (long long r = (long long)blockIdx.x * groups + gi; r < N; r += (long long)gridDim.x * groups) {
+      float v[VEC], g[VEC];
+      loadv<T, VEC>(x + r * F + c, v);
+      loadv<T, VEC>(dout + r * F + c, g);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float xh = (v[j] - mean[c + j]) * rstd[c + j];
+        float y = xh * gamma[c + j] + beta[c + j];
+        float dz = (relu && !(y > 0.f)) ? 0.f : beta_c * g[j];
+        s1[j] += dz;
+        s2[j] += dz * xh;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[(gi * 2 + 0) * F + c + j] = s1[j]; red[(gi * 2 + 1) * F + c + j] = s2[j]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * F; i += 256) {
+    float t = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) t += red[g2 * 2 * F + i];
+    partials[(long long)blockIdx.x * 2 * F + i] = t;
+  }
+}
+
+// ------------------------------------------------------------------ activation + dropout (after a Linear)
+// act: 0 none, 1 relu, 2 leaky_relu(0.01)
+template <typename T, int VEC>
+__global__ void k_act_dropout_fwd(const T* __restrict__ x, T* __restrict__ y, long long n, int act, unsigned thresh,
+                                  float inv_keep, unsigned long long seed, unsigned rstream) {
+  long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * VEC;
+  long long stride = (long long)gridDim.x * blockDim.x * VEC;
+  for (; i < n; i += stride) {
+    const bool full = i + VEC <= n;
+    float v[VEC];
+    if (full) loadv<T, VEC>(x + i, v);
+    else
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = i + j < n ? to_f<T>(x[i + j]) : 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float u = v[j];
+      if (act == 1) u = fmaxf(u, 0.f);
+      else if (act == 2) u = u > 0.f ? u : 0.01f * u;
+      if (thresh) u *= drop_scale(seed, rstream, (unsigned long long)(i + j), thresh, inv_keep);
+      v[j] = u;
+    }
+    if (full) storev<T, VEC>(y + i, v);
+    else
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) if (i + j < n) y[i + j] = from_f<T>(v[j]);
+  }
+}
+
+// dx = dy * mask * act'(x)   (x = pre-activation, kept by the caller as the Linear's output)
+template <typename T, int VEC>
+__global__ void k_act_dropout_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long long n,
+                                  int act, unsigned thresh, float inv_keep, unsigned long long seed, unsigned rstream) {
+  long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * VEC;
+  long long stride = (long long)gridDim.x * blockDim.x * VEC;
+  for (; i < n; i += stride) {
+    const bool full = i + VEC <= n;
+    float v[VEC], g[VEC];
+    if (full) { loadv<T, VEC>(x + i, v); loadv<T, VEC>(dy + i, g); }
+    else
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { v[j] = i + j < n ? to_f<T>(x[i + j]) : 0.f; g[j] = i + j < n ? to_f<T>(dy[i + j]) : 0.f; }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float d = g[j];
+      if (act == 1) d = v[j] > 0.f ? d : 0.f;
+      else if (act == 2) d = v[j] > 0.f ? d : 0.01f * d;
+      if (thresh) d *= drop_scale(seed, rstream, (unsigned long long)(i + j), thresh, inv_keep);
+      g[j] = d;
+    }
+    if (full) storev<T, VEC>(dx + i, g);
+    else
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) if (i + j < n) dx[i + j] = from_f<T>(g[j]);
+  }
+}
+
+// y = alpha*a + beta*b  (edge update residual: fused.py:254 (.5,.5); tabgnn.py:190 (1,.5); x_tab merge fused.py:172)
+template <typename T, int VEC>
+__global__ void k_axpby(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n, float alpha,
+                        float beta) {
+  long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * VEC;
+  long long stride = (long long)gridDim.x * blockDim.x * VEC;
+  for (; i < n; i += stride) {
+    float u[VEC], v[VEC];
+    loadv<T, VEC>(a + i, u);
+    loadv<T, VEC>(b + i, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) u[j] = alpha * u[j] + beta * v[j];
+    storev<T, VEC>(y + i, u);
+  }
+}
+
+// CLS-token merge of the fused layer (fused.py:259-260): out = x_tab with token 0 <- (x_tab[:,0] + xf[:, :C]) / 2
+template <typename T, int VEC>
+__global__ void k_cls_merge_fwd(const T* __restrict__ xtab, const T* __restrict__ xf, T* __restrict__ out, long long B,
+                                int S, int C, int D) {
+  const int vpr = S * C / VEC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = B * vpr;
+  for (; i < total; i += stride) {
+    long long r = i / vpr;
+    int c = (int)(i % vpr) * VEC;
+    float v[VEC];
+    loadv<T, VEC>(xtab + r * S * C + c, v);
+    if (c < C) {
+      float t[VEC];
+      loadv<T, VEC>(xf + r * D + c, t);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = 0.5f * (v[j] + t[j]);
+    }
+    storev<T, VEC>(out + r * S * C + c, v);
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+#define DISPATCH_T(dt, ...)                       \
+  if ((dt) == F32) {                              \
+    using T = float;                              \
+    constexpr int VEC = 4;                        \
+    __VA_ARGS__                                   \
+  } else {                                        \
+    using T = bf16_t;                             \
+    constexpr int VEC = 8;                        \
+    __VA_ARGS__                                   \
+  }
+
+static int ln_geometry(int C, int vec, int& lpr, int& vpl) {
+  int nvec = C / vec;
+  lpr = 64;
+  while (lpr > 1 && (nvec % lpr != 0)) lpr >>= 1;
+  // prefer at most 64 lanes; odd factors (e.g. 48 = 16*3) go to VPL
+  vpl = nvec / lpr;
+  while (vpl > 4 && lpr < 64) { lpr <<= 1; vpl = (nvec + lpr - 1) / lpr; }
+  return vpl <= 4 ? 0 : 1;
+}
+
+extern "C" int tg_ln_partials_floats(int64_t M, int32_t C) { return 512 * 3 * C; }
+
+#define LN_LAUNCH(KERN, VPLV, ...)                                                      \
+  switch (VPLV) {                                                                       \
+    case 1: hipLaunchKernelGGL((KERN<T, VEC, 1>), __VA_ARGS__); break;                  \
+    case 2: hipLaunchKernelGGL((KERN<T, VEC, 2>), __VA_ARGS__); break;                  \
+    case 3: hipLaunchKernelGGL((KERN<T, VEC, 3>), __VA_ARGS__); break;                  \
+    default: hipLaunchKernelGGL((KERN<T, VEC, 4>), __VA_ARGS__); break;                 \
+  }
+
+extern "C" int tg_ln_fwd(const void* a, const void* b, const float* bias_b, const float* gamma, const float* beta,
+                         const void* res, void* out, float* stats, int64_t M, int32_t C, float eps, float alpha,
+                         float beta_c, float p_drop, uint64_t seed, uint32_t rstream, int32_t dt, void* stream) {
+  TG_CHECK(C % 8 == 0 && C <= 2048, "tg_ln_fwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
+  if (M == 0) return 0;
+  unsigned thresh = (b && p_drop > 0.f) ? drop_threshold(p_drop) : 0u;
+  float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  DISPATCH_T(dt, {
+    int lpr, vpl;
+    TG_CHECK(ln_geometry(C, VEC, lpr, vpl) == 0, "tg_ln_fwd: unsupported width C=%d", C);
+    int groups = LN_BLOCK / lpr;
+    int grid = grid_cap(ceil_div(M, groups), 256 * 16);
+    LN_LAUNCH(k_ln_fwd, vpl, dim3(grid), dim3(LN_BLOCK), 0, (hipStream_t)stream, (const T*)a, (const T*)b, bias_b,
+              gamma, beta, (const T*)res, (T*)out, stats, (long long)M, C, lpr, eps, alpha, beta_c, thresh, inv_keep,
+              (unsigned long long)seed, rstream);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// dparams: float[3*C] = (dgamma, dbeta, dbias_b) — written (not accumulated)
+extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* gamma, const float* stats,
+                         const void* dout, void* da, void* db, void* dres, float* dparams, float* partials, int64_t M,
+                         int32_t C, float alpha, float beta_c, float p_drop, uint64_t seed, uint32_t rstream,
+                         int32_t dt, void* stream) {
+  TG_CHECK(C % 8 == 0 && C <= 2048, "tg_ln_bwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    (void)hipMemsetAsync(dparams, 0, 3 * C * sizeof(float), st);
+    return 0;
+  }
+  unsigned thresh = (b && p_drop > 0.f) ? drop_threshold(p_drop) : 0u;
+  float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  int grid = 1;
+  DISPATCH_T(dt, {
+    int lpr, vpl;
+    TG_CHECK(ln_geometry(C, VEC, lpr, vpl) == 0, "tg_ln_bwd: unsupported width C=%d", C);
+    int groups = LN_BLOCK / lpr;
+    grid = grid_cap(ceil_div(M, groups), 512);
+    size_t shm = (size_t)groups * 3 * C * sizeof(float);
+    TG_CHECK(shm <= 160 * 1024, "tg_ln_bwd: LDS %zu too large", shm);
+    LN_LAUNCH(k_ln_bwd, vpl, dim3(grid), dim3(LN_BLOCK), shm, st, (const T*)a, (const T*)b, bias_b, gamma, stats,
+              (const T*)dout, (T*)da, (T*)db, (T*)dres, partials, (long long)M, C, lpr, alpha, beta_c, thresh, inv_keep,
+              (unsigned long long)seed, rstream);
+  })
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 256)), dim3(256), 0, st, partials, grid, 3 * C, dparams);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_bn_partials_floats(int64_t N, int32_t F) { return 512 * 2 * F; }
+
+// training=1: batch statistics (and running-stat update when running_* given); training=0: running statistics.
+// mean/rstd [F] are outputs kept for the backward.
+extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float* mean, float* rstd, void* out,
+                                 float* partials, int64_t N, int32_t F, int32_t training, float momentum, float eps,
+                                 int32_t relu, float alpha, float beta_c, int32_t dt, void* stream) {
+  TG_CHECK(F % 8 == 0 && F <= 1024 && N > 0, "tg_bn_act_res_fwd: bad F=%d N=%lld", F, (long long)N);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dt, {
+    TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_fwd: F/VEC must divide 256 (F=%d)", F);
+    if (training) {
+      int groups = 256 / (F / VEC);
+      int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
+      size_t shm = (size_t)groups * 2 * F * sizeof(float);
+      hipLaunchKernelGGL((k_col_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, partials, (long long)N, F, 0);
+      hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, st, partials, grid, (long long)N, F, eps,
+                         momentum, mean, rstd, running_mean, running_var);
+    } else {
+      hipLaunchKernelGGL(k_bn_eval_stats, dim3(ceil_div(F, 256)), dim3(256), 0, st, running_mean, running_var, F, eps,
+                         mean, rstd);
+    }
+    long long total = (long long)N * (F / VEC);
+    hipLaunchKernelGGL((k_bn_apply<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, st, (const T*)x,
+                       (const T*)res, mean, rstd, gamma, beta, (T*)out, (long long)N, F, relu, alpha, beta_c);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// dparams: float[2*F] = (dbeta_sum = sum dz, dgamma = sum dz*xhat)
+extern "C" int tg_bn_act_res_bwd(const void* x, const void* dout, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, void* dx, void* dres, float* dparams,
+                                 float* partials, int64_t N, int32_t F, int32_t training, int32_t relu, float alpha,
+                                 float beta_c, int32_t dt, void* stream) {
+  TG_CHECK(F % 8 == 0 && F <= 1024 && N > 0, "tg_bn_act_res_bwd: bad F=%d N=%lld", F, (long long)N);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dt, {
+    TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_bwd: F/VEC must divide 256 (F=%d)", F);
+    int groups = 256 / (F / VEC);
+    int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
+    size_t shm = (size_t)groups * 2 * F * sizeof(float);
+    hipLaunchKernelGGL((k_bn_bwd_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)dout, mean,
+                       rstd, gamma, beta, partials, (long long)N, F, relu, beta_c);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 256)), dim3(256), 0, st, partials, grid, 2 * F, dparams);
+    long long total = (long long)N * (F / VEC);
+    hipLaunchKernelGGL((k_bn_bwd_apply<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, st, (const T*)x,
+                       (const T*)dout, mean, rstd, gamma, beta, dparams, (T*)dx, (T*)dres, (long long)N, F, relu,
+                       training, alpha, beta_c);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_act_dropout_fwd(const void* x, void* y, int64_t n, int32_t act, float p_drop, uint64_t seed,
+                                  uint32_t rstream, int32_t dt, void* stream) {
+  if (n == 0) return 0;
+  unsigned thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((k_act_dropout_fwd<T, VEC>), dim3(grid_cap(ceil_div(ceil_div(n, VEC), 256))), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)x, (T*)y, (long long)n, act, thresh, inv_keep,
+                       (unsigned long long)seed, rstream);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_act_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t act, float p_drop,
+                                  uint64_t seed, uint32_t rstream, int32_t dt, void* stream) {
+  if (n == 0) return 0;
+  unsigned thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((k_act_dropout_bwd<T, VEC>), dim3(grid_cap(ceil_div(ceil_div(n, VEC), 256))), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, (long long)n, act, thresh, inv_keep,
+                       (unsigned long long)seed, rstream);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_axpby(const void* a, const void* b, void* y, int64_t n, float alpha, float beta, int32_t dt,
+                        void* stream) {
+  TG_CHECK(n % 8 == 0, "tg_axpby: n must be a multiple of 8 (n=%lld)", (long long)n);
+  if (n == 0) return 0;
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((k_axpby<T, VEC>), dim3(grid_cap(ceil_div(n / VEC, 256))), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)a, (const T*)b, (T*)y, (long long)n, alpha, beta);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_cls_merge_fwd(const void* xtab, const void* xf, void* out, int64_t B, int32_t S, int32_t C,
+                                int32_t D, int32_t dt, void* stream) {
+  TG_CHECK(C % 8 == 0 && D % 8 == 0, "tg_cls_merge_fwd: C, D must be multiples of 8");
+  if (B == 0) return 0;
+  DISPATCH_T(dt, {
+    long long total = (long long)B * (S * C / VEC);
+    hipLaunchKernelGGL((k_cls_merge_fwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)xtab, (const T*)xf, (T*)out, (long long)B, S, C, D);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}

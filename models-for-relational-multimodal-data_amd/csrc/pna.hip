@@ -1,0 +1,351 @@
+// PNA message passing on the sampled subgraph (torch_geometric 2.5.3 PNAConv as configured at
+// src/nn/models/fused.py:200-207; restated in oracle/pna.py):
+//   * gather-concat of node/edge rows (PNAConv.message input [x_i, x_j, e]; edge update fused.py:254;
+//     fuse input fused.py:257; ClassifierHead input decoder.py:18-19),
+//   * its backward as a deterministic segmented sum over the CSR (no atomics),
+//   * the multi-aggregation mean/max/min/std per destination ("the SpMM"; HBM-bound:
+//     E*(F*b+4) bytes read + N*4F*b bytes written per call) and its backward,
+//   * the degree-scaler combine (identity / amplification / attenuation) folded AFTER the post GEMM so the
+//     [N,12F] / [N,13F] tensors of the reference never exist.
+#include "common.hpp"
+#include "../../include/tabgnn_hip.h"
+
+namespace tg {
+
+struct GatherPart {
+  const void* src;
+  const int* idx;       // nullptr = identity
+  long long stride;     // elements between source rows
+  int width;            // elements copied
+  int relu;
+};
+
+template <typename T, int VEC>
+__global__ void k_gather_concat3(GatherPart p0, GatherPart p1, GatherPart p2, T* __restrict__ out, long long rows) {
+  const int W = p0.width + p1.width + p2.width;
+  const int vpr = W / VEC;
+  long long total = rows * vpr;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    long long r = i / vpr;
+    int c = (int)(i % vpr) * VEC;
+    const GatherPart& p = c < p0.width ? p0 : (c < p0.width + p1.width ? p1 : p2);
+    int cc = c < p0.width ? c : (c < p0.width + p1.width ? c - p0.width : c - p0.width - p1.width);
+    long long sr = p.idx ? (long long)p.idx[r] : r;
+    float v[VEC];
+    loadv<T, VEC>((const T*)p.src + sr * p.stride + cc, v);
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    storev<T, VEC>(out + r * W + c, v);
+  }
+}
+
+// dx[i, :] = sum_{q in segA(i)} g[rowA(q), offA:offA+F] + sum_{q in segB(i)} g[rowB(q), offB:offB+F]
+// seedB > 0: ONE CSR over 2*seedB slots; slot s < seedB reads (row s, offA), else (row s-seedB, offB).
+template <typename T, int VEC>
+__global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int offA, const int* __restrict__ rpA,
+                               const int* __restrict__ pmA, int offB, const int* __restrict__ rpB,
+                               const int* __restrict__ pmB, int seedB, const T* __restrict__ relu_src,
+                               T* __restrict__ dx, int N, int F) {
+  const int lpn = F / VEC;  // lanes per node
+  long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = (long long)N * lpn;
+  for (; gid < total; gid += stride) {
+    int n = (int)(gid / lpn), c = (int)(gid % lpn) * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    {
+      int s = rpA[n], e = rpA[n + 1];
+      for (int q = s; q < e; ++q) {
+        int row = pmA[q], off = offA;
+        if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
+        float t[VEC];
+        loadv<T, VEC>(g + (long long)row * gstride + off + c, t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+      }
+    }
+    if (rpB) {
+      int s = rpB[n], e = rpB[n + 1];
+      for (int q = s; q < e; ++q) {
+        float t[VEC];
+        loadv<T, VEC>(g + (long long)pmB[q] * gstride + offB + c, t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+      }
+    }
+    if (relu_src) {
+      float x[VEC];
+      loadv<T, VEC>(relu_src + (long long)n * F + c, x);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = x[j] > 0.f ? acc[j] : 0.f;
+    }
+    storev<T, VEC>(dx + (long long)n * F + c, acc);
+  }
+}
+
+// ------------------------------------------------------------------ multi-aggregation forward
+// One group of F/VEC lanes per destination node (16 lanes for bf16 F=128 -> 4 nodes per wave),
+// 16-byte loads of whole message rows in CSR order, single pass for sum, sum of squares, max, min.
+constexpr float STD_EPS = 1e-5f;
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__ h, const int* __restrict__ rowptr,
+                                                            const int* __restrict__ perm, T* __restrict__ agg, int N,
+                                                            int F) {
+  const int lpn = F / VEC;
+  long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = (long long)N * lpn;
+  for (; gid < total; gid += stride) {
+    int n = (int)(gid / lpn), c = (int)(gid % lpn) * VEC;
+    int s = rowptr[n], e = rowptr[n + 1];
+    float s1[VEC], s2[VEC], mx[VEC], mn[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; mx[j] = -INFINITY; mn[j] = INFINITY; }
+    int q = s;
+    for (; q + 1 < e; q += 2) {  // two rows in flight
+      float a[VEC], b[VEC];
+      int r0 = perm[q], r1 = perm[q + 1];
+      loadv<T, VEC>(h + (long long)r0 * F + c, a);
+      loadv<T, VEC>(h + (long long)r1 * F + c, b);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1[j] += a[j]; s2[j] += a[j] * a[j]; mx[j] = fmaxf(mx[j], a[j]); mn[j] = fminf(mn[j], a[j]);
+        s1[j] += b[j]; s2[j] += b[j] * b[j]; mx[j] = fmaxf(mx[j], b[j]); mn[j] = fminf(mn[j], b[j]);
+      }
+    }
+    if (q < e) {
+      float a[VEC];
+      loadv<T, VEC>(h + (long long)perm[q] * F + c, a);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        s1[j] += a[j]; s2[j] += a[j] * a[j]; mx[j] = fmaxf(mx[j], a[j]); mn[j] = fminf(mn[j], a[j]);
+      }
+    }
+    float mean[VEC], sd[VEC];
+    if (e > s) {
+      float inv = 1.f / (float)(e - s);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        mean[j] = s1[j] * inv;
+        float var = s2[j] * inv - mean[j] * mean[j];
+        float t = sqrtf(fmaxf(var, STD_EPS));
+        sd[j] = t <= sqrtf(STD_EPS) ? 0.f : t;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { mean[j] = 0.f; mx[j] = 0.f; mn[j] = 0.f; sd[j] = 0.f; }
+    }
+    T* o = agg + (long long)n * 4 * F + c;
+    storev<T, VEC>(o, mean);
+    storev<T, VEC>(o + F, mx);
+    storev<T, VEC>(o + 2 * F, mn);
+    storev<T, VEC>(o + 3 * F, sd);
+  }
+}
+
+// backward: dh[e] = g_mean/cnt + [h==max] g_max/ties + [h==min] g_min/ties + g_std (h-mean)/(cnt*std)
+// (ties share the gradient evenly, as torch.scatter_reduce amax/amin backward does)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_pna_aggregate_bwd(const T* __restrict__ h, const T* __restrict__ agg,
+                                                            const T* __restrict__ dagg, const int* __restrict__ rowptr,
+                                                            const int* __restrict__ perm, T* __restrict__ dh, int N,
+                                                            int F) {
+  const int lpn = F / VEC;
+  long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = (long long)N * lpn;
+  for (; gid < total; gid += stride) {
+    int n = (int)(gid / lpn), c = (int)(gid % lpn) * VEC;
+    int s = rowptr[n], e = rowptr[n + 1];
+    if (e == s) continue;
+    const T* a = agg + (long long)n * 4 * F + c;
+    const T* d = dagg + (long long)n * 4 * F + c;
+    float mean[VEC], mx[VEC], mn[VEC], sd[VEC], gm[VEC], gx[VEC], gn[VEC], gs[VEC];
+    loadv<T, VEC>(a, mean); loadv<T, VEC>(a + F, mx); loadv<T, VEC>(a + 2 * F, mn); loadv<T, VEC>(a + 3 * F, sd);
+    loadv<T, VEC>(d, gm); loadv<T, VEC>(d + F, gx); loadv<T, VEC>(d + 2 * F, gn); loadv<T, VEC>(d + 3 * F, gs);
+    float inv = 1.f / (float)(e - s);
+    float tx[VEC], tn[VEC];
+    if (e - s > 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { tx[j] = 0.f; tn[j] = 0.f; }
+      for (int q = s; q < e; ++q) {
+        float v[VEC];
+        loadv<T, VEC>(h + (long long)perm[q] * F + c, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { tx[j] += (v[j] == mx[j]); tn[j] += (v[j] == mn[j]); }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { tx[j] = 1.f; tn[j] = 1.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      gm[j] *= inv;
+      gx[j] = gx[j] / fmaxf(tx[j], 1.f);
+      gn[j] = gn[j] / fmaxf(tn[j], 1.f);
+      gs[j] = sd[j] > 0.f ? gs[j] * inv / sd[j] : 0.f;
+    }
+    for (int q = s; q < e; ++q) {
+      int row = perm[q];
+      float v[VEC], o[VEC];
+      loadv<T, VEC>(h + (long long)row * F + c, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j)
+        o[j] = gm[j] + (v[j] == mx[j] ? gx[j] : 0.f) + (v[j] == mn[j] ? gn[j] : 0.f) + gs[j] * (v[j] - mean[j]);
+      storev<T, VEC>(dh + (long long)row * F + c, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ degree-scaler combine
+// out = xw + G[:,0:F] + amp*G[:,F:2F] + att*G[:,2F:3F],  amp = log(deg+1)/avg, att = avg/log(max(deg,1)+1)
+__device__ __forceinline__ void scalers(const int* rowptr, int n, float avg_log, float& amp, float& att) {
+  float deg = (float)(rowptr[n + 1] - rowptr[n]);
+  amp = logf(deg + 1.f) / avg_log;
+  att = avg_log / logf(fmaxf(deg, 1.f) + 1.f);
+}
+
+template <typename T, int VEC>
+__global__ void k_scale_combine_fwd(const T* __restrict__ xw, const T* __restrict__ G, const int* __restrict__ rowptr,
+                                    const float* __restrict__ avg_log, T* __restrict__ out, int N, int F) {
+  const int vpr = F / VEC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = (long long)N * vpr;
+  float al = avg_log[0];
+  for (; i < total; i += stride) {
+    int n = (int)(i / vpr), c = (int)(i % vpr) * VEC;
+    float amp, att;
+    scalers(rowptr, n, al, amp, att);
+    float a[VEC], g0[VEC], g1[VEC], g2[VEC];
+    loadv<T, VEC>(xw + (long long)n * F + c, a);
+    const T* g = G + (long long)n * 3 * F + c;
+    loadv<T, VEC>(g, g0); loadv<T, VEC>(g + F, g1); loadv<T, VEC>(g + 2 * F, g2);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a[j] = a[j] + g0[j] + amp * g1[j] + att * g2[j];
+    storev<T, VEC>(out + (long long)n * F + c, a);
+  }
+}
+
+template <typename T, int VEC>
+__global__ void k_scale_combine_bwd(const T* __restrict__ gout, const int* __restrict__ rowptr,
+                                    const float* __restrict__ avg_log, T* __restrict__ dG, int N, int F) {
+  const int vpr = F / VEC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  long long total = (long long)N * vpr;
+  float al = avg_log[0];
+  for (; i < total; i += stride) {
+    int n = (int)(i / vpr), c = (int)(i % vpr) * VEC;
+    float amp, att;
+    scalers(rowptr, n, al, amp, att);
+    float g[VEC], g1[VEC], g2[VEC];
+    loadv<T, VEC>(gout + (long long)n * F + c, g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { g1[j] = amp * g[j]; g2[j] = att * g[j]; }
+    T* o = dG + (long long)n * 3 * F + c;
+    storev<T, VEC>(o, g); storev<T, VEC>(o + F, g1); storev<T, VEC>(o + 2 * F, g2);
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+#define DISPATCH_T(dt, ...)                       \
+  if ((dt) == F32) {                              \
+    using T = float;                              \
+    constexpr int VEC = 4;                        \
+    __VA_ARGS__                                   \
+  } else {                                        \
+    using T = bf16_t;                             \
+    constexpr int VEC = 8;                        \
+    __VA_ARGS__                                   \
+  }
+
+extern "C" int tg_gather_concat3(const void* a, const int32_t* ia, int64_t sa, int32_t wa, int32_t relu_a,
+                                 const void* b, const int32_t* ib, int64_t sb, int32_t wb, int32_t relu_b,
+                                 const void* c, const int32_t* ic, int64_t sc, int32_t wc, void* out, int64_t rows,
+                                 int32_t dt, void* stream) {
+  TG_CHECK(wa % 8 == 0 && wb % 8 == 0 && wc % 8 == 0 && sa % 8 == 0 && sb % 8 == 0 && sc % 8 == 0,
+           "tg_gather_concat3: widths/strides must be multiples of 8 (%d,%d,%d)", wa, wb, wc);
+  if (rows == 0) return 0;
+  GatherPart p0{a, ia, sa, wa, relu_a}, p1{b, ib, sb, wb, relu_b}, p2{c, ic, sc, wc, 0};
+  DISPATCH_T(dt, {
+    long long total = rows * ((wa + wb + wc) / VEC);
+    hipLaunchKernelGGL((k_gather_concat3<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0,
+                       (hipStream_t)stream, p0, p1, p2, (T*)out, (long long)rows);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA,
+                               int32_t offB, const int32_t* rpB, const int32_t* pmB, int32_t seedB,
+                               const void* relu_src, void* dx, int32_t N, int32_t F, int32_t dt, void* stream) {
+  TG_CHECK(F % 8 == 0 && offA % 8 == 0 && offB % 8 == 0 && gstride % 8 == 0, "tg_segment_sum2: misaligned F=%d", F);
+  TG_CHECK(rpA && pmA, "tg_segment_sum2: CSR A required");
+  DISPATCH_T(dt, {
+    long long total = (long long)N * (F / VEC);
+    hipLaunchKernelGGL((k_segment_sum2<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 16)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)g, (long long)gstride, offA, rpA, pmA, offB, rpB, pmB, seedB,
+                       (const T*)relu_src, (T*)dx, N, F);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const int32_t* perm, void* agg, int32_t N,
+                                    int32_t F, int32_t dt, void* stream) {
+  TG_CHECK(F % 8 == 0 && N > 0, "tg_pna_aggregate_fwd: F must be a multiple of 8 (F=%d)", F);
+  DISPATCH_T(dt, {
+    long long total = (long long)N * (F / VEC);
+    hipLaunchKernelGGL((k_pna_aggregate_fwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)h, rowptr, perm, (T*)agg, N, F);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_pna_aggregate_bwd(const void* h, const void* agg, const void* dagg, const int32_t* rowptr,
+                                    const int32_t* perm, void* dh, int32_t N, int32_t F, int32_t dt, void* stream) {
+  TG_CHECK(F % 8 == 0 && N > 0, "tg_pna_aggregate_bwd: F must be a multiple of 8 (F=%d)", F);
+  DISPATCH_T(dt, {
+    long long total = (long long)N * (F / VEC);
+    hipLaunchKernelGGL((k_pna_aggregate_bwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm, (T*)dh, N, F);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_pna_scale_combine_fwd(const void* xw, const void* G, const int32_t* rowptr, const float* avg_log,
+                                        void* out, int32_t N, int32_t F, int32_t dt, void* stream) {
+  TG_CHECK(F % 8 == 0, "tg_pna_scale_combine_fwd: F must be a multiple of 8 (F=%d)", F);
+  DISPATCH_T(dt, {
+    long long total = (long long)N * (F / VEC);
+    hipLaunchKernelGGL((k_scale_combine_fwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)xw, (const T*)G, rowptr, avg_log, (T*)out, N, F);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_pna_scale_combine_bwd(const void* gout, const int32_t* rowptr, const float* avg_log, void* dG,
+                                        int32_t N, int32_t F, int32_t dt, void* stream) {
+  TG_CHECK(F % 8 == 0, "tg_pna_scale_combine_bwd: F must be a multiple of 8 (F=%d)", F);
+  DISPATCH_T(dt, {
+    long long total = (long long)N * (F / VEC);
+    hipLaunchKernelGGL((k_scale_combine_bwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0,
+                       (hipStream_t)stream, (const T*)gout, rowptr, avg_log, (T*)dG, N, F);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}

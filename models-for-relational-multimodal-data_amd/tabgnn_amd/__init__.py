@@ -1,0 +1,19 @@
+"""tabgnn_amd — MI355X-native drop-in for the fused tabular-transformer + PNA hot path of
+Atahanak/models-for-relational-multimodal-data (``src/nn/models/fused.py`` behind ``utils.py:TABGNNFusedS``).
+
+Importing this package loads ``libtabgnn_hip.so`` (C ABI: ``include/tabgnn_hip.h``); it raises if the library
+is missing.  There is no CPU/eager fallback: tensors must live on a gfx950 device.
+"""
+from . import _lib
+
+_lib.load()
+
+from .encoders import (EmbeddingEncoder, LinearEncoder, ProjectionEncoder,  # noqa: E402
+                       StypeWiseFeatureEncoder, TimestampEncoder)
+from .frame import TensorFrame, stype  # noqa: E402
+from .heads import ClassifierHead, NodeClassificationHead  # noqa: E402
+from .layers import BatchNorm, ColumnTransformerLayer, PNAConv, PNAConvHetero  # noqa: E402
+from .models import (TABGNN, FTTransformerLayer, FTTransformerPNAFusedLayer, PNALayer,  # noqa: E402
+                     TABGNNFused)
+from .train import DataParallel, FlatParams, FusedAdam, train_step  # noqa: E402
+from .wrappers import TABGNNFusedS, TABGNNS, degree_histogram  # noqa: E402

@@ -1,0 +1,130 @@
+"""ctypes binding of libtabgnn_hip.so (C ABI declared in include/tabgnn_hip.h).
+
+The product path has NO fallback: if the library is missing or a kernel reports an error the
+call raises.  torch is used for device memory (caching allocator), streams and distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtabgnn_hip.so")
+ABI_VERSION = 1
+
+_vp, _i32, _i64, _f32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/tabgnn_hip.h one to one
+SIGNATURES = {
+    "tg_last_error": [],
+    "tg_abi_version": [],
+    "tg_device_check": [],
+    "tg_ids_to_i32": [_vp, _i64, _i32, _vp, _vp, _vp],
+    "tg_csr_workspace_ints": [_i64, _i32],
+    "tg_csr_build": [_vp, _i64, _i32, _vp, _vp, _vp, _vp],
+    "tg_encode_max_cols": [],
+    "tg_encode_small_table_rows": [],
+    "tg_encode_bwd_blocks": [],
+    "tg_encode_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "tg_encode_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "tg_attn_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp],
+    "tg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp],
+    "tg_ln_partials_floats": [_i64, _i32],
+    "tg_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _u64, _u32, _i32, _vp],
+    "tg_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _u64, _u32,
+                  _i32, _vp],
+    "tg_bn_partials_floats": [_i64, _i32],
+    "tg_bn_act_res_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _i32, _f32,
+                          _f32, _i32, _vp],
+    "tg_bn_act_res_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _i32,
+                          _vp],
+    "tg_act_dropout_fwd": [_vp, _vp, _i64, _i32, _f32, _u64, _u32, _i32, _vp],
+    "tg_act_dropout_bwd": [_vp, _vp, _vp, _i64, _i32, _f32, _u64, _u32, _i32, _vp],
+    "tg_axpby": [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp],
+    "tg_cls_merge_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "tg_gather_concat3": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64,
+                          _i32, _vp],
+    "tg_segment_sum2": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_pna_aggregate_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_pna_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_pna_scale_combine_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_pna_scale_combine_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "tg_seed_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "tg_weighted_ce_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
+    "tg_weighted_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
+    "tg_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],
+    "tg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+}
+_RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64}
+
+
+class EncCol(C.Structure):
+    _fields_ = [("kind", _i32), ("out_col", _i32), ("src_col", _i32), ("rows", _i32), ("tab_off", _i32),
+                ("acc_off", _i32), ("ts_slot", _i32), ("pad", _i32)]
+
+
+class EncDesc(C.Structure):
+    _fields_ = [("ncol", _i32), ("nts", _i32), ("col", EncCol * 16)]
+
+
+class EncPtrs(C.Structure):
+    _fields_ = [("num", _vp), ("nn", _i32), ("cat", _vp), ("nc", _i32), ("ts", _vp), ("nt", _i32), ("rel", _vp),
+                ("nr", _i32), ("num_mean", _vp), ("num_std", _vp), ("num_w", _vp), ("num_b", _vp),
+                ("cat_table", _vp), ("ts_min_year", _vp), ("ts_w", _vp), ("ts_b", _vp), ("rel_w", _vp),
+                ("rel_b", _vp)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C models-for-relational-multimodal-data_amd` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.tg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libtabgnn_hip ABI {lib.tg_abi_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib.tg_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous CUDA(HIP) tensors."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("tabgnn_amd ops need tensors on the MI355X (got a CPU tensor); there is no CPU path")
+    if not t.is_contiguous():
+        raise RuntimeError("tabgnn_amd ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise RuntimeError(f"unsupported activation dtype {t.dtype} (float32 or bfloat16)")

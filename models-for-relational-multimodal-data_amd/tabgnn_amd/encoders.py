@@ -1,0 +1,250 @@
+"""Stype-wise column encoders with the pytorch-frame module/state-dict layout, executed by one HIP kernel.
+
+Mirrors ``torch_frame.nn`` ``StypeWiseFeatureEncoder`` + ``EmbeddingEncoder`` / ``LinearEncoder`` /
+``TimestampEncoder`` / (fork) ``ProjectionEncoder`` as the reference configures them
+(``src/datasets/ibm_transactions_for_aml.py:283-294,313-319``) and calls them
+(``utils.py:357-359``: ``encoder(tf) -> (Tensor[R, ncols, C], col_names)``).
+Parameter names follow upstream: ``encoder_dict.<stype>.…``.  Semantics restated in ``oracle/encoders.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from .frame import STYPE_ORDER, TensorFrame, stype
+
+KIND = {stype.numerical: 0, stype.categorical: 1, stype.timestamp: 2, stype.relation: 3}
+TS_FIELDS, TS_OUT = 7, 8
+
+
+class LinearEncoder(nn.Module):
+    """numerical: ((v - mean_c) / std_c) * w_c + b_c."""
+
+    def __init__(self, out_channels, means, stds):
+        super().__init__()
+        n = len(means)
+        self.register_buffer("mean", torch.tensor(means, dtype=torch.float32))
+        self.register_buffer("std", torch.tensor(stds, dtype=torch.float32) + 1e-6)
+        self.weight = nn.Parameter(torch.empty(n, out_channels))
+        self.bias = nn.Parameter(torch.empty(n, out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.normal_(self.weight, std=0.01)
+        nn.init.zeros_(self.bias)
+
+
+class EmbeddingEncoder(nn.Module):
+    """categorical: Embedding(card+1, C, padding_idx=0)(idx + 1) per column (``embs.<i>.weight``)."""
+
+    def __init__(self, out_channels, cardinalities):
+        super().__init__()
+        self.embs = nn.ModuleList([nn.Embedding(c + 1, out_channels, padding_idx=0) for c in cardinalities])
+
+    def reset_parameters(self):
+        for e in self.embs:
+            e.reset_parameters()
+
+
+class TimestampEncoder(nn.Module):
+    """timestamp: positional (year - min_year) / cyclic (month..second) features, out_size 8, contracted with
+    ``weight [ncol, 7, 8, C]`` + ``bias``."""
+
+    def __init__(self, out_channels, min_years):
+        super().__init__()
+        n = len(min_years)
+        self.register_buffer("min_year", torch.tensor(min_years, dtype=torch.float32))
+        self.register_buffer("max_values", torch.tensor([12., 31., 7., 24., 60., 60.]))
+        self.weight = nn.Parameter(torch.empty(n, TS_FIELDS, TS_OUT, out_channels))
+        self.bias = nn.Parameter(torch.empty(n, out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.normal_(self.weight, std=0.01)
+        nn.init.zeros_(self.bias)
+
+
+class ProjectionEncoder(nn.Module):
+    """relation (fork-only, semantics restated): v * w_c + b_c."""
+
+    def __init__(self, out_channels, ncols):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(ncols, out_channels))
+        self.bias = nn.Parameter(torch.empty(ncols, out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.normal_(self.weight, std=0.01)
+        nn.init.zeros_(self.bias)
+
+
+class _Encode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, feats, out_dtype, *params):
+        # params order: num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b (None where the stype is absent)
+        plan = enc._plan
+        R = next(iter(feats.values())).shape[0]
+        dev = next(iter(feats.values())).device
+        Cc = enc.out_channels
+        out = torch.empty(R, plan["ncols"], Cc, dtype=out_dtype, device=dev)
+        ptrs = enc._ptrs(feats, params)
+        for desc in plan["descs"]:
+            L.call("tg_encode_fwd", C.addressof(desc), C.addressof(ptrs), L.ptr(out), R, plan["ncols"], Cc,
+                   L.dt(out), L.stream())
+        ctx.enc, ctx.feats, ctx.params, ctx.R = enc, feats, params, R
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        enc, feats, params, R = ctx.enc, ctx.feats, ctx.params, ctx.R
+        plan = enc._plan
+        g = g.contiguous()
+        dev = g.device
+        Cc = enc.out_channels
+        ptrs = enc._ptrs(feats, params)
+        num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b = params
+        grads = [None if p is None else torch.zeros_like(p) for p in params]
+        nblk = L.load().tg_encode_bwd_blocks()
+        for desc, acc_floats, segs in zip(plan["descs"], plan["acc_floats"], plan["segments"]):
+            dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
+            partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
+            L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), L.ptr(g), R, plan["ncols"], Cc, acc_floats,
+                   L.ptr(dflat), L.ptr(partials), L.ptr(grads[2]), L.dt(g), L.stream())
+            for kind, src_col, off, rows, tab_off in segs:
+                if kind == 0:
+                    grads[0][src_col] = dflat[off:off + Cc]; grads[1][src_col] = dflat[off + Cc:off + 2 * Cc]
+                elif kind == 3:
+                    grads[5][src_col] = dflat[off:off + Cc]; grads[6][src_col] = dflat[off + Cc:off + 2 * Cc]
+                elif kind == 2:
+                    grads[3][src_col] = dflat[off:off + 56 * Cc].view(TS_FIELDS, TS_OUT, Cc)
+                    grads[4][src_col] = dflat[off + 56 * Cc:off + 57 * Cc]
+                elif off >= 0:
+                    grads[2][tab_off:tab_off + rows] = dflat[off:off + rows * Cc].view(rows, Cc)
+        return (None, None, None, *grads)
+
+
+class StypeWiseFeatureEncoder(nn.Module):
+    """``encoder(tf) -> (x [R, ncols, C], col_names)``; columns ordered numerical, categorical, timestamp, relation."""
+
+    def __init__(self, out_channels, col_stats, col_names_dict, compute_dtype=torch.float32):
+        """col_stats[name]: numerical {'mean','std'}; categorical {'cardinality'}; timestamp {'min_year'}."""
+        super().__init__()
+        self.out_channels = out_channels
+        self.col_names_dict = {s: list(col_names_dict[s]) for s in STYPE_ORDER if s in col_names_dict}
+        self.compute_dtype = compute_dtype
+        self.encoder_dict = nn.ModuleDict()
+        for s, names in self.col_names_dict.items():
+            if s == stype.numerical:
+                m = LinearEncoder(out_channels, [col_stats[n]["mean"] for n in names], [col_stats[n]["std"] for n in names])
+            elif s == stype.categorical:
+                m = EmbeddingEncoder(out_channels, [col_stats[n]["cardinality"] for n in names])
+            elif s == stype.timestamp:
+                m = TimestampEncoder(out_channels, [col_stats[n]["min_year"] for n in names])
+            else:
+                m = ProjectionEncoder(out_channels, len(names))
+            self.encoder_dict[s.value] = m
+        self._plan = self._make_plan()
+
+    def reset_parameters(self):
+        for m in self.encoder_dict.values():
+            m.reset_parameters()
+
+    # ------------------------------------------------------------------ launch plan (host structs)
+    def _make_plan(self):
+        lib = L.load()
+        max_cols, small = lib.tg_encode_max_cols(), lib.tg_encode_small_table_rows()
+        Cc = self.out_channels
+        cols, out_col, tab_off = [], 0, 0
+        for s, names in self.col_names_dict.items():
+            for i, _ in enumerate(names):
+                rows = 0
+                toff = 0
+                if s == stype.categorical:
+                    rows = self.encoder_dict["categorical"].embs[i].num_embeddings
+                    toff = tab_off
+                    tab_off += rows
+                cols.append(dict(kind=KIND[s], out_col=out_col, src_col=i, rows=rows, tab_off=toff))
+                out_col += 1
+        budget = 100 * 1024 // 4          # floats of LDS accumulators per launch (feats + acc <= 150 KiB)
+        groups, cur, cur_f = [], [], 0
+        for c in cols:
+            need = {0: 2 * Cc, 3: 2 * Cc, 2: 57 * Cc}.get(c["kind"], c["rows"] * Cc if c["rows"] <= small else 0)
+            if cur and (len(cur) == max_cols or cur_f + need > budget):
+                groups.append(cur); cur, cur_f = [], 0
+            cur.append(c); cur_f += need
+        if cur:
+            groups.append(cur)
+        descs, accs, segments = [], [], []
+        for grp in groups:
+            d = L.EncDesc()
+            d.ncol = len(grp)
+            off, nts, segs = 0, 0, []
+            for j, c in enumerate(grp):
+                e = d.col[j]
+                e.kind, e.out_col, e.src_col, e.rows, e.tab_off = c["kind"], c["out_col"], c["src_col"], c["rows"], c["tab_off"]
+                e.ts_slot = 0
+                if c["kind"] == 2:
+                    e.ts_slot = nts; nts += 1
+                    need = 57 * Cc
+                elif c["kind"] == 1:
+                    need = c["rows"] * Cc if c["rows"] <= small else 0
+                else:
+                    need = 2 * Cc
+                e.acc_off = off if need > 0 else -1
+                segs.append((c["kind"], c["src_col"], e.acc_off, c["rows"], c["tab_off"]))
+                off += need
+            d.nts = nts
+            descs.append(d); accs.append(off); segments.append(segs)
+        return dict(ncols=out_col, descs=descs, acc_floats=accs, segments=segments)
+
+    def _cat_table(self):
+        embs = self.encoder_dict["categorical"].embs
+        return torch.cat([e.weight for e in embs], dim=0) if len(embs) > 1 else embs[0].weight
+
+    def _ptrs(self, feats, params):
+        num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b = params
+        p = L.EncPtrs()
+        ed = self.encoder_dict
+
+        def raw(s, dtype):
+            if s not in feats:
+                return None, 0
+            t = feats[s]
+            if t.dtype != dtype or not t.is_contiguous():
+                t = t.to(dtype).contiguous()
+                feats[s] = t
+            return L.ptr(t), t.shape[1]
+        p.num, p.nn = raw(stype.numerical, torch.float32)
+        p.cat, p.nc = raw(stype.categorical, torch.int64)
+        p.ts, p.nt = raw(stype.timestamp, torch.int64)
+        p.rel, p.nr = raw(stype.relation, torch.float32)
+        if "numerical" in ed:
+            p.num_mean, p.num_std = L.ptr(ed["numerical"].mean), L.ptr(ed["numerical"].std)
+            p.num_w, p.num_b = L.ptr(num_w), L.ptr(num_b)
+        if "categorical" in ed:
+            p.cat_table = L.ptr(cat_table)
+        if "timestamp" in ed:
+            p.ts_min_year, p.ts_w, p.ts_b = L.ptr(ed["timestamp"].min_year), L.ptr(ts_w), L.ptr(ts_b)
+        if "relation" in ed:
+            p.rel_w, p.rel_b = L.ptr(rel_w), L.ptr(rel_b)
+        return p
+
+    def forward(self, tf: TensorFrame):
+        ed = self.encoder_dict
+        feats = {s: tf.feat_dict[s] for s in self.col_names_dict}
+        params = [
+            ed["numerical"].weight if "numerical" in ed else None,
+            ed["numerical"].bias if "numerical" in ed else None,
+            self._cat_table() if "categorical" in ed else None,
+            ed["timestamp"].weight if "timestamp" in ed else None,
+            ed["timestamp"].bias if "timestamp" in ed else None,
+            ed["relation"].weight if "relation" in ed else None,
+            ed["relation"].bias if "relation" in ed else None,
+        ]
+        x = _Encode.apply(self, feats, self.compute_dtype, *params)
+        names = [n for s in self.col_names_dict for n in self.col_names_dict[s]]
+        return x, names

@@ -1,0 +1,175 @@
+"""Building blocks with the reference's module/parameter names, running on the HIP operators.
+
+* ``ColumnTransformerLayer`` — state-dict compatible with ``torch.nn.TransformerEncoderLayer(d_model=C, nhead,
+  dim_feedforward, dropout, 'relu', batch_first=True)`` as built at ``src/nn/models/fused.py:83-92,187-196``.
+* ``PNAConv`` / ``BatchNorm`` — state-dict compatible with torch_geometric 2.5.3 (``fused.py:204-214``).
+* ``PNAConvHetero`` — ``src/nn/gnn/pna.py:17-46``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+class Linear(nn.Linear):
+    """nn.Linear parameters, HIP-path forward (also stands in for ``torch_geometric.nn.Linear``)."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x, res=None, alpha=0.0, beta_c=1.0):
+        return ops.layer_norm(x, self.weight, self.bias, res=res, eps=self.eps, alpha=alpha, beta_c=beta_c)
+
+
+class _SelfAttention(nn.Module):
+    """Parameter holder named like ``nn.MultiheadAttention`` (packed in-projection + ``out_proj``)."""
+
+    def __init__(self, channels, nhead):
+        super().__init__()
+        self.num_heads = nhead
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * channels, channels))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * channels))
+        self.out_proj = nn.Linear(channels, channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.in_proj_bias)
+        self.out_proj.reset_parameters()
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class ColumnTransformerLayer(nn.Module):
+    """Post-norm encoder layer over the S column tokens of each row: [R,S,C] -> [R,S,C]."""
+
+    def __init__(self, channels, nhead, dim_feedforward=None, dropout=0.5, activation="relu"):
+        super().__init__()
+        if activation != "relu":
+            raise ValueError("only the reference's activation='relu' is implemented")
+        if channels % nhead != 0 or (channels // nhead) not in (4, 8, 16, 32, 64):
+            raise ValueError(f"head dim {channels}/{nhead} unsupported (need 4/8/16/32/64)")
+        ff = dim_feedforward or channels
+        self.nhead, self.p = nhead, dropout
+        self.self_attn = _SelfAttention(channels, nhead)
+        self.linear1 = nn.Linear(channels, ff)
+        self.linear2 = nn.Linear(ff, channels)
+        self.norm1 = nn.LayerNorm(channels, eps=1e-5)
+        self.norm2 = nn.LayerNorm(channels, eps=1e-5)
+
+    def forward(self, x):
+        p = self.p if self.training else 0.0
+        sa = self.self_attn
+        qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        o = ops.attention_core(qkv, self.nhead, p)
+        y = ops.linear(o, sa.out_proj.weight, None)
+        x1 = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, b=y, bias_b=sa.out_proj.bias, p_drop=p)
+        h = ops.act_dropout(ops.linear(x1, self.linear1.weight, self.linear1.bias), "relu", p)
+        y2 = ops.linear(h, self.linear2.weight, None)
+        return ops.layer_norm(x1, self.norm2.weight, self.norm2.bias, b=y2, bias_b=self.linear2.bias, p_drop=p)
+
+
+class BatchNorm(nn.Module):
+    """torch_geometric ``BatchNorm``: wraps ``BatchNorm1d`` as ``module`` (state-dict ``module.*``)."""
+
+    def __init__(self, in_channels, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.module = nn.BatchNorm1d(in_channels, eps, momentum)
+
+    def reset_parameters(self):
+        self.module.reset_parameters()
+
+    def forward(self, x, res=None, relu=False, alpha=0.0, beta_c=1.0):
+        m = self.module
+        training = self.training and x.shape[0] > 1
+        out = ops.batch_norm_act_res(x, m.weight, m.bias, m.running_mean, m.running_var, training, res=res,
+                                     momentum=m.momentum, eps=m.eps, relu=relu, alpha=alpha, beta_c=beta_c)
+        if training:
+            m.num_batches_tracked += 1
+        return out
+
+
+class _DegreeScalerBuffers(nn.Module):
+    def __init__(self, deg):
+        super().__init__()
+        h = deg.to(torch.float)
+        n = float(h.sum())
+        bins = torch.arange(h.numel(), dtype=torch.float)
+        self.register_buffer("avg_deg_lin", torch.tensor([float((bins * h).sum()) / n]))
+        self.register_buffer("avg_deg_log", torch.tensor([float(((bins + 1).log() * h).sum()) / n]))
+
+
+class PNAConv(nn.Module):
+    """PNAConv(F, F, ['mean','max','min','std'], ['identity','amplification','attenuation'], deg, edge_dim=F,
+    towers=1, pre_layers=1, post_layers=1, divide_input=False).
+
+    Linear maps with nothing between them are folded on the (tiny) weights each call, so no E- or N-scale
+    intermediate exists for them: edge_encoder into the message projection, ``lin`` into the post projection;
+    the degree scalers are applied after the post GEMM (``[N,12F]`` never materialises)."""
+
+    def __init__(self, in_channels, out_channels, aggregators, scalers, deg, edge_dim=None, towers=1, pre_layers=1,
+                 post_layers=1, divide_input=False, **kw):
+        super().__init__()
+        if (list(aggregators) != ["mean", "max", "min", "std"]
+                or list(scalers) != ["identity", "amplification", "attenuation"] or towers != 1 or pre_layers != 1
+                or post_layers != 1 or divide_input or edge_dim is None or in_channels != out_channels):
+            raise ValueError("PNAConv: only the reference's configuration (fused.py:200-207) is implemented")
+        F = in_channels
+        self.F = F
+        self.aggr_module = _DegreeScalerBuffers(deg)
+        self.edge_encoder = nn.Linear(edge_dim, F)
+        self.pre_nns = nn.ModuleList([nn.Sequential(nn.Linear(3 * F, F))])
+        self.post_nns = nn.ModuleList([nn.Sequential(nn.Linear(13 * F, out_channels))])
+        self.lin = nn.Linear(out_channels, out_channels)
+
+    def reset_parameters(self):
+        for m in (self.edge_encoder, self.pre_nns[0][0], self.post_nns[0][0], self.lin):
+            m.reset_parameters()
+
+    def forward(self, x, edge_index, edge_attr):
+        F = self.F
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        pre, post = self.pre_nns[0][0], self.post_nns[0][0]
+        # message: W_pre [x_i, x_j, W_e e + b_e] + b_pre
+        w3 = pre.weight[:, 2 * F:] @ self.edge_encoder.weight
+        w_msg = torch.cat([pre.weight[:, :2 * F], w3], dim=1)
+        b_msg = pre.bias + pre.weight[:, 2 * F:] @ self.edge_encoder.bias
+        h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst"), w_msg, b_msg)
+        agg = ops.pna_aggregate(h, g)                                   # [N,4F]
+        # lin(post([x, agg, amp*agg, att*agg])) = x Wx^T + b + (agg Wid^T) + amp (agg Wamp^T) + att (agg Watt^T)
+        w_eff = self.lin.weight @ post.weight                            # [F,13F]
+        b_eff = self.lin.weight @ post.bias + self.lin.bias
+        xw = ops.linear(x, w_eff[:, :F], b_eff)
+        w_st = torch.cat([w_eff[:, F:5 * F], w_eff[:, 5 * F:9 * F], w_eff[:, 9 * F:]], dim=0)   # [3F,4F]
+        G = ops.linear(agg, w_st, None)
+        return ops.pna_scale_combine(xw, G, g, self.aggr_module.avg_deg_log)
+
+
+class PNAConvHetero(nn.Module):
+    """Forward + reverse message passing (src/nn/gnn/pna.py:17-46)."""
+
+    def __init__(self, n_hidden, in_channels, out_channels, aggregators, scalers, deg, edge_dim, towers=1,
+                 pre_layers=1, post_layers=1, divide_input=False):
+        super().__init__()
+        kw = dict(in_channels=in_channels, out_channels=out_channels, aggregators=aggregators, scalers=scalers, deg=deg,
+                  edge_dim=edge_dim, towers=towers, pre_layers=pre_layers, post_layers=post_layers,
+                  divide_input=divide_input)
+        self.conv_forw = PNAConv(**kw)
+        self.conv_back = PNAConv(**kw)
+        self.lin = Linear(n_hidden * 3, n_hidden)
+
+    def reset_parameters(self):
+        self.conv_forw.reset_parameters()
+        self.conv_back.reset_parameters()
+        self.lin.reset_parameters()
+
+    def forward(self, x, edge_index, edge_attr):
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        a_in = self.conv_forw(x, g, edge_attr)
+        a_out = self.conv_back(x, g.flip(), edge_attr)
+        return self.lin(torch.cat([x, a_in, a_out], dim=1))

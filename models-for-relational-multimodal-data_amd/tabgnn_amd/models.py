@@ -1,0 +1,261 @@
+"""Backbones with the reference's constructor arguments, forward signatures and state-dict names.
+
+* ``TABGNNFused`` / ``FTTransformerPNAFusedLayer`` — ``src/nn/models/fused.py:31-269``
+* ``TABGNN`` / ``PNALayer`` / ``FTTransformerLayer`` — ``src/nn/models/tabgnn.py:27-219``
+Drop-in: ``from tabgnn_amd import TABGNNFused`` replaces ``from src.nn.models import TABGNNFused``
+(``utils.py:16``, ``fused.py:20``); ``load_state_dict`` accepts the reference's checkpoints.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .layers import BatchNorm, ColumnTransformerLayer, PNAConv, PNAConvHetero
+
+_AGGR = ["mean", "max", "min", "std"]
+_SCAL = ["identity", "amplification", "attenuation"]
+
+
+def _make_conv(nhidden, deg, reverse_mp):
+    kw = dict(in_channels=nhidden, out_channels=nhidden, aggregators=_AGGR, scalers=_SCAL, deg=deg, edge_dim=nhidden,
+              towers=1, pre_layers=1, post_layers=1, divide_input=False)
+    return PNAConvHetero(n_hidden=nhidden, **kw) if reverse_mp else PNAConv(**kw)
+
+
+def _xavier_matrices(module):
+    for p in module.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class _PrependCLS(torch.autograd.Function):
+    """[cls | row] per table row (fused.py:158-159,162-163) without a broadcast temp: one gather-concat launch."""
+
+    @staticmethod
+    def forward(ctx, cls, rows):
+        R, ncols, C = rows.shape
+        rows = rows.contiguous()
+        c = cls.detach().to(rows.dtype).contiguous().view(1, C)
+        flat = rows.view(R, ncols * C)
+        out = torch.empty(R, (ncols + 1) * C, dtype=rows.dtype, device=rows.device)
+        from . import _lib as L
+        L.call("tg_gather_concat3", c.data_ptr(), None, 0, C, 0, flat.data_ptr(), None, ncols * C, ncols * C, 0,
+               flat.data_ptr(), None, ncols * C, 0, L.ptr(out), R, L.dt(out), L.stream())
+        ctx.C = C
+        return out.view(R, ncols + 1, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        C = ctx.C
+        dcls = g[:, 0, :].sum(0, dtype=torch.float32)
+        return dcls, g[:, 1:, :].contiguous()
+
+
+def prepend_cls(cls, rows):
+    return _PrependCLS.apply(cls, rows)
+
+
+class FTTransformerPNAFusedLayer(nn.Module):
+    def __init__(self, channels: int, nhead: int, feedforward_channels: Optional[int] = None, dropout: float = 0.5,
+                 activation: str = "relu", nhidden: int = 128, deg=None, reverse_mp: bool = False) -> None:
+        super().__init__()
+        self.channels, self.nhidden, self.p = channels, nhidden, dropout
+        D = channels + 2 * nhidden
+        self.tab_conv = ColumnTransformerLayer(channels, nhead, feedforward_channels, dropout, activation)
+        self.tab_norm = nn.LayerNorm(channels)
+        self.gnn_conv = _make_conv(nhidden, deg, reverse_mp)
+        self.gnn_norm = BatchNorm(nhidden)
+        self.gnn_edge_update = nn.Sequential(nn.Linear(3 * nhidden, nhidden), nn.ReLU(), nn.Linear(nhidden, nhidden))
+        self.fuse = nn.Sequential(nn.LayerNorm(D), nn.Linear(D, 4 * D), nn.LeakyReLU(), nn.Dropout(dropout),
+                                  nn.Linear(4 * D, 4 * D), nn.LeakyReLU(), nn.Dropout(dropout), nn.Linear(4 * D, D))
+        self.fuse_norm = nn.LayerNorm(D)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _xavier_matrices(self.tab_conv)
+        self.tab_norm.reset_parameters()
+        self.gnn_conv.reset_parameters()
+        self.gnn_norm.reset_parameters()
+        _xavier_matrices(self.gnn_edge_update)
+        _xavier_matrices(self.fuse)
+        self.fuse_norm.reset_parameters()
+
+    def forward(self, x_tab, x_gnn, edge_index, edge_attr, target_edge_index, lp=False):
+        N = x_gnn.shape[0]
+        g = ops.SubgraphIndex.build(edge_index, N)
+        p = self.p if self.training else 0.0
+        # x_tab + LN(enc(x_tab)) / 2   (sic, fused.py:249)
+        t = self.tab_conv(x_tab)
+        x_tab = ops.layer_norm(t, self.tab_norm.weight, self.tab_norm.bias, res=x_tab, alpha=1.0, beta_c=0.5)
+        # (x_gnn + relu(BN(PNA))) / 2   (fused.py:252)
+        conv = self.gnn_conv(x_gnn, g, edge_attr)
+        x_gnn = self.gnn_norm(conv, res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
+        # (e + MLP([x[src], x[dst], e])) / 2   (fused.py:253-254)
+        up0, up2 = self.gnn_edge_update[0], self.gnn_edge_update[2]
+        m = ops.act_dropout(ops.linear(ops.edge_gather(x_gnn, edge_attr, g, "src"), up0.weight, up0.bias), "relu", 0.0)
+        edge_attr = ops.axpby(edge_attr, ops.linear(m, up2.weight, up2.bias), 0.5, 0.5)
+        if not lp:
+            seeds = ops.SeedIndex(target_edge_index, N)
+            f = self.fuse
+            xf0 = ops.seed_gather(x_gnn, x_tab, seeds, "fuse")                      # [cls_tab, x[src], x[dst]]
+            h = ops.layer_norm(xf0, f[0].weight, f[0].bias)
+            h = ops.act_dropout(ops.linear(h, f[1].weight, f[1].bias), "leaky_relu", p)
+            h = ops.act_dropout(ops.linear(h, f[4].weight, f[4].bias), "leaky_relu", p)
+            h = ops.linear(h, f[7].weight, f[7].bias)
+            xf = ops.layer_norm(h, self.fuse_norm.weight, self.fuse_norm.bias, res=xf0, alpha=0.5, beta_c=0.5)
+            x_tab = ops.cls_merge(x_tab, xf)                                        # fused.py:259-260
+            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels)                  # fused.py:261-268
+        return x_tab, x_gnn, edge_attr
+
+
+class TABGNNFused(nn.Module):
+    def __init__(self, channels: int, num_layers: int, encoder=None, deg=None, node_dim: int = 1, nhidden: int = 128,
+                 edge_dim: int = None, reverse_mp: bool = False, feedforward_channels: Optional[int] = None,
+                 nhead: int = 8, dropout: float = 0.5, activation: str = "relu") -> None:
+        super().__init__()
+        if num_layers <= 0:
+            raise ValueError(f"num_layers must be a positive integer (got {num_layers})")
+        self.channels, self.nhidden, self.node_dim = channels, nhidden, node_dim
+        self.edge_dim = edge_dim + channels
+        self.encoder, self.reverse_mp = encoder, reverse_mp
+        self.cls_embedding = nn.Parameter(torch.empty(channels))
+        self.node_emb = nn.Linear(node_dim, nhidden)
+        self.edge_emb = nn.Linear(self.edge_dim, nhidden)
+        self.tab_conv = ColumnTransformerLayer(channels, nhead, feedforward_channels, dropout, activation)
+        self.tab_norm = nn.LayerNorm(channels)
+        self.backbone = nn.ModuleList([
+            FTTransformerPNAFusedLayer(channels, nhead, feedforward_channels, dropout, activation, nhidden, deg,
+                                       reverse_mp) for _ in range(num_layers)])
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.normal_(self.cls_embedding, std=0.01)
+        self.node_emb.reset_parameters()
+        self.edge_emb.reset_parameters()
+        self.tab_norm.reset_parameters()
+        _xavier_matrices(self.tab_conv)
+        for layer in self.backbone:
+            layer.reset_parameters()
+
+    def get_shared_params(self):
+        groups = [self.encoder.parameters() if self.encoder is not None else [], self.tab_conv.parameters(),
+                  self.tab_norm.parameters(), [self.cls_embedding], self.node_emb.parameters(),
+                  self.edge_emb.parameters(), self.backbone.parameters()]
+        return [p for grp in groups for p in grp]
+
+    def zero_grad_shared_params(self):
+        for p in self.get_shared_params():
+            if p.grad is not None:
+                p.grad.data.zero_()
+
+    def forward(self, x, edge_index, edge_attr, target_edge_index, target_edge_attr, lp=False):
+        """x [N, n_node_feats, C]; edge_index int64 [2,E_n]; edge_attr [E_n, ncols, C]; target_edge_index int64
+        [2,B]; target_edge_attr [B, ncols, C] -> (x_gnn [N,F], edge_attr [E_n,F], target_edge_attr [B,F])."""
+        N = x.shape[0]
+        g = ops.SubgraphIndex.build(edge_index, N)
+        seeds = ops.SeedIndex(target_edge_index, N) if not lp else target_edge_index
+        tn = self.tab_norm
+        x_gnn = ops.linear(x.reshape(-1, self.node_dim), self.node_emb.weight, self.node_emb.bias)
+
+        t0 = prepend_cls(self.cls_embedding, target_edge_attr)
+        target = ops.layer_norm(self.tab_conv(t0), tn.weight, tn.bias)                       # fused.py:160
+        e0 = prepend_cls(self.cls_embedding, edge_attr)
+        e = ops.layer_norm(self.tab_conv(e0), tn.weight, tn.bias, res=e0, alpha=0.5, beta_c=0.5)   # :164
+        e = ops.linear(e.reshape(-1, self.edge_dim), self.edge_emb.weight, self.edge_emb.bias)     # :165-166
+
+        x_tab = target
+        for layer in self.backbone:
+            x_tab, x_gnn, e = layer(x_tab, x_gnn, g, e, seeds, lp)
+
+        t_out = ops.axpby(x_tab, target, 0.5, 0.5).reshape(-1, self.edge_dim)                # :172-173
+        t_out = ops.linear(t_out, self.edge_emb.weight, self.edge_emb.bias)
+        return x_gnn, e, t_out
+
+
+# --------------------------------------------------------------------------------------- non-fused TABGNN
+
+
+class FTTransformerLayer(nn.Module):
+    def __init__(self, channels, nhead, feedforward_channels=None, dropout=0.5, activation="relu", nhidden=128):
+        super().__init__()
+        self.tab_conv = ColumnTransformerLayer(channels, nhead, feedforward_channels, dropout, activation)
+        self.tab_norm = nn.LayerNorm(channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _xavier_matrices(self.tab_conv)
+        self.tab_norm.reset_parameters()
+
+    def forward(self, x_tab):                                                               # tabgnn.py:218-219
+        return ops.layer_norm(self.tab_conv(x_tab), self.tab_norm.weight, self.tab_norm.bias, res=x_tab, alpha=0.5,
+                              beta_c=0.5)
+
+
+class PNALayer(nn.Module):
+    def __init__(self, channels, nhidden=128, deg=None, reverse_mp=False):
+        super().__init__()
+        self.gnn_conv = _make_conv(nhidden, deg, reverse_mp)
+        self.gnn_norm = BatchNorm(nhidden)
+        self.gnn_edge_update = nn.Sequential(nn.Linear(3 * nhidden, nhidden), nn.ReLU(), nn.Linear(nhidden, nhidden))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.gnn_conv.reset_parameters()
+        self.gnn_norm.reset_parameters()
+        _xavier_matrices(self.gnn_edge_update)
+
+    def forward(self, x_gnn, edge_index, edge_attr):                                        # tabgnn.py:187-191
+        g = ops.SubgraphIndex.build(edge_index, x_gnn.shape[0])
+        x_gnn = self.gnn_norm(self.gnn_conv(x_gnn, g, edge_attr), res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
+        up0, up2 = self.gnn_edge_update[0], self.gnn_edge_update[2]
+        m = ops.act_dropout(ops.linear(ops.edge_gather(x_gnn, edge_attr, g, "src"), up0.weight, up0.bias), "relu", 0.0)
+        return x_gnn, ops.axpby(edge_attr, ops.linear(m, up2.weight, up2.bias), 1.0, 0.5)  # e + MLP/2 (sic)
+
+
+class TABGNN(nn.Module):
+    def __init__(self, channels: int, num_layers: int, deg=None, node_dim: int = 1, nhidden: int = 128,
+                 edge_dim: int = None, reverse_mp: bool = False, feedforward_channels: Optional[int] = None,
+                 nhead: int = 8, dropout: float = 0.5, activation: str = "relu") -> None:
+        super().__init__()
+        if num_layers <= 0:
+            raise ValueError(f"num_layers must be a positive integer (got {num_layers})")
+        self.channels, self.nhidden = channels, nhidden
+        self.node_dim = node_dim + channels
+        self.edge_dim = edge_dim + channels
+        self.cls_embedding = nn.Parameter(torch.empty(channels))
+        self.node_emb = nn.Linear(self.node_dim, nhidden)
+        self.edge_emb = nn.Linear(self.edge_dim, nhidden)
+        self.tabular_backbone = nn.ModuleList(
+            [FTTransformerLayer(channels, nhead, feedforward_channels, dropout, activation, nhidden)
+             for _ in range(num_layers)])
+        self.gnn_backbone = nn.ModuleList([PNALayer(channels, nhidden, deg, reverse_mp) for _ in range(num_layers)])
+        nn.init.normal_(self.cls_embedding, std=0.01)
+
+    def get_shared_params(self):
+        groups = [[self.cls_embedding], self.node_emb.parameters(), self.edge_emb.parameters(),
+                  self.tabular_backbone.parameters(), self.gnn_backbone.parameters()]
+        return [p for grp in groups for p in grp]
+
+    def zero_grad_shared_params(self):
+        for p in self.get_shared_params():
+            if p.grad is not None:
+                p.grad.data.zero_()
+
+    def forward(self, x, edge_index, edge_attr):                                             # tabgnn.py:100-151
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        x = prepend_cls(self.cls_embedding, x)
+        e = prepend_cls(self.cls_embedding, edge_attr)
+        tx, te = x, e
+        for layer in self.tabular_backbone:          # the same layer serves node rows and edge rows
+            tx = layer(tx)
+            te = layer(te)
+        x = ops.axpby(x, tx, 0.5, 0.5)
+        e = ops.axpby(e, te, 0.5, 0.5)
+        x = ops.linear(x.reshape(-1, self.node_dim), self.node_emb.weight, self.node_emb.bias)
+        e = ops.linear(e.reshape(-1, self.edge_dim), self.edge_emb.weight, self.edge_emb.bias)
+        for layer in self.gnn_backbone:
+            x, e = layer(x, g, e)
+        return x, e

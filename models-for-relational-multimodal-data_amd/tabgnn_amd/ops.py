@@ -1,0 +1,554 @@
+"""Autograd operators of the hot path: thin torch.autograd.Function shells around the C-ABI kernels.
+
+Every operator runs on the current HIP stream through ``_lib.call`` and raises if the library or a GPU
+is missing — there is no eager/CPU fallback.  Plain dense projections use torch's GEMM (hipBLASLt);
+everything else (gather, attention core, norms, aggregation, pooling, loss, optimiser) is a HIP kernel.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib as L
+
+# --------------------------------------------------------------------------- dropout RNG bookkeeping
+
+
+class DropoutRNG:
+    """Counter-based dropout: a mask is a pure function of (seed, stream id, element index), so the
+    backward recomputes it.  ``seed`` advances once per training step, ``stream`` once per dropout site."""
+    seed = 0x5EED
+    _stream = 0
+
+    @classmethod
+    def next_stream(cls):
+        cls._stream = (cls._stream + 1) & 0x7FFFFFFF
+        return cls._stream
+
+    @classmethod
+    def new_step(cls, seed=None):
+        cls.seed = (cls.seed * 6364136223846793005 + 1442695040888963407) & ((1 << 64) - 1) if seed is None else seed
+        cls._stream = 0
+
+
+def _workspace(n_floats, device):
+    return torch.empty(max(int(n_floats), 1), dtype=torch.float32, device=device)
+
+
+# --------------------------------------------------------------------------- index structure
+
+
+class SubgraphIndex:
+    """int32 endpoints + stable CSR by destination and by source of one sampled subgraph
+    (``edge_index`` of ``TABGNNFused.forward``, src/nn/models/fused.py:144)."""
+
+    def __init__(self, src, dst, by_dst, by_src, num_nodes):
+        self.src, self.dst, self.by_dst, self.by_src, self.N = src, dst, by_dst, by_src, num_nodes
+        self.E = src.numel()
+
+    @staticmethod
+    def ids32(ids, num_nodes):
+        ids = ids.contiguous()
+        out = torch.empty(ids.shape, dtype=torch.int32, device=ids.device)
+        err = torch.zeros(1, dtype=torch.int32, device=ids.device)
+        L.call("tg_ids_to_i32", L.ptr(ids), ids.numel(), num_nodes, L.ptr(out), L.ptr(err), L.stream())
+        return out, err
+
+    @staticmethod
+    def csr(keys32, num_nodes):
+        M = keys32.numel()
+        dev = keys32.device
+        rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+        perm = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+        work = torch.empty(L.load().tg_csr_workspace_ints(M, num_nodes), dtype=torch.int32, device=dev)
+        L.call("tg_csr_build", L.ptr(keys32), M, num_nodes, L.ptr(rowptr), L.ptr(perm), L.ptr(work), L.stream())
+        return rowptr, perm
+
+    @classmethod
+    def build(cls, edge_index, num_nodes, check=False):
+        if isinstance(edge_index, SubgraphIndex):
+            return edge_index
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2 or edge_index.dtype != torch.int64:
+            raise RuntimeError("edge_index must be int64 [2, E]")
+        ei32, err = cls.ids32(edge_index, num_nodes)
+        if check and int(err.item()) != 0:
+            raise RuntimeError("edge_index holds node ids outside [0, num_nodes)")
+        src, dst = ei32[0], ei32[1]
+        g = cls(src, dst, cls.csr(dst, num_nodes), cls.csr(src, num_nodes), num_nodes)
+        g.err = err
+        return g
+
+    def flip(self):
+        """The graph with every edge reversed (``edge_index.flipud()``, src/nn/gnn/pna.py:40)."""
+        return SubgraphIndex(self.dst, self.src, self.by_src, self.by_dst, self.N)
+
+
+class SeedIndex:
+    """Seed edges ``target_edge_index [2,B]``: int32 endpoints and the CSR over the 2B endpoint slots
+    (replaces ``torch.unique(..., return_inverse=True)`` + ``bincount``, fused.py:261-266)."""
+
+    def __init__(self, target_edge_index, num_nodes):
+        if isinstance(target_edge_index, SeedIndex):
+            self.__dict__.update(target_edge_index.__dict__)
+            return
+        t32, self.err = SubgraphIndex.ids32(target_edge_index, num_nodes)
+        self.tei = t32.reshape(-1)               # [2B]: sources then destinations
+        self.src, self.dst = t32[0], t32[1]
+        self.B = t32.shape[1]
+        self.N = num_nodes
+        self.rowptr, self.perm = SubgraphIndex.csr(self.tei, num_nodes)
+
+
+# --------------------------------------------------------------------------- dense projection
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b.  GEMM by torch (hipBLASLt); W/b are fp32 masters, ``w_lp``/``b_lp`` their
+    compute-dtype shadows (bf16 mode).  Weight gradients are returned in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_lp, b_lp):
+        w = weight if w_lp is None else w_lp
+        b = bias if b_lp is None else b_lp
+        x2 = x.reshape(-1, x.shape[-1])
+        y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        dx = (g2 @ w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = (g2.t() @ x2).float() if ctx.needs_input_grad[1] else None
+        db = g2.sum(0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
+def shadow(p, dtype):
+    """Compute-dtype copy of a master parameter (flat bf16 shadow maintained by the optimiser when present)."""
+    if p is None or dtype == torch.float32:
+        return None
+    lp = getattr(p, "_lp", None)
+    if lp is not None and lp.dtype == dtype:
+        return lp
+    return p.detach().to(dtype)
+
+
+def linear(x, weight, bias=None):
+    dtype = x.dtype
+    return _Linear.apply(x, weight, bias, shadow(weight, dtype), shadow(bias, dtype))
+
+
+# --------------------------------------------------------------------------- attention core
+
+
+class _AttnCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, nhead, p_drop):
+        R, S, C3 = qkv.shape
+        C = C3 // 3
+        qkv = qkv.contiguous()
+        out = torch.empty(R, S, C, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(R, nhead, S, dtype=torch.float32, device=qkv.device)
+        ctx.seed, ctx.rs = DropoutRNG.seed, DropoutRNG.next_stream()
+        L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(out), L.ptr(lse), R, S, C, nhead, p_drop, ctx.seed, ctx.rs,
+               L.dt(qkv), L.stream())
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (R, S, C, nhead, p_drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, out, lse = ctx.saved_tensors
+        R, S, C, H, p = ctx.cfg
+        dqkv = torch.empty_like(qkv)
+        L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(out), L.ptr(g.contiguous()), L.ptr(lse), L.ptr(dqkv), R, S, C, H, p,
+               ctx.seed, ctx.rs, L.dt(qkv), L.stream())
+        return dqkv, None, None
+
+
+def attention_core(qkv, nhead, p_drop=0.0):
+    return _AttnCore.apply(qkv, nhead, float(p_drop))
+
+
+# --------------------------------------------------------------------------- LayerNorm (+pre-add, +combine)
+
+
+class _LayerNorm(torch.autograd.Function):
+    """out = alpha*res + beta_c*LN(a + dropout(b + bias_b))"""
+
+    @staticmethod
+    def forward(ctx, a, b, bias_b, gamma, beta, res, eps, alpha, beta_c, p_drop):
+        C = a.shape[-1]
+        a = a.contiguous()
+        M = a.numel() // C
+        b = b.contiguous() if b is not None else None
+        res = res.contiguous() if res is not None else None
+        out = torch.empty_like(a)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=a.device)
+        ctx.seed, ctx.rs = DropoutRNG.seed, DropoutRNG.next_stream()
+        L.call("tg_ln_fwd", L.ptr(a), L.ptr(b), L.ptr(bias_b), L.ptr(gamma), L.ptr(beta), L.ptr(res), L.ptr(out),
+               L.ptr(stats), M, C, eps, alpha, beta_c, p_drop, ctx.seed, ctx.rs, L.dt(a), L.stream())
+        ctx.save_for_backward(a, b, bias_b, gamma, stats)
+        ctx.cfg = (M, C, alpha, beta_c, p_drop, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, bias_b, gamma, stats = ctx.saved_tensors
+        M, C, alpha, beta_c, p_drop, has_res = ctx.cfg
+        g = g.contiguous()
+        da = torch.empty_like(a)
+        db = torch.empty_like(a) if b is not None else None
+        dres = torch.empty_like(a) if has_res else None
+        dparams = torch.empty(3, C, dtype=torch.float32, device=a.device)
+        partials = _workspace(L.load().tg_ln_partials_floats(M, C), a.device)
+        L.call("tg_ln_bwd", L.ptr(a), L.ptr(b), L.ptr(bias_b), L.ptr(gamma), L.ptr(stats), L.ptr(g), L.ptr(da),
+               L.ptr(db), L.ptr(dres), L.ptr(dparams), L.ptr(partials), M, C, alpha, beta_c, p_drop, ctx.seed, ctx.rs,
+               L.dt(a), L.stream())
+        dbias = dparams[2] if bias_b is not None else None
+        return da, db, dbias, dparams[0], dparams[1], dres, None, None, None, None
+
+
+def layer_norm(a, gamma, beta, b=None, bias_b=None, res=None, eps=1e-5, alpha=0.0, beta_c=1.0, p_drop=0.0):
+    return _LayerNorm.apply(a, b, bias_b, gamma, beta, res, eps, float(alpha), float(beta_c), float(p_drop))
+
+
+# --------------------------------------------------------------------------- BatchNorm + ReLU + residual
+
+
+class _BatchNormActRes(torch.autograd.Function):
+    """out = alpha*res + beta_c*relu(BN(x)); updates running statistics in training mode."""
+
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, alpha, beta_c):
+        x = x.contiguous()
+        N, F = x.shape
+        res = res.contiguous() if res is not None else None
+        out = torch.empty_like(x)
+        mean = torch.empty(F, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(F, dtype=torch.float32, device=x.device)
+        partials = _workspace(L.load().tg_bn_partials_floats(N, F), x.device)
+        L.call("tg_bn_act_res_fwd", L.ptr(x), L.ptr(res), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
+               L.ptr(running_var), L.ptr(mean), L.ptr(rstd), L.ptr(out), L.ptr(partials), N, F, int(training), momentum,
+               eps, int(relu), alpha, beta_c, L.dt(x), L.stream())
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (N, F, int(training), int(relu), alpha, beta_c, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, F, training, relu, alpha, beta_c, has_res = ctx.cfg
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if has_res else None
+        dparams = torch.empty(2, F, dtype=torch.float32, device=x.device)
+        partials = _workspace(L.load().tg_bn_partials_floats(N, F), x.device)
+        L.call("tg_bn_act_res_bwd", L.ptr(x), L.ptr(g), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dx),
+               L.ptr(dres), L.ptr(dparams), L.ptr(partials), N, F, training, relu, alpha, beta_c, L.dt(x), L.stream())
+        return dx, dres, dparams[1], dparams[0], None, None, None, None, None, None, None, None
+
+
+def batch_norm_act_res(x, gamma, beta, running_mean, running_var, training, res=None, momentum=0.1, eps=1e-5,
+                       relu=True, alpha=0.0, beta_c=1.0):
+    return _BatchNormActRes.apply(x, res, gamma, beta, running_mean, running_var, bool(training), float(momentum),
+                                  float(eps), bool(relu), float(alpha), float(beta_c))
+
+
+# --------------------------------------------------------------------------- activation + dropout, axpby
+
+
+class _ActDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, p_drop):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ctx.seed, ctx.rs = DropoutRNG.seed, DropoutRNG.next_stream()
+        L.call("tg_act_dropout_fwd", L.ptr(x), L.ptr(y), x.numel(), act, p_drop, ctx.seed, ctx.rs, L.dt(x), L.stream())
+        ctx.save_for_backward(x)
+        ctx.cfg = (act, p_drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        act, p = ctx.cfg
+        dx = torch.empty_like(x)
+        L.call("tg_act_dropout_bwd", L.ptr(x), L.ptr(g.contiguous()), L.ptr(dx), x.numel(), act, p, ctx.seed, ctx.rs,
+               L.dt(x), L.stream())
+        return dx, None, None
+
+
+ACT = {"none": 0, "relu": 1, "leaky_relu": 2}
+
+
+def act_dropout(x, act="relu", p_drop=0.0):
+    if act == "none" and p_drop == 0.0:
+        return x
+    return _ActDropout.apply(x, ACT[act], float(p_drop))
+
+
+class _Axpby(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, alpha, beta):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        L.call("tg_axpby", L.ptr(a), L.ptr(b), L.ptr(y), a.numel(), alpha, beta, L.dt(a), L.stream())
+        ctx.cfg = (alpha, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, beta = ctx.cfg
+        return g * alpha, g * beta, None, None
+
+
+def axpby(a, b, alpha, beta):
+    return _Axpby.apply(a, b, float(alpha), float(beta))
+
+
+# --------------------------------------------------------------------------- gather-concat and its backward
+
+
+def _gather3(parts, rows, dtype, device):
+    """parts: three (tensor, index|None, width, relu) tuples; tensor rows of stride ``tensor.stride(0)``."""
+    W = sum(p[2] for p in parts)
+    out = torch.empty(rows, W, dtype=dtype, device=device)
+    args = []
+    for i, (t, idx, w, relu) in enumerate(parts):
+        args += [t.data_ptr(), L.ptr(idx), t.stride(0), w]
+        if i < 2:
+            args.append(int(relu))
+    L.call("tg_gather_concat3", *args, L.ptr(out), rows, L.dt(out), L.stream())
+    return out
+
+
+class _EdgeGather(torch.autograd.Function):
+    """[x[ia] | x[ib] | e]  for all edges (PNAConv.message input / edge update, fused.py:254)."""
+
+    @staticmethod
+    def forward(ctx, x, e, graph, first):
+        # first == "dst": [x[dst], x[src], e] (message, x_i = target);  first == "src": [x[src], x[dst], e]
+        x, e = x.contiguous(), e.contiguous()
+        F = x.shape[1]
+        ia, ib = (graph.dst, graph.src) if first == "dst" else (graph.src, graph.dst)
+        out = _gather3([(x, ia, F, 0), (x, ib, F, 0), (e, None, e.shape[1], 0)], e.shape[0], x.dtype, x.device)
+        ctx.graph, ctx.first, ctx.F, ctx.We = graph, first, F, e.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        graph, F = ctx.graph, ctx.F
+        csr_a, csr_b = (graph.by_dst, graph.by_src) if ctx.first == "dst" else (graph.by_src, graph.by_dst)
+        dx = torch.empty(graph.N, F, dtype=g.dtype, device=g.device)
+        L.call("tg_segment_sum2", L.ptr(g), g.shape[1], 0, L.ptr(csr_a[0]), L.ptr(csr_a[1]), F, L.ptr(csr_b[0]),
+               L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.dt(g), L.stream())
+        de = g[:, 2 * F:].contiguous()
+        return dx, de, None, None
+
+
+def edge_gather(x, e, graph, first):
+    return _EdgeGather.apply(x, e, graph, first)
+
+
+class _SeedGather(torch.autograd.Function):
+    """Seed-edge rows: [lead | x[t_src] | x[t_dst]] (fuse input, fused.py:257) or
+    [relu(x[t_src]) | relu(x[t_dst]) | tail] (ClassifierHead input, decoder.py:18-19)."""
+
+    @staticmethod
+    def forward(ctx, x, other, seeds, mode):
+        x = x.contiguous()
+        F = x.shape[1]
+        B = seeds.B
+        if mode == "fuse":      # other = x_tab [B,S,C]; lead = its CLS token (row stride S*C)
+            C = other.shape[-1]
+            other = other.contiguous()
+            lead = other.reshape(B, -1)
+            out = _gather3([(lead, None, C, 0), (x, seeds.src, F, 0), (x, seeds.dst, F, 0)], B, x.dtype, x.device)
+            ctx.offs = (C, C + F)
+        else:                   # head: other = target edge embedding [B, Fe]
+            other = other.contiguous()
+            out = _gather3([(x, seeds.src, F, 1), (x, seeds.dst, F, 1), (other, None, other.shape[1], 0)], B, x.dtype,
+                           x.device)
+            ctx.offs = (0, F)
+            ctx.save_for_backward(x)
+        ctx.seeds, ctx.mode, ctx.F, ctx.oshape = seeds, mode, F, other.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        seeds, F = ctx.seeds, ctx.F
+        relu_src = ctx.saved_tensors[0] if ctx.mode == "head" else None
+        dx = torch.empty(seeds.N, F, dtype=g.dtype, device=g.device)
+        L.call("tg_segment_sum2", L.ptr(g), g.shape[1], ctx.offs[0], L.ptr(seeds.rowptr), L.ptr(seeds.perm),
+               ctx.offs[1], None, None, seeds.B, L.ptr(relu_src), L.ptr(dx), seeds.N, F, L.dt(g), L.stream())
+        if ctx.mode == "fuse":
+            C = ctx.oshape[-1]
+            dother = torch.zeros(ctx.oshape, dtype=g.dtype, device=g.device)
+            dother[:, 0, :] = g[:, :C]
+        else:
+            dother = g[:, 2 * F:].contiguous()
+        return dx, dother, None, None
+
+
+def seed_gather(x, other, seeds, mode):
+    return _SeedGather.apply(x, other, seeds, mode)
+
+
+# --------------------------------------------------------------------------- PNA aggregation + scalers
+
+
+class _PNAAggregate(torch.autograd.Function):
+    """messages h [E,F] -> [N,4F] = mean | max | min | std per destination."""
+
+    @staticmethod
+    def forward(ctx, h, graph):
+        h = h.contiguous()
+        E, F = h.shape
+        rowptr, perm = graph.by_dst
+        agg = torch.empty(graph.N, 4 * F, dtype=h.dtype, device=h.device)
+        L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rowptr), L.ptr(perm), L.ptr(agg), graph.N, F, L.dt(h),
+               L.stream())
+        ctx.save_for_backward(h, agg)
+        ctx.graph = graph
+        return agg
+
+    @staticmethod
+    def backward(ctx, g):
+        h, agg = ctx.saved_tensors
+        rowptr, perm = ctx.graph.by_dst
+        dh = torch.empty_like(h)
+        L.call("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(g.contiguous()), L.ptr(rowptr), L.ptr(perm),
+               L.ptr(dh), ctx.graph.N, h.shape[1], L.dt(h), L.stream())
+        return dh, None
+
+
+def pna_aggregate(h, graph):
+    return _PNAAggregate.apply(h, graph)
+
+
+class _ScaleCombine(torch.autograd.Function):
+    """out = xw + G[:, :F] + amp*G[:, F:2F] + att*G[:, 2F:]  (degree scalers after the post projection)."""
+
+    @staticmethod
+    def forward(ctx, xw, G, graph, avg_log):
+        xw, G = xw.contiguous(), G.contiguous()
+        N, F = xw.shape
+        out = torch.empty_like(xw)
+        rowptr = graph.by_dst[0]
+        L.call("tg_pna_scale_combine_fwd", L.ptr(xw), L.ptr(G), L.ptr(rowptr), L.ptr(avg_log), L.ptr(out), N, F,
+               L.dt(xw), L.stream())
+        ctx.graph, ctx.avg_log = graph, avg_log
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, F = g.shape
+        dG = torch.empty(N, 3 * F, dtype=g.dtype, device=g.device)
+        L.call("tg_pna_scale_combine_bwd", L.ptr(g), L.ptr(ctx.graph.by_dst[0]), L.ptr(ctx.avg_log), L.ptr(dG), N, F,
+               L.dt(g), L.stream())
+        return g, dG, None, None
+
+
+def pna_scale_combine(xw, G, graph, avg_log):
+    return _ScaleCombine.apply(xw, G, graph, avg_log)
+
+
+# --------------------------------------------------------------------------- fused-layer tail: CLS merge + pooling
+
+
+class _ClsMerge(torch.autograd.Function):
+    """x_tab with its CLS token replaced by (cls + xf[:, :C]) / 2  (fused.py:259-260)."""
+
+    @staticmethod
+    def forward(ctx, xtab, xf):
+        xtab, xf = xtab.contiguous(), xf.contiguous()
+        B, S, C = xtab.shape
+        out = torch.empty_like(xtab)
+        L.call("tg_cls_merge_fwd", L.ptr(xtab), L.ptr(xf), L.ptr(out), B, S, C, xf.shape[1], L.dt(xtab), L.stream())
+        ctx.cfg = (C, xf.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C, D = ctx.cfg
+        dxtab = g.clone()
+        dxtab[:, 0, :] *= 0.5
+        dxf = torch.zeros(g.shape[0], D, dtype=g.dtype, device=g.device)
+        dxf[:, :C] = g[:, 0, :] * 0.5
+        return dxtab, dxf
+
+
+def cls_merge(xtab, xf):
+    return _ClsMerge.apply(xtab, xf)
+
+
+class _SeedPool(torch.autograd.Function):
+    """x_gnn with every seed endpoint averaged with the mean of its fused embeddings (fused.py:261-268)."""
+
+    @staticmethod
+    def forward(ctx, x, xf, seeds, C):
+        x, xf = x.contiguous(), xf.contiguous()
+        N, F = x.shape
+        out = torch.empty_like(x)
+        L.call("tg_seed_pool_fwd", L.ptr(x), L.ptr(xf), L.ptr(seeds.rowptr), L.ptr(seeds.perm), L.ptr(out), N, F,
+               seeds.B, C, L.dt(x), L.stream())
+        ctx.seeds, ctx.cfg = seeds, (N, F, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        seeds = ctx.seeds
+        N, F, C = ctx.cfg
+        dx = torch.empty_like(g)
+        dxf = torch.empty(seeds.B, C + 2 * F, dtype=g.dtype, device=g.device)
+        L.call("tg_seed_pool_bwd", L.ptr(g), L.ptr(seeds.tei), L.ptr(seeds.rowptr), L.ptr(dx), L.ptr(dxf), N, F,
+               seeds.B, C, L.dt(g), L.stream())
+        return dx, dxf, None, None
+
+
+def seed_pool(x, xf, seeds, C):
+    return _SeedPool.apply(x, xf, seeds, C)
+
+
+# --------------------------------------------------------------------------- loss
+
+
+class _WeightedCE(torch.autograd.Function):
+    """torch.nn.CrossEntropyLoss(weight=w) (main.py:335): sum_i w[y_i] * nll_i / sum_i w[y_i]."""
+
+    @staticmethod
+    def forward(ctx, logits, y, w):
+        logits, y = logits.contiguous(), y.contiguous()
+        B, K = logits.shape
+        lossden = torch.empty(2, dtype=torch.float32, device=logits.device)
+        partials = _workspace(512, logits.device)
+        L.call("tg_weighted_ce_fwd", L.ptr(logits), L.ptr(y), L.ptr(w), B, K, L.ptr(lossden), L.ptr(partials),
+               L.dt(logits), L.stream())
+        ctx.save_for_backward(logits, y, w, lossden)
+        return lossden[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, y, w, lossden = ctx.saved_tensors
+        B, K = logits.shape
+        dl = torch.empty_like(logits)
+        g = g.reshape(1).float().contiguous()
+        L.call("tg_weighted_ce_bwd", L.ptr(logits), L.ptr(y), L.ptr(w), L.ptr(lossden), L.ptr(g), B, K, L.ptr(dl),
+               L.dt(logits), L.stream())
+        return dl, None, None
+
+
+def weighted_cross_entropy(logits, y, weight=None):
+    if y.dtype != torch.int64:
+        y = y.long()
+    return _WeightedCE.apply(logits, y.view(-1), weight)

@@ -1,0 +1,117 @@
+"""Train-step machinery around the model (reference ``main.py:33-76,335-336``), MI355X-first:
+
+* ``FlatParams``  — all parameters (and gradients) are views into ONE contiguous fp32 buffer, so the optimiser is
+  one kernel launch and the data-parallel gradient exchange is one (bucketed) RCCL all-reduce;
+  a bf16 shadow buffer (same layout) feeds the GEMMs in bf16 mode and is refreshed by the Adam kernel.
+* ``FusedAdam``   — ``torch.optim.Adam(lr)`` semantics (betas 0.9/0.999, eps 1e-8), one HIP kernel.
+* ``DataParallel``— one process per GPU; rank-0 broadcast at start, gradient all-reduce (mean) per step over
+  ``torch.distributed`` (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+* ``train_step``  — zero_grad -> forward -> weighted CE on the first batch_size rows -> backward -> (all-reduce) -> Adam.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+
+
+class FlatParams:
+    def __init__(self, module: torch.nn.Module, shadow_dtype=None):
+        params = [p for p in module.parameters() if p.requires_grad]
+        seen, uniq = set(), []
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p)); uniq.append(p)
+        self.params = uniq
+        dev = uniq[0].device
+        sizes = [(p.numel() + 7) // 8 * 8 for p in uniq]           # keep every view 32-byte aligned
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        n = self.offsets[-1]
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.shadow = torch.zeros(n, dtype=shadow_dtype, device=dev) if shadow_dtype not in (None, torch.float32) else None
+        for p, off in zip(uniq, self.offsets):
+            view = self.flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[off:off + p.numel()].view_as(p)
+            if self.shadow is not None:
+                p._lp = self.shadow[off:off + p.numel()].view_as(p)
+        self.refresh_shadow()
+
+    @property
+    def numel(self):
+        return self.flat.numel()
+
+    def refresh_shadow(self):
+        if self.shadow is None:
+            return
+        if self.flat.is_cuda:
+            L.call("tg_cast_f32_to_bf16", L.ptr(self.flat), L.ptr(self.shadow), self.flat.numel(), L.stream())
+        else:
+            self.shadow.copy_(self.flat)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, off in zip(self.params, self.offsets):     # autograd may have replaced .grad; re-point the views
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + p.numel()].view_as(p)
+
+
+class FusedAdam:
+    def __init__(self, flat: FlatParams, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.flat, self.lr, self.betas, self.eps = flat, lr, betas, eps
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.t = 0
+
+    def step(self, grad_scale=1.0, zero_grad=False):
+        self.t += 1
+        f = self.flat
+        L.call("tg_adam_step", L.ptr(f.flat), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(f.shadow),
+               f.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t, grad_scale, int(zero_grad),
+               L.stream())
+
+
+class DataParallel:
+    """Gradient-averaging data parallelism over independently sampled mini-batches."""
+
+    def __init__(self, module, flat: FlatParams, bucket_mb=32, sync_buffers=True):
+        self.module, self.flat = module, flat
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.bucket = int(bucket_mb * (1 << 20) // 4)
+        if self.world > 1:
+            dist.broadcast(flat.flat, src=0)
+            if sync_buffers:
+                for b in module.buffers():
+                    dist.broadcast(b, src=0)
+            flat.refresh_shadow()
+
+    def all_reduce_grads(self):
+        """Sum over ranks, bucketed (async, in flight together); the 1/world factor is folded into the optimiser."""
+        if self.world == 1:
+            return 1.0
+        g = self.flat.grad
+        works = [dist.all_reduce(g[i:i + self.bucket], op=dist.ReduceOp.SUM, async_op=True)
+                 for i in range(0, g.numel(), self.bucket)]
+        for w in works:
+            w.wait()
+        return 1.0 / self.world
+
+
+def train_step(model, flat, opt, batch, loss_weight, ddp=None, step_seed=None):
+    """One supervised step (main.py:41-75).  batch = (node_tf, edge_index, edge_tf, y)."""
+    node_tf, edge_index, edge_tf, y = batch
+    ops.DropoutRNG.new_step(step_seed)
+    flat.zero_grad()
+    logits = model(node_tf, edge_index, edge_tf)
+    bs = y.shape[0]
+    loss = ops.weighted_cross_entropy(logits[:bs], y.view(-1), loss_weight)
+    loss.backward()
+    scale = ddp.all_reduce_grads() if ddp is not None else 1.0
+    opt.step(grad_scale=scale)
+    return loss.detach(), logits.detach()

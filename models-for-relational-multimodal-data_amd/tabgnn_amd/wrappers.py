@@ -1,0 +1,98 @@
+"""Model wrappers with the reference's ``config`` contract (``utils.py:235-404``).
+
+``TABGNNFusedS(config).forward(x: TensorFrame, edge_index, edge_attr: TensorFrame) -> logits``: the first
+``batch_size`` edges are the seed edges (``ibm_transactions_for_aml.py:64-66``), encoders -> backbone -> head.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .heads import ClassifierHead, NodeClassificationHead
+from .models import TABGNN, TABGNNFused
+
+
+def degree_histogram(in_degrees):
+    """utils.py:383-389: histogram of the train-graph in-degrees (main.py:283-286)."""
+    in_degrees = in_degrees.to(torch.long)
+    hist = torch.zeros(int(in_degrees.max()) + 1, dtype=torch.long)
+    hist += torch.bincount(in_degrees, minlength=hist.numel()).cpu()
+    return hist
+
+
+class TABGNNFusedS(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.batch_size = config["batch_size"]
+        self.node_encoder = config["node_encoder"]
+        self.edge_encoder = config["edge_encoder"]
+        self.model = self.get_model(config)
+        if config["task"] == "edge_classification":
+            self.decoder = ClassifierHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
+        elif config["task"] == "node_classification":
+            self.decoder = NodeClassificationHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
+        else:
+            raise ValueError(f"task {config['task']} is outside the supervised hot path")
+        if config.get("load_model") is not None and config.get("checkpoint"):
+            self.decoder.load_state_dict(torch.load(config["load_model"] + "decoder"))
+
+    def forward(self, x, edge_index, edge_attr):
+        bs = self.batch_size
+        edge_attr, target_edge_attr = edge_attr[bs:, :], edge_attr[:bs, :]
+        edge_index, target_edge_index = edge_index[:, bs:].contiguous(), edge_index[:, :bs].contiguous()
+        x, _ = self.node_encoder(x)
+        edge_attr, _ = self.edge_encoder(edge_attr)
+        target_edge_attr, _ = self.edge_encoder(target_edge_attr)
+        x, edge_attr, target_edge_attr = self.model(x, edge_index, edge_attr, target_edge_index, target_edge_attr)
+        if self.config["task"] == "edge_classification":
+            return self.decoder(x, target_edge_index, target_edge_attr)
+        return self.decoder(x)
+
+    def get_model(self, config):
+        n_dim = config["num_node_features"] * config["n_hidden"]
+        e_dim = config["num_edge_features"] * config["n_hidden"]
+        if config["model"] != "tabgnnfused":
+            raise ValueError("Invalid model name!")
+        if config.get("in_degrees") is None:
+            raise ValueError("In degrees are not provided for PNA model!")
+        kw = {k: config[k] for k in ("nhead", "backbone_dropout") if k in config}
+        model = TABGNNFused(node_dim=n_dim, nhidden=config["n_hidden"], channels=config["n_hidden"],
+                            num_layers=config["n_gnn_layers"], edge_dim=e_dim,
+                            deg=degree_histogram(config["in_degrees"]), reverse_mp=config.get("reverse_mp", False),
+                            nhead=kw.get("nhead", 8), dropout=kw.get("backbone_dropout", 0.5))
+        if config.get("load_model") is not None:
+            model.load_state_dict(torch.load(config["load_model"] + "model"))
+        return model
+
+
+class TABGNNS(nn.Module):
+    """``utils.py:235-328``: sequential FT-Transformer -> PNA model (BASELINE config 4, ``--model tabgnn``)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.batch_size = config["batch_size"]
+        self.node_encoder = config["node_encoder"]
+        self.edge_encoder = config["edge_encoder"]
+        n_dim = config["num_node_features"] * config["n_hidden"]
+        e_dim = config["num_edge_features"] * config["n_hidden"]
+        if config.get("in_degrees") is None:
+            raise ValueError("In degrees are not provided for PNA model!")
+        self.model = TABGNN(node_dim=n_dim, nhidden=config["n_hidden"], channels=config["n_hidden"],
+                            num_layers=config["n_gnn_layers"], edge_dim=e_dim,
+                            deg=degree_histogram(config["in_degrees"]), reverse_mp=config.get("reverse_mp", False),
+                            nhead=config.get("nhead", 8), dropout=config.get("backbone_dropout", 0.5))
+        if config["task"] == "edge_classification":
+            self.decoder = ClassifierHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
+        else:
+            self.decoder = NodeClassificationHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
+
+    def forward(self, x, edge_index, edge_attr):
+        x, _ = self.node_encoder(x)
+        edge_attr, _ = self.edge_encoder(edge_attr)
+        x, edge_attr = self.model(x, edge_index, edge_attr)
+        if self.config["task"] == "edge_classification":
+            bs = self.batch_size
+            return self.decoder(x, edge_index[:, :bs].contiguous(), edge_attr[:bs].contiguous())
+        return self.decoder(x)
