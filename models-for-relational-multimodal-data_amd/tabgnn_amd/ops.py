@@ -32,6 +32,36 @@ class DropoutRNG:
         cls._stream = 0
 
 
+class KernelTimer:
+    """HIP-event timing of selected launches on the stream they run on (bench.py's live roofline measurement)."""
+    active = None
+
+    def __init__(self):
+        self.spans = {}
+
+    def timed(self, name, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.spans.setdefault(name, []).append((e0, e1))
+
+    def mean_ms(self, name):
+        sp = self.spans.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in sp) / len(sp) if sp else float("nan")
+
+    def count(self, name):
+        return len(self.spans.get(name, []))
+
+
+def _launch(name, *args):
+    t = KernelTimer.active
+    if t is None:
+        L.call(name, *args)
+    else:
+        t.timed(name, lambda: L.call(name, *args))
+
+
 def _workspace(n_floats, device):
     return torch.empty(max(int(n_floats), 1), dtype=torch.float32, device=device)
 
@@ -414,8 +444,8 @@ class _PNAAggregate(torch.autograd.Function):
         E, F = h.shape
         rowptr, perm = graph.by_dst
         agg = torch.empty(graph.N, 4 * F, dtype=h.dtype, device=h.device)
-        L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rowptr), L.ptr(perm), L.ptr(agg), graph.N, F, L.dt(h),
-               L.stream())
+        _launch("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rowptr), L.ptr(perm), L.ptr(agg), graph.N, F, L.dt(h),
+                L.stream())
         ctx.save_for_backward(h, agg)
         ctx.graph = graph
         return agg
@@ -425,8 +455,8 @@ class _PNAAggregate(torch.autograd.Function):
         h, agg = ctx.saved_tensors
         rowptr, perm = ctx.graph.by_dst
         dh = torch.empty_like(h)
-        L.call("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(g.contiguous()), L.ptr(rowptr), L.ptr(perm),
-               L.ptr(dh), ctx.graph.N, h.shape[1], L.dt(h), L.stream())
+        _launch("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(g.contiguous()), L.ptr(rowptr), L.ptr(perm),
+                L.ptr(dh), ctx.graph.N, h.shape[1], L.dt(h), L.stream())
         return dh, None
 
 
