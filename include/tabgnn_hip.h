@@ -121,9 +121,10 @@ int tg_gather_concat3(const void* a, const int32_t* ia, int64_t sa, int32_t wa, 
                       const int32_t* ib, int64_t sb, int32_t wb, int32_t relu_b, const void* c, const int32_t* ic,
                       int64_t sc, int32_t wc, void* out, int64_t rows, int32_t dt, void* stream);
 /* backward of the two gathered parts as a deterministic segmented sum over CSR(s) */
+int64_t tg_segment_hub_ints(int64_t total_rows); /* size of hub_work for tg_segment_sum2 */
 int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA, int32_t offB,
                     const int32_t* rpB, const int32_t* pmB, int32_t seedB, const void* relu_src, void* dx, int32_t N,
-                    int32_t F, int32_t dt, void* stream);
+                    int32_t F, int32_t* hub_work, int32_t dt, void* stream);
 /* mean|max|min|std of messages h[E,F] per destination -> agg[N,4F]  (PNAConv.aggregate, "the SpMM") */
 int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const int32_t* perm, void* agg, int32_t N, int32_t F,
                          int32_t dt, void* stream);
@@ -139,6 +140,12 @@ int tg_seed_pool_fwd(const void* x, const void* xf, const int32_t* rowptr, const
                      int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);
 int tg_seed_pool_bwd(const void* g, const int32_t* tei, const int32_t* rowptr, void* dx, void* dxf, int32_t N,
                      int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);
+
+/* ---- weight gradient of every Linear on the path (autograd of torch.nn.Linear in the reference):
+ *      out[M,N] (fp32) = G[R,M]^T X[R,N], bf16 operands, split over row slabs, deterministic slab sum ------- */
+int64_t tg_gemm_tn_workspace_floats(int64_t R, int32_t M, int32_t N);
+int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* workspace, int64_t R, int32_t M, int32_t N,
+                    int64_t ldg, int64_t ldx, void* stream);
 
 /* ---- train-step tail (main.py:70-75,335-336) ------------------------------------------------------------ */
 int tg_weighted_ce_fwd(const void* logits, const int64_t* y, const float* w, int64_t B, int32_t K,

@@ -188,12 +188,29 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
 }
 
 // out[i] = sum_blk partials[blk][i]   (i < width)
-__global__ void k_reduce_partials(const float* __restrict__ partials, int nblk, int width, float* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= width) return;
+// 256 threads = 64 columns x 4 strips of blocks; four loads in flight per thread; strips meet in LDS in strip order
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partials, int nblk, int width,
+                                                          float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
   float t = 0.f;
-  for (int bIdx = 0; bIdx < nblk; ++bIdx) t += partials[(long long)bIdx * width + i];
-  out[i] = t;
+  if (col < width) {
+    int per = (nblk + 3) / 4, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+      t0 += partials[(long long)b * width + col];
+      t1 += partials[(long long)(b + 1) * width + col];
+      t2 += partials[(long long)(b + 2) * width + col];
+      t3 += partials[(long long)(b + 3) * width + col];
+    }
+    for (; b < b1; ++b) t0 += partials[(long long)b * width + col];
+    t = (t0 + t1) + (t2 + t3);
+  }
+  red[strip][lane] = t;
+  __syncthreads();
+  if (strip == 0 && col < width) out[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 // ------------------------------------------------------------------ BatchNorm (+ReLU, + residual average)
@@ -248,8 +265,7 @@ __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, long
                               float* __restrict__ running_mean, float* __restrict__ running_var) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= F) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int bIdx = 0; bIdx < nblk; ++bIdx) { s1 += partials[(long long)bIdx * 2 * F + c]; s2 += partials[(long long)bIdx * 2 * F + F + c]; }
+  float s1 = partials[c], s2 = partials[F + c];   // already reduced over blocks (k_reduce_partials)
   float mu = s1 / (float)N;
   float var = fmaxf(s2 / (float)N - mu * mu, 0.f);
   mean[c] = mu;
@@ -551,12 +567,12 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
               (const T*)dout, (T*)da, (T*)db, (T*)dres, partials, (long long)M, C, lpr, alpha, beta_c, thresh, inv_keep,
               (unsigned long long)seed, rstream);
   })
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 256)), dim3(256), 0, st, partials, grid, 3 * C, dparams);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 64)), dim3(256), 0, st, partials, grid, 3 * C, dparams);
   TG_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int tg_bn_partials_floats(int64_t N, int32_t F) { return 512 * 2 * F; }
+extern "C" int tg_bn_partials_floats(int64_t N, int32_t F) { return 513 * 2 * F; }
 
 // training=1: batch statistics (and running-stat update when running_* given); training=0: running statistics.
 // mean/rstd [F] are outputs kept for the backward.
@@ -574,7 +590,9 @@ extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* ga
       size_t shm = (size_t)groups * 2 * F * sizeof(float);
       hipLaunchKernelGGL((k_col_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)nullptr,
                          (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, partials, (long long)N, F, 0);
-      hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, st, partials, grid, (long long)N, F, eps,
+      float* sums = partials + (size_t)512 * 2 * F;
+      hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(256), 0, st, partials, grid, 2 * F, sums);
+      hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, st, sums, 1, (long long)N, F, eps,
                          momentum, mean, rstd, running_mean, running_var);
     } else {
       hipLaunchKernelGGL(k_bn_eval_stats, dim3(ceil_div(F, 256)), dim3(256), 0, st, running_mean, running_var, F, eps,
@@ -602,7 +620,7 @@ extern "C" int tg_bn_act_res_bwd(const void* x, const void* dout, const float* g
     size_t shm = (size_t)groups * 2 * F * sizeof(float);
     hipLaunchKernelGGL((k_bn_bwd_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)dout, mean,
                        rstd, gamma, beta, partials, (long long)N, F, relu, beta_c);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 256)), dim3(256), 0, st, partials, grid, 2 * F, dparams);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(256), 0, st, partials, grid, 2 * F, dparams);
     long long total = (long long)N * (F / VEC);
     hipLaunchKernelGGL((k_bn_bwd_apply<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, st, (const T*)x,
                        (const T*)dout, mean, rstd, gamma, beta, dparams, (T*)dx, (T*)dres, (long long)N, F, relu,

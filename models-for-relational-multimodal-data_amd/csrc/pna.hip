@@ -45,39 +45,64 @@ __global__ void k_gather_concat3(GatherPart p0, GatherPart p1, GatherPart p2, T*
 
 // dx[i, :] = sum_{q in segA(i)} g[rowA(q), offA:offA+F] + sum_{q in segB(i)} g[rowB(q), offB:offB+F]
 // seedB > 0: ONE CSR over 2*seedB slots; slot s < seedB reads (row s, offA), else (row s-seedB, offB).
+// Nodes whose segments together exceed HUB_THRESH rows are deferred to k_segment_sum2_hub (one block per hub),
+// so a heavy-tailed degree distribution does not serialise on one lane group.
+constexpr int HUB_THRESH = 256;
+
 template <typename T, int VEC>
 __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int offA, const int* __restrict__ rpA,
                                const int* __restrict__ pmA, int offB, const int* __restrict__ rpB,
                                const int* __restrict__ pmB, int seedB, const T* __restrict__ relu_src,
-                               T* __restrict__ dx, int N, int F) {
+                               T* __restrict__ dx, int N, int F, int* __restrict__ hub /*[0]=count, [1..]=ids*/) {
   const int lpn = F / VEC;  // lanes per node
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   long long total = (long long)N * lpn;
   for (; gid < total; gid += stride) {
     int n = (int)(gid / lpn), c = (int)(gid % lpn) * VEC;
+    int sA = rpA[n], eA = rpA[n + 1];
+    int sB = rpB ? rpB[n] : 0, eB = rpB ? rpB[n + 1] : 0;
+    if ((eA - sA) + (eB - sB) > HUB_THRESH) {
+      if (c == 0) hub[1 + atomicAdd(hub, 1)] = n;
+      continue;
+    }
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    {
-      int s = rpA[n], e = rpA[n + 1];
-      for (int q = s; q < e; ++q) {
-        int row = pmA[q], off = offA;
-        if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
-        float t[VEC];
-        loadv<T, VEC>(g + (long long)row * gstride + off + c, t);
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+    int q = sA;
+    for (; q + 1 < eA; q += 2) {   // two rows in flight
+      int r0 = pmA[q], r1 = pmA[q + 1], o0 = offA, o1 = offA;
+      if (seedB > 0) {
+        if (r0 >= seedB) { r0 -= seedB; o0 = offB; }
+        if (r1 >= seedB) { r1 -= seedB; o1 = offB; }
       }
+      float t0[VEC], t1[VEC];
+      loadv<T, VEC>(g + (long long)r0 * gstride + o0 + c, t0);
+      loadv<T, VEC>(g + (long long)r1 * gstride + o1 + c, t1);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = (acc[j] + t0[j]) + t1[j];
     }
-    if (rpB) {
-      int s = rpB[n], e = rpB[n + 1];
-      for (int q = s; q < e; ++q) {
-        float t[VEC];
-        loadv<T, VEC>(g + (long long)pmB[q] * gstride + offB + c, t);
+    if (q < eA) {
+      int row = pmA[q], off = offA;
+      if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
+      float t[VEC];
+      loadv<T, VEC>(g + (long long)row * gstride + off + c, t);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] += t[j];
-      }
+      for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+    }
+    q = sB;
+    for (; q + 1 < eB; q += 2) {
+      float t0[VEC], t1[VEC];
+      loadv<T, VEC>(g + (long long)pmB[q] * gstride + offB + c, t0);
+      loadv<T, VEC>(g + (long long)pmB[q + 1] * gstride + offB + c, t1);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = (acc[j] + t0[j]) + t1[j];
+    }
+    if (q < eB) {
+      float t[VEC];
+      loadv<T, VEC>(g + (long long)pmB[q] * gstride + offB + c, t);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += t[j];
     }
     if (relu_src) {
       float x[VEC];
@@ -86,6 +111,56 @@ __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int o
       for (int j = 0; j < VEC; ++j) acc[j] = x[j] > 0.f ? acc[j] : 0.f;
     }
     storev<T, VEC>(dx + (long long)n * F + c, acc);
+  }
+}
+
+// one 1024-thread block per hub node: lane groups take strided rows, partial sums meet in LDS in group order
+template <typename T, int VEC>
+__global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__ g, long long gstride, int offA,
+                                                            const int* __restrict__ rpA, const int* __restrict__ pmA,
+                                                            int offB, const int* __restrict__ rpB,
+                                                            const int* __restrict__ pmB, int seedB,
+                                                            const T* __restrict__ relu_src, T* __restrict__ dx, int F,
+                                                            const int* __restrict__ hub) {
+  extern __shared__ float part[];  // [groups][F]
+  const int lpn = F / VEC, groups = 1024 / lpn;
+  const int gi = threadIdx.x / lpn, c = (threadIdx.x % lpn) * VEC;
+  const int nh = hub[0];
+  for (int hIdx = blockIdx.x; hIdx < nh; hIdx += gridDim.x) {
+    int n = hub[1 + hIdx];
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    if (gi < groups) {
+      int sA = rpA[n], eA = rpA[n + 1];
+      for (int q = sA + gi; q < eA; q += groups) {
+        int row = pmA[q], off = offA;
+        if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
+        float t[VEC];
+        loadv<T, VEC>(g + (long long)row * gstride + off + c, t);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+      }
+      if (rpB) {
+        int sB = rpB[n], eB = rpB[n + 1];
+        for (int q = sB + gi; q < eB; q += groups) {
+          float t[VEC];
+          loadv<T, VEC>(g + (long long)pmB[q] * gstride + offB + c, t);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) part[gi * F + c + j] = acc[j];
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += 1024) {
+      float t = 0.f;
+      for (int g2 = 0; g2 < groups; ++g2) t += part[g2 * F + f];
+      if (relu_src && !(to_f<T>(relu_src[(long long)n * F + f]) > 0.f)) t = 0.f;
+      dx[(long long)n * F + f] = from_f<T>(t);
+    }
+    __syncthreads();
   }
 }
 
@@ -287,16 +362,28 @@ extern "C" int tg_gather_concat3(const void* a, const int32_t* ia, int64_t sa, i
   return 0;
 }
 
+extern "C" int64_t tg_segment_hub_ints(int64_t total_rows) { return 2 + total_rows / HUB_THRESH; }
+
 extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA,
                                int32_t offB, const int32_t* rpB, const int32_t* pmB, int32_t seedB,
-                               const void* relu_src, void* dx, int32_t N, int32_t F, int32_t dt, void* stream) {
+                               const void* relu_src, void* dx, int32_t N, int32_t F, int32_t* hub_work, int32_t dt,
+                               void* stream) {
   TG_CHECK(F % 8 == 0 && offA % 8 == 0 && offB % 8 == 0 && gstride % 8 == 0, "tg_segment_sum2: misaligned F=%d", F);
-  TG_CHECK(rpA && pmA, "tg_segment_sum2: CSR A required");
+  TG_CHECK(rpA && pmA && hub_work, "tg_segment_sum2: CSR A and hub workspace required");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(hub_work, 0, sizeof(int), st) != hipSuccess) {
+    set_error("tg_segment_sum2: memset failed");
+    return 2;
+  }
   DISPATCH_T(dt, {
+    TG_CHECK(1024 % (F / VEC) == 0, "tg_segment_sum2: F/VEC must divide 1024 (F=%d)", F);
     long long total = (long long)N * (F / VEC);
-    hipLaunchKernelGGL((k_segment_sum2<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 16)), dim3(256), 0,
-                       (hipStream_t)stream, (const T*)g, (long long)gstride, offA, rpA, pmA, offB, rpB, pmB, seedB,
-                       (const T*)relu_src, (T*)dx, N, F);
+    hipLaunchKernelGGL((k_segment_sum2<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 16)), dim3(256), 0, st,
+                       (const T*)g, (long long)gstride, offA, rpA, pmA, offB, rpB, pmB, seedB, (const T*)relu_src,
+                       (T*)dx, N, F, hub_work);
+    size_t shm = (size_t)(1024 / (F / VEC)) * F * sizeof(float);
+    hipLaunchKernelGGL((k_segment_sum2_hub<T, VEC>), dim3(256), dim3(1024), shm, st, (const T*)g, (long long)gstride,
+                       offA, rpA, pmA, offB, rpB, pmB, seedB, (const T*)relu_src, (T*)dx, F, hub_work);
   })
   TG_LAUNCH_CHECK();
   return 0;

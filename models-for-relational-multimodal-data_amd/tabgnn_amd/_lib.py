@@ -46,19 +46,23 @@ SIGNATURES = {
     "tg_cls_merge_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "tg_gather_concat3": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64,
                           _i32, _vp],
-    "tg_segment_sum2": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_segment_hub_ints": [_i64],
+    "tg_segment_sum2": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp],
     "tg_pna_aggregate_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_pna_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_pna_scale_combine_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_pna_scale_combine_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "tg_seed_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "tg_gemm_tn_workspace_floats": [_i64, _i32, _i32],
+    "tg_gemm_tn_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _vp],
     "tg_weighted_ce_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "tg_weighted_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "tg_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],
     "tg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
-_RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64}
+_RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,
+             "tg_gemm_tn_workspace_floats": _i64}
 
 
 class EncCol(C.Structure):

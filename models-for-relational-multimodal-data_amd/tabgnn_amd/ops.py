@@ -153,9 +153,25 @@ class _Linear(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
         dx = (g2 @ w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = (g2.t() @ x2).float() if ctx.needs_input_grad[1] else None
+        dw = weight_grad(g2, x2) if ctx.needs_input_grad[1] else None
         db = g2.sum(0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
+
+
+def weight_grad(g2, x2):
+    """dW [M,N] fp32 = g2[R,M]^T x2[R,N].  Tall-skinny bf16 problems go to the split-row MFMA kernel
+    (tg_gemm_tn_bf16); small or fp32 ones to torch's GEMM."""
+    R, M = g2.shape
+    N = x2.shape[1]
+    if (g2.dtype == torch.bfloat16 and R >= 4096 and M % 8 == 0 and N % 8 == 0 and g2.stride(1) == 1
+            and x2.stride(1) == 1 and g2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
+            and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
+        out = torch.empty(M, N, dtype=torch.float32, device=g2.device)
+        ws = _workspace(L.load().tg_gemm_tn_workspace_floats(R, M, N), g2.device)
+        L.call("tg_gemm_tn_bf16", g2.data_ptr(), x2.data_ptr(), L.ptr(out), L.ptr(ws), R, M, N, g2.stride(0),
+               x2.stride(0), L.stream())
+        return out
+    return (g2.t() @ x2).float()
 
 
 def shadow(p, dtype):
@@ -377,8 +393,9 @@ class _EdgeGather(torch.autograd.Function):
         graph, F = ctx.graph, ctx.F
         csr_a, csr_b = (graph.by_dst, graph.by_src) if ctx.first == "dst" else (graph.by_src, graph.by_dst)
         dx = torch.empty(graph.N, F, dtype=g.dtype, device=g.device)
+        hub = torch.empty(L.load().tg_segment_hub_ints(2 * graph.E), dtype=torch.int32, device=g.device)
         L.call("tg_segment_sum2", L.ptr(g), g.shape[1], 0, L.ptr(csr_a[0]), L.ptr(csr_a[1]), F, L.ptr(csr_b[0]),
-               L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.dt(g), L.stream())
+               L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.ptr(hub), L.dt(g), L.stream())
         de = g[:, 2 * F:].contiguous()
         return dx, de, None, None
 
@@ -417,8 +434,10 @@ class _SeedGather(torch.autograd.Function):
         seeds, F = ctx.seeds, ctx.F
         relu_src = ctx.saved_tensors[0] if ctx.mode == "head" else None
         dx = torch.empty(seeds.N, F, dtype=g.dtype, device=g.device)
+        hub = torch.empty(L.load().tg_segment_hub_ints(2 * seeds.B), dtype=torch.int32, device=g.device)
         L.call("tg_segment_sum2", L.ptr(g), g.shape[1], ctx.offs[0], L.ptr(seeds.rowptr), L.ptr(seeds.perm),
-               ctx.offs[1], None, None, seeds.B, L.ptr(relu_src), L.ptr(dx), seeds.N, F, L.dt(g), L.stream())
+               ctx.offs[1], None, None, seeds.B, L.ptr(relu_src), L.ptr(dx), seeds.N, F, L.ptr(hub), L.dt(g),
+               L.stream())
         if ctx.mode == "fuse":
             C = ctx.oshape[-1]
             dother = torch.zeros(ctx.oshape, dtype=g.dtype, device=g.device)
