@@ -1,23 +1,27 @@
-// Per-stype column encoders: raw table rows -> [R, ncols, C] column embeddings, all stypes in ONE
-// kernel (the reference runs one module per stype and a Python loop per categorical column;
-// pytorch-frame fork EmbeddingEncoder / LinearEncoder / TimestampEncoder / ProjectionEncoder,
-// constructed at src/datasets/ibm_transactions_for_aml.py:283-294,313-319, called at utils.py:357-359;
-// semantics restated in oracle/encoders.py).
+// Per-stype column encoders: raw table rows -> [R, ncols, C] column embeddings (the reference runs one module per
+// stype and a Python loop per categorical column; pytorch-frame fork EmbeddingEncoder / LinearEncoder /
+// TimestampEncoder / ProjectionEncoder, constructed at src/datasets/ibm_transactions_for_aml.py:283-294,313-319,
+// called at utils.py:357-359; semantics restated in oracle/encoders.py).
 //
 // Forward is output-write bound: R*ncols*C*b bytes out, R*(nc*8 + nn*4 + nt*56) bytes in, tables L2-resident.
-// Backward reduces [R, ncols, C] gradients into tiny parameters: every accumulator (weight/bias element,
-// small-table element) is owned by exactly one thread of a block and lives in LDS, blocks write partial
-// vectors, a second kernel sums them in block order -> deterministic, no float atomics
-// (tables with more than ENC_SMALL_TABLE rows fall back to global atomics).
+//   * numerical / categorical / relation columns: one generic kernel, 16-byte stores;
+//   * timestamp columns: a [R,56] x [56,C] contraction per column.  Each thread owns two output channels and keeps
+//     their 56x2 weights in registers; the 56 sin/cos features of a row chunk are staged once in LDS and
+//     broadcast-read, so the weights never leave the register file.
+// Backward reduces [R, ncols, C] gradients into tiny parameters without float atomics: every accumulator is
+// owned by exactly one thread (register or LDS), blocks write partial vectors, a second kernel sums them in
+// block order (tables with more than ENC_SMALL_TABLE rows fall back to global atomics).
 #include "common.hpp"
 #include "../../include/tabgnn_hip.h"
 
 namespace tg {
 
 constexpr int ENC_MAX_COLS = 16;   // columns per launch (host splits wider tables into several launches)
-constexpr int ENC_RCH = 16;        // rows per chunk
+constexpr int ENC_RCH = 16;        // rows per chunk (generic kernels)
+constexpr int TS_RCH = 32;         // rows per chunk (timestamp kernels)
 constexpr int TS_F = 7, TS_O = 8, TS_K = TS_F * TS_O;  // 7 calendar fields x out_size 8
 constexpr int ENC_SMALL_TABLE = 64;
+constexpr int ENC_BWD_BLOCKS = 1024;
 
 enum EncKind : int { ENC_NUM = 0, ENC_CAT = 1, ENC_TS = 2, ENC_REL = 3 };
 
@@ -27,7 +31,7 @@ struct EncCol {
   int src_col;     // column inside its stype tensor
   int rows;        // categorical: table rows (card + 1)
   int tab_off;     // categorical: first row of this column's table in the concatenated table
-  int acc_off;     // backward: offset (floats) of this column's accumulators in the per-block vector; -1 = global atomics
+  int acc_off;     // backward: offset (floats) of this column's accumulators in the reduced vector; -1 = global atomics
   int ts_slot;     // timestamp: index among the timestamp columns of this launch
   int pad;
 };
@@ -72,28 +76,18 @@ __device__ __forceinline__ void ts_features(const long long* t7, float min_year,
   }
 }
 
+// ------------------------------------------------------------------ generic columns (num / cat / rel)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_encode_fwd(EncDesc d, EncPtrs p, T* __restrict__ out, long long R, int ncols,
                                                      int C) {
-  extern __shared__ float feats[];  // [ENC_RCH][nts][56]
   const int vpr = C / VEC;
   for (long long r0 = (long long)blockIdx.x * ENC_RCH; r0 < R; r0 += (long long)gridDim.x * ENC_RCH) {
     int nrows = (int)((R - r0) < ENC_RCH ? (R - r0) : ENC_RCH);
-    if (d.nts > 0) {
-      __syncthreads();
-      for (int it = threadIdx.x; it < nrows * d.ncol * TS_F; it += 256) {
-        int field = it % TS_F, ci = (it / TS_F) % d.ncol, rr = it / (TS_F * d.ncol);
-        const EncCol& c = d.col[ci];
-        if (c.kind == ENC_TS)
-          ts_features(p.ts + ((r0 + rr) * p.nt + c.src_col) * TS_F, p.ts_min_year[c.src_col],
-                      feats + (rr * d.nts + c.ts_slot) * TS_K, field);
-      }
-      __syncthreads();
-    }
     int items = nrows * d.ncol * vpr;
     for (int it = threadIdx.x; it < items; it += 256) {
       int cv = (it % vpr) * VEC, ci = (it / vpr) % d.ncol, rr = it / (vpr * d.ncol);
       const EncCol& c = d.col[ci];
+      if (c.kind == ENC_TS) continue;
       long long r = r0 + rr;
       float o[VEC];
       if (c.kind == ENC_NUM) {
@@ -104,22 +98,12 @@ __global__ void __launch_bounds__(256) k_encode_fwd(EncDesc d, EncPtrs p, T* __r
         float z = p.rel[r * p.nr + c.src_col];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = z * p.rel_w[c.src_col * C + cv + j] + p.rel_b[c.src_col * C + cv + j];
-      } else if (c.kind == ENC_CAT) {
+      } else {
         long long idx = p.cat[r * p.nc + c.src_col] + 1;   // NaN index -1 -> padding row 0
         idx = idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx);
         const float* row = p.cat_table + ((long long)c.tab_off + idx) * C + cv;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = row[j];
-      } else {
-        const float* f = feats + (rr * d.nts + c.ts_slot) * TS_K;
-        const float* w = p.ts_w + (long long)c.src_col * TS_K * C + cv;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = p.ts_b[c.src_col * C + cv + j];
-        for (int k = 0; k < TS_K; ++k) {
-          float fk = f[k];
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) o[j] += fk * w[(long long)k * C + j];
-        }
       }
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] = isnan(o[j]) ? 0.f : o[j];   // nan_to_num(nan=0)
@@ -129,67 +113,51 @@ __global__ void __launch_bounds__(256) k_encode_fwd(EncDesc d, EncPtrs p, T* __r
 }
 
 // accumulator layout of one column (floats): NUM/REL: w[C], b[C];  TS: w[56*C], b[C];  CAT(small): table[rows*C]
+// (timestamp columns are reduced by k_encode_ts_bwd; their slots in this kernel's partial vector stay zero)
 template <typename T>
 __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const T* __restrict__ g, long long R,
                                                      int ncols, int C, int acc_floats, float* __restrict__ partials,
                                                      float* __restrict__ big_table_grad) {
-  extern __shared__ float lds[];
-  float* acc = lds;                 // [acc_floats]
-  float* feats = lds + acc_floats;  // [ENC_RCH][nts][56]
+  extern __shared__ float acc[];   // [acc_floats]
   for (int i = threadIdx.x; i < acc_floats; i += 256) acc[i] = 0.f;
   __syncthreads();
+  const long long rowstride = (long long)ncols * C;
   for (long long r0 = (long long)blockIdx.x * ENC_RCH; r0 < R; r0 += (long long)gridDim.x * ENC_RCH) {
     int nrows = (int)((R - r0) < ENC_RCH ? (R - r0) : ENC_RCH);
-    if (d.nts > 0) {
-      __syncthreads();
-      for (int it = threadIdx.x; it < nrows * d.ncol * TS_F; it += 256) {
-        int field = it % TS_F, ci = (it / TS_F) % d.ncol, rr = it / (TS_F * d.ncol);
-        const EncCol& c = d.col[ci];
-        if (c.kind == ENC_TS)
-          ts_features(p.ts + ((r0 + rr) * p.nt + c.src_col) * TS_F, p.ts_min_year[c.src_col],
-                      feats + (rr * d.nts + c.ts_slot) * TS_K, field);
-      }
-      __syncthreads();
-    }
     // each (column, channel) pair is owned by one thread of the block
     for (int pr = threadIdx.x; pr < d.ncol * C; pr += 256) {
       int ch = pr % C, ci = pr / C;
       const EncCol& c = d.col[ci];
+      if (c.kind == ENC_TS) continue;
       const T* gp = g + (r0 * ncols + c.out_col) * C + ch;
+      float gv[ENC_RCH];
+#pragma unroll
+      for (int rr = 0; rr < ENC_RCH; ++rr) gv[rr] = rr < nrows ? to_f<T>(gp[rr * rowstride]) : 0.f;   // 16 loads in flight
       if (c.kind == ENC_NUM || c.kind == ENC_REL) {
         float aw = 0.f, ab = 0.f;
-        for (int rr = 0; rr < nrows; ++rr) {
-          float z = c.kind == ENC_NUM
-                        ? (p.num[(r0 + rr) * p.nn + c.src_col] - p.num_mean[c.src_col]) / p.num_std[c.src_col]
-                        : p.rel[(r0 + rr) * p.nr + c.src_col];
-          float gv = to_f<T>(gp[(long long)rr * ncols * C]);
-          if (!isnan(z)) { aw += gv * z; ab += gv; }
+#pragma unroll
+        for (int rr = 0; rr < ENC_RCH; ++rr) {
+          if (rr < nrows) {
+            float z = c.kind == ENC_NUM
+                          ? (p.num[(r0 + rr) * p.nn + c.src_col] - p.num_mean[c.src_col]) / p.num_std[c.src_col]
+                          : p.rel[(r0 + rr) * p.nr + c.src_col];
+            if (!isnan(z)) { aw += gv[rr] * z; ab += gv[rr]; }
+          }
         }
         acc[c.acc_off + ch] += aw;
         acc[c.acc_off + C + ch] += ab;
-      } else if (c.kind == ENC_CAT) {
-        for (int rr = 0; rr < nrows; ++rr) {
-          long long idx = p.cat[(r0 + rr) * p.nc + c.src_col] + 1;
-          idx = idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx);
-          if (idx == 0) continue;  // padding_idx row receives no gradient
-          float gv = to_f<T>(gp[(long long)rr * ncols * C]);
-          if (c.acc_off >= 0) acc[c.acc_off + (int)idx * C + ch] += gv;
-          else atomicAdd(big_table_grad + ((long long)c.tab_off + idx) * C + ch, gv);
-        }
       } else {
-        float aw[TS_K], ab = 0.f;
 #pragma unroll
-        for (int k = 0; k < TS_K; ++k) aw[k] = 0.f;
-        for (int rr = 0; rr < nrows; ++rr) {
-          float gv = to_f<T>(gp[(long long)rr * ncols * C]);
-          const float* f = feats + (rr * d.nts + c.ts_slot) * TS_K;
-          ab += gv;
-#pragma unroll
-          for (int k = 0; k < TS_K; ++k) aw[k] += gv * f[k];
+        for (int rr = 0; rr < ENC_RCH; ++rr) {
+          if (rr < nrows) {
+            long long idx = p.cat[(r0 + rr) * p.nc + c.src_col] + 1;
+            idx = idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx);
+            if (idx != 0) {  // padding_idx row receives no gradient
+              if (c.acc_off >= 0) acc[c.acc_off + (int)idx * C + ch] += gv[rr];
+              else atomicAdd(big_table_grad + ((long long)c.tab_off + idx) * C + ch, gv[rr]);
+            }
+          }
         }
-#pragma unroll
-        for (int k = 0; k < TS_K; ++k) acc[c.acc_off + k * C + ch] += aw[k];
-        acc[c.acc_off + TS_K * C + ch] += ab;
       }
     }
   }
@@ -197,27 +165,141 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
   for (int i = threadIdx.x; i < acc_floats; i += 256) partials[(long long)blockIdx.x * acc_floats + i] = acc[i];
 }
 
-__global__ void k_enc_reduce(const float* __restrict__ partials, int nblk, int width, float* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= width) return;
+// ------------------------------------------------------------------ timestamp columns
+// thread = (row lane rl, channel pair cg); 256 threads = RL x (C/2)
+template <typename T>
+__global__ void __launch_bounds__(256) k_encode_ts_fwd(const long long* __restrict__ ts, int nt, int src_col,
+                                                        const float* __restrict__ min_year_p, const float* __restrict__ w /*[56,C]*/,
+                                                        const float* __restrict__ bias /*[C]*/, T* __restrict__ out,
+                                                        long long R, int ncols, int out_col, int C) {
+  __shared__ __attribute__((aligned(16))) float feats[TS_RCH * TS_K];
+  const int ngrp = C / 2, cg = threadIdx.x % ngrp, rl = threadIdx.x / ngrp, RL = 256 / ngrp;
+  const int c0 = cg * 2;
+  const float min_year = min_year_p[0];
+  float w0[TS_K], w1[TS_K];
+#pragma unroll
+  for (int k = 0; k < TS_K; ++k) { w0[k] = w[k * C + c0]; w1[k] = w[k * C + c0 + 1]; }
+  const float b0 = bias[c0], b1 = bias[c0 + 1];
+  for (long long r0 = (long long)blockIdx.x * TS_RCH; r0 < R; r0 += (long long)gridDim.x * TS_RCH) {
+    int nrows = (int)((R - r0) < TS_RCH ? (R - r0) : TS_RCH);
+    __syncthreads();
+    if (threadIdx.x < nrows * TS_F) {
+      int rr = threadIdx.x / TS_F, field = threadIdx.x % TS_F;
+      ts_features(ts + ((r0 + rr) * nt + src_col) * TS_F, min_year, feats + rr * TS_K, field);
+    }
+    __syncthreads();
+    for (int rr = rl; rr < nrows; rr += RL) {
+      const float4* f4 = reinterpret_cast<const float4*>(feats + rr * TS_K);
+      float a0 = b0, a1 = b1;
+#pragma unroll
+      for (int k4 = 0; k4 < TS_K / 4; ++k4) {
+        float4 f = f4[k4];
+        a0 += f.x * w0[4 * k4] + f.y * w0[4 * k4 + 1] + f.z * w0[4 * k4 + 2] + f.w * w0[4 * k4 + 3];
+        a1 += f.x * w1[4 * k4] + f.y * w1[4 * k4 + 1] + f.z * w1[4 * k4 + 2] + f.w * w1[4 * k4 + 3];
+      }
+      a0 = isnan(a0) ? 0.f : a0;
+      a1 = isnan(a1) ? 0.f : a1;
+      T* o = out + ((r0 + rr) * ncols + out_col) * C + c0;
+      o[0] = from_f<T>(a0);
+      o[1] = from_f<T>(a1);
+    }
+  }
+}
+
+// partial[blk][57*C] = (dW[56][C], db[C]) of this block's rows
+template <typename T>
+__global__ void __launch_bounds__(256) k_encode_ts_bwd(const long long* __restrict__ ts, int nt, int src_col,
+                                                        const float* __restrict__ min_year_p, const T* __restrict__ g, long long R, int ncols,
+                                                        int out_col, int C, float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // feats [TS_RCH*56] | acc [57*C]
+  float* feats = sm;
+  float* acc = sm + TS_RCH * TS_K;
+  const int ngrp = C / 2, cg = threadIdx.x % ngrp, rl = threadIdx.x / ngrp, RL = 256 / ngrp;
+  const int c0 = cg * 2;
+  const float min_year = min_year_p[0];
+  float a0[TS_K], a1[TS_K], s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < TS_K; ++k) { a0[k] = 0.f; a1[k] = 0.f; }
+  for (long long r0 = (long long)blockIdx.x * TS_RCH; r0 < R; r0 += (long long)gridDim.x * TS_RCH) {
+    int nrows = (int)((R - r0) < TS_RCH ? (R - r0) : TS_RCH);
+    __syncthreads();
+    if (threadIdx.x < nrows * TS_F) {
+      int rr = threadIdx.x / TS_F, field = threadIdx.x % TS_F;
+      ts_features(ts + ((r0 + rr) * nt + src_col) * TS_F, min_year, feats + rr * TS_K, field);
+    }
+    __syncthreads();
+    for (int rr = rl; rr < nrows; rr += RL) {
+      const T* gp = g + ((r0 + rr) * ncols + out_col) * C + c0;
+      float g0 = to_f<T>(gp[0]), g1 = to_f<T>(gp[1]);
+      const float4* f4 = reinterpret_cast<const float4*>(feats + rr * TS_K);
+      s0 += g0;
+      s1 += g1;
+#pragma unroll
+      for (int k4 = 0; k4 < TS_K / 4; ++k4) {
+        float4 f = f4[k4];
+        a0[4 * k4] += g0 * f.x; a0[4 * k4 + 1] += g0 * f.y; a0[4 * k4 + 2] += g0 * f.z; a0[4 * k4 + 3] += g0 * f.w;
+        a1[4 * k4] += g1 * f.x; a1[4 * k4 + 1] += g1 * f.y; a1[4 * k4 + 2] += g1 * f.z; a1[4 * k4 + 3] += g1 * f.w;
+      }
+    }
+  }
+  // row lanes add their registers into the block vector one after another (fixed order)
+  for (int turn = 0; turn < RL; ++turn) {
+    __syncthreads();
+    if (rl == turn) {
+#pragma unroll
+      for (int k = 0; k < TS_K; ++k) {
+        if (turn == 0) { acc[k * C + c0] = a0[k]; acc[k * C + c0 + 1] = a1[k]; }
+        else { acc[k * C + c0] += a0[k]; acc[k * C + c0 + 1] += a1[k]; }
+      }
+      if (turn == 0) { acc[TS_K * C + c0] = s0; acc[TS_K * C + c0 + 1] = s1; }
+      else { acc[TS_K * C + c0] += s0; acc[TS_K * C + c0 + 1] += s1; }
+    }
+  }
+  __syncthreads();
+  const int width = (TS_K + 1) * C;
+  for (int i = threadIdx.x; i < width; i += 256) partials[(long long)blockIdx.x * width + i] = acc[i];
+}
+
+// 256 threads = 64 columns x 4 strips of blocks; strips meet in LDS in strip order
+__global__ void __launch_bounds__(256) k_enc_reduce(const float* __restrict__ partials, int nblk, int width,
+                                                     float* __restrict__ out, const int* __restrict__ skip_lo,
+                                                     int nskip) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += partials[(long long)b * width + i];
-  out[i] = t;
+  if (col < width) {
+    int per = (nblk + 3) / 4, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+      t0 += partials[(long long)b * width + col];
+      t1 += partials[(long long)(b + 1) * width + col];
+      t2 += partials[(long long)(b + 2) * width + col];
+      t3 += partials[(long long)(b + 3) * width + col];
+    }
+    for (; b < b1; ++b) t0 += partials[(long long)b * width + col];
+    t = (t0 + t1) + (t2 + t3);
+  }
+  red[strip][lane] = t;
+  __syncthreads();
+  if (strip == 0 && col < width) out[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
 }  // namespace tg
 
 using namespace tg;
 
-// Host-side description of one launch, filled by the Python host (ctypes.Structure mirrors of these).
 static_assert(sizeof(EncCol) == 32, "EncCol layout is part of the C ABI");
 
 extern "C" int tg_encode_max_cols(void) { return ENC_MAX_COLS; }
 extern "C" int tg_encode_small_table_rows(void) { return ENC_SMALL_TABLE; }
-extern "C" int tg_encode_bwd_blocks(void) { return 256; }
+extern "C" int tg_encode_bwd_blocks(void) { return ENC_BWD_BLOCKS; }
 
-static int check_desc(const EncDesc* d, const char* who) {
+static int check_desc(const EncDesc* d, int C, const char* who) {
   TG_CHECK(d && d->ncol > 0 && d->ncol <= ENC_MAX_COLS, "%s: ncol out of range", who);
+  TG_CHECK(C % 8 == 0, "%s: C must be a multiple of 8 (C=%d)", who, C);
+  if (d->nts > 0) TG_CHECK(256 % (C / 2) == 0 && C <= 512, "%s: timestamp columns need C/2 | 256 (C=%d)", who, C);
   return 0;
 }
 
@@ -225,46 +307,83 @@ extern "C" int tg_encode_fwd(const void* desc, const void* ptrs, void* out, int6
                              int32_t dt, void* stream) {
   const EncDesc* d = (const EncDesc*)desc;
   const EncPtrs* p = (const EncPtrs*)ptrs;
-  if (check_desc(d, "tg_encode_fwd")) return 1;
-  TG_CHECK(C % 8 == 0, "tg_encode_fwd: C must be a multiple of 8 (C=%d)", C);
+  if (check_desc(d, C, "tg_encode_fwd")) return 1;
   if (R == 0) return 0;
-  size_t shm = (size_t)ENC_RCH * (d->nts > 0 ? d->nts : 1) * TS_K * sizeof(float);
-  int grid = grid_cap(ceil_div(R, ENC_RCH), 256 * 8);
-  if (dt == F32)
-    hipLaunchKernelGGL((k_encode_fwd<float, 4>), dim3(grid), dim3(256), shm, (hipStream_t)stream, *d, *p, (float*)out,
-                       (long long)R, ncols, C);
-  else
-    hipLaunchKernelGGL((k_encode_fwd<bf16_t, 8>), dim3(grid), dim3(256), shm, (hipStream_t)stream, *d, *p,
-                       (bf16_t*)out, (long long)R, ncols, C);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->nts < d->ncol) {
+    int grid = grid_cap(ceil_div(R, ENC_RCH), 256 * 8);
+    if (dt == F32)
+      hipLaunchKernelGGL((k_encode_fwd<float, 4>), dim3(grid), dim3(256), 0, st, *d, *p, (float*)out, (long long)R,
+                         ncols, C);
+    else
+      hipLaunchKernelGGL((k_encode_fwd<bf16_t, 8>), dim3(grid), dim3(256), 0, st, *d, *p, (bf16_t*)out, (long long)R,
+                         ncols, C);
+  }
+  for (int i = 0; i < d->ncol; ++i) {
+    const EncCol& c = d->col[i];
+    if (c.kind != ENC_TS) continue;
+    TG_CHECK(p->ts && p->ts_w && p->ts_b && p->ts_min_year, "tg_encode_fwd: timestamp pointers missing");
+    int grid = grid_cap(ceil_div(R, TS_RCH), 256 * 8);
+    const float* w = p->ts_w + (long long)c.src_col * TS_K * C;
+    const float* b = p->ts_b + (long long)c.src_col * C;
+    const float* min_year_host = p->ts_min_year + c.src_col;   // device pointer
+    if (dt == F32)
+      hipLaunchKernelGGL((k_encode_ts_fwd<float>), dim3(grid), dim3(256), 0, st, (const long long*)p->ts, p->nt,
+                         c.src_col, min_year_host, w, b, (float*)out, (long long)R, ncols, c.out_col, C);
+    else
+      hipLaunchKernelGGL((k_encode_ts_fwd<bf16_t>), dim3(grid), dim3(256), 0, st, (const long long*)p->ts, p->nt,
+                         c.src_col, min_year_host, w, b, (bf16_t*)out, (long long)R, ncols, c.out_col, C);
+  }
   TG_LAUNCH_CHECK();
   return 0;
 }
 
-// dflat [acc_floats]: reduced accumulators in the layout given by EncCol.acc_off; partials [256*acc_floats].
 extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, int64_t R, int32_t ncols, int32_t C,
                              int32_t acc_floats, float* dflat, float* partials, float* big_table_grad, int32_t dt,
                              void* stream) {
   const EncDesc* d = (const EncDesc*)desc;
   const EncPtrs* p = (const EncPtrs*)ptrs;
-  if (check_desc(d, "tg_encode_bwd")) return 1;
+  if (check_desc(d, C, "tg_encode_bwd")) return 1;
   hipStream_t st = (hipStream_t)stream;
-  size_t shm = ((size_t)acc_floats + (size_t)ENC_RCH * (d->nts > 0 ? d->nts : 1) * TS_K) * sizeof(float);
-  TG_CHECK(shm <= 150 * 1024, "tg_encode_bwd: column group needs %zu B of LDS (> 150 KiB); split the launch", shm);
   if (R == 0) {
     (void)hipMemsetAsync(dflat, 0, (size_t)acc_floats * sizeof(float), st);
     return 0;
   }
-  int grid = grid_cap(ceil_div(R, ENC_RCH), 256);
-  if (dt == F32) {
-    (void)hipFuncSetAttribute((const void*)k_encode_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((k_encode_bwd<float>), dim3(grid), dim3(256), shm, st, *d, *p, (const float*)g, (long long)R,
-                       ncols, C, acc_floats, partials, big_table_grad);
-  } else {
-    (void)hipFuncSetAttribute((const void*)k_encode_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    hipLaunchKernelGGL((k_encode_bwd<bf16_t>), dim3(grid), dim3(256), shm, st, *d, *p, (const bf16_t*)g, (long long)R,
-                       ncols, C, acc_floats, partials, big_table_grad);
+  if (d->nts < d->ncol) {
+    size_t shm = (size_t)acc_floats * sizeof(float);
+    TG_CHECK(shm <= 150 * 1024, "tg_encode_bwd: column group needs %zu B of LDS (> 150 KiB); split the launch", shm);
+    int grid = grid_cap(ceil_div(R, ENC_RCH), ENC_BWD_BLOCKS);
+    if (dt == F32) {
+      (void)hipFuncSetAttribute((const void*)k_encode_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_encode_bwd<float>), dim3(grid), dim3(256), shm, st, *d, *p, (const float*)g, (long long)R,
+                         ncols, C, acc_floats, partials, big_table_grad);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_encode_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_encode_bwd<bf16_t>), dim3(grid), dim3(256), shm, st, *d, *p, (const bf16_t*)g,
+                         (long long)R, ncols, C, acc_floats, partials, big_table_grad);
+    }
+    hipLaunchKernelGGL(k_enc_reduce, dim3(ceil_div(acc_floats, 64)), dim3(256), 0, st, partials, grid, acc_floats,
+                       dflat, (const int*)nullptr, 0);
   }
-  hipLaunchKernelGGL(k_enc_reduce, dim3(ceil_div(acc_floats, 256)), dim3(256), 0, st, partials, grid, acc_floats, dflat);
+  for (int i = 0; i < d->ncol; ++i) {
+    const EncCol& c = d->col[i];
+    if (c.kind != ENC_TS) continue;
+    const float* min_year_host = p->ts_min_year + c.src_col;   // device pointer
+    int width = (TS_K + 1) * C;
+    size_t shm = ((size_t)TS_RCH * TS_K + width) * sizeof(float);
+    int grid = grid_cap(ceil_div(R, TS_RCH), ENC_BWD_BLOCKS);
+    if (dt == F32) {
+      (void)hipFuncSetAttribute((const void*)k_encode_ts_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_encode_ts_bwd<float>), dim3(grid), dim3(256), shm, st, (const long long*)p->ts, p->nt,
+                         c.src_col, min_year_host, (const float*)g, (long long)R, ncols, c.out_col, C, partials);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_encode_ts_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_encode_ts_bwd<bf16_t>), dim3(grid), dim3(256), shm, st, (const long long*)p->ts, p->nt,
+                         c.src_col, min_year_host, (const bf16_t*)g, (long long)R, ncols, c.out_col, C, partials);
+    }
+    hipLaunchKernelGGL(k_enc_reduce, dim3(ceil_div(width, 64)), dim3(256), 0, st, partials, grid, width,
+                       dflat + c.acc_off, (const int*)nullptr, 0);
+  }
   TG_LAUNCH_CHECK();
   return 0;
 }

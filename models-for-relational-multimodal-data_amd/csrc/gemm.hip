@@ -45,8 +45,9 @@ __device__ __forceinline__ v8bf frag_tr(const char* tile, int ks, int cb, int la
 
 __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __restrict__ G,
                                                        const unsigned short* __restrict__ X,
-                                                       float* __restrict__ partial, long long R, int M, int N,
-                                                       long long ldg, long long ldx, long long rows_per_slab) {
+                                                       float* __restrict__ partial, float* __restrict__ colsum_part,
+                                                       long long R, int M, int N, long long ldg, long long ldx,
+                                                       long long rows_per_slab) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];   // [buf][G|X][64 x 256 B] = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
@@ -92,6 +93,11 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
     TG_STORE_PIECE(0, rg0, rx0) TG_STORE_PIECE(1, rg1, rx1) TG_STORE_PIECE(2, rg2, rx2) TG_STORE_PIECE(3, rg3, rx3) \
   }
 
+  // bias gradient: thread t sums column (t & 127) over rows (t >> 7)*32 .. +31 of every G tile
+  const bool do_cs = colsum_part != nullptr && blockIdx.y == 0;
+  float cs = 0.f;
+  const int cs_col = tid & 127, cs_r0 = (tid >> 7) * 32;
+
   if (r_begin < r_end) {
     load_tile(r_begin)
     store_tile(0)
@@ -112,9 +118,24 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     }
+    if (do_cs) {
+#pragma unroll 8
+      for (int rr = 0; rr < 32; ++rr) {
+        int row = cs_r0 + rr;
+        unsigned short hv = *reinterpret_cast<const unsigned short*>(tg_ + lds_off(row, cs_col >> 3) + 2 * (cs_col & 7));
+        cs += bf2f(hv);
+      }
+    }
     if (more) store_tile(buf ^ 1)
     __syncthreads();
     buf ^= 1;
+  }
+
+  if (do_cs) {   // the two row halves meet in LDS (all tiles consumed: last loop iteration ended with a barrier)
+    float* red = reinterpret_cast<float*>(lds);
+    if (tid >= 128) red[cs_col] = cs;
+    __syncthreads();
+    if (tid < 128 && m0 + cs_col < M) colsum_part[(long long)blockIdx.z * M + m0 + cs_col] = cs + red[cs_col];
   }
 
   // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
@@ -132,21 +153,52 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
     }
 }
 
-__global__ void k_sum_slabs(const float* __restrict__ partial, int nslab, long long mn, float* __restrict__ out) {
-  long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;
-  if (i >= mn) return;
-  if (i + 4 <= mn) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < nslab; ++s) {
-      float4 v = *reinterpret_cast<const float4*>(partial + (long long)s * mn + i);
-      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+// out[i] = sum_s partial[s][i]: 256 threads = 16 float4 columns x 16 slab strips, four loads in flight per
+// thread, strips combined through LDS in strip order (deterministic)
+__global__ void __launch_bounds__(256) k_sum_slabs(const float* __restrict__ partial, int nslab, long long mn,
+                                                    float* __restrict__ out) {
+  __shared__ float4 red[16][16];
+  const int col = threadIdx.x & 15, strip = threadIdx.x >> 4;
+  const long long i = ((long long)blockIdx.x * 16 + col) * 4;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < mn) {
+    const int per = (nslab + 15) / 16, s0 = strip * per, s1 = s0 + per < nslab ? s0 + per : nslab;
+    if (i + 4 <= mn) {
+      float4 u0 = t, u1 = t, u2 = t, u3 = t;
+      int sl = s0;
+      for (; sl + 3 < s1; sl += 4) {
+        float4 v0 = *reinterpret_cast<const float4*>(partial + (long long)sl * mn + i);
+        float4 v1 = *reinterpret_cast<const float4*>(partial + (long long)(sl + 1) * mn + i);
+        float4 v2 = *reinterpret_cast<const float4*>(partial + (long long)(sl + 2) * mn + i);
+        float4 v3 = *reinterpret_cast<const float4*>(partial + (long long)(sl + 3) * mn + i);
+        u0.x += v0.x; u0.y += v0.y; u0.z += v0.z; u0.w += v0.w;
+        u1.x += v1.x; u1.y += v1.y; u1.z += v1.z; u1.w += v1.w;
+        u2.x += v2.x; u2.y += v2.y; u2.z += v2.z; u2.w += v2.w;
+        u3.x += v3.x; u3.y += v3.y; u3.z += v3.z; u3.w += v3.w;
+      }
+      for (; sl < s1; ++sl) {
+        float4 v0 = *reinterpret_cast<const float4*>(partial + (long long)sl * mn + i);
+        u0.x += v0.x; u0.y += v0.y; u0.z += v0.z; u0.w += v0.w;
+      }
+      t.x = (u0.x + u1.x) + (u2.x + u3.x); t.y = (u0.y + u1.y) + (u2.y + u3.y);
+      t.z = (u0.z + u1.z) + (u2.z + u3.z); t.w = (u0.w + u1.w) + (u2.w + u3.w);
+    } else {
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int sl = s0; sl < s1; ++sl)
+        for (int k = 0; k < 4; ++k)
+          if (i + k < mn) e[k] += partial[(long long)sl * mn + i + k];
+      t = make_float4(e[0], e[1], e[2], e[3]);
     }
-    *reinterpret_cast<float4*>(out + i) = t;
-  } else {
-    for (long long k = i; k < mn; ++k) {
-      float t = 0.f;
-      for (int s = 0; s < nslab; ++s) t += partial[(long long)s * mn + k];
-      out[k] = t;
+  }
+  red[strip][col] = t;
+  __syncthreads();
+  if (strip == 0 && i < mn) {
+    float4 r = red[0][col];
+    for (int k = 1; k < 16; ++k) { float4 v = red[k][col]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
+    if (i + 4 <= mn) *reinterpret_cast<float4*>(out + i) = r;
+    else {
+      float e[4] = {r.x, r.y, r.z, r.w};
+      for (int k = 0; k < 4; ++k) if (i + k < mn) out[i + k] = e[k];
     }
   }
 }
@@ -169,12 +221,13 @@ extern "C" int64_t tg_gemm_tn_workspace_floats(int64_t R, int32_t M, int32_t N) 
   int tm, tn, nslab;
   long long rps;
   tn_geometry(R, M, N, tm, tn, nslab, rps);
-  return (int64_t)nslab * M * N;
+  return (int64_t)nslab * M * N + (int64_t)nslab * M;
 }
 
 // out[M,N] (fp32) = G[R,M]^T X[R,N];  G, X bf16 with row strides ldg, ldx (elements, multiples of 8)
-extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* workspace, int64_t R, int32_t M,
-                               int32_t N, int64_t ldg, int64_t ldx, void* stream) {
+// colsum (optional, fp32 [M]) = column sums of G = the bias gradient of the same Linear
+extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* colsum, float* workspace, int64_t R,
+                               int32_t M, int32_t N, int64_t ldg, int64_t ldx, void* stream) {
   TG_CHECK(R > 0 && M > 0 && N > 0, "tg_gemm_tn_bf16: empty problem");
   TG_CHECK(M % 8 == 0 && N % 8 == 0 && ldg % 8 == 0 && ldx % 8 == 0,
            "tg_gemm_tn_bf16: M, N and row strides must be multiples of 8 (M=%d N=%d)", M, N);
@@ -185,9 +238,14 @@ extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* 
   tn_geometry(R, M, N, tm, tn, nslab, rps);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(tm, tn, nslab), dim3(256), 0, st, (const unsigned short*)G,
-                     (const unsigned short*)X, workspace, (long long)R, M, N, (long long)ldg, (long long)ldx, rps);
+                     (const unsigned short*)X, workspace, colsum ? workspace + (long long)nslab * M * N : nullptr,
+                     (long long)R, M, N, (long long)ldg, (long long)ldx, rps);
   long long mn = (long long)M * N;
-  hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(mn, 4), 256)), dim3(256), 0, st, workspace, nslab, mn, out);
+  hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(mn, 4), 16)), dim3(256), 0, st, workspace, nslab, mn, out);
+  if (colsum) {
+    float* cs = workspace + (long long)nslab * mn;
+    hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(M, 4), 16)), dim3(256), 0, st, cs, nslab, (long long)M, colsum);
+  }
   TG_LAUNCH_CHECK();
   return 0;
 }

@@ -295,14 +295,23 @@ __global__ void k_bn_apply(const T* __restrict__ x, const T* __restrict__ res, c
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   long long total = N * vpr;
+  // 256 % vpr == 0 (checked by the host): a thread keeps its channel vector for the whole grid-stride loop,
+  // so the per-channel parameters are loaded once into registers
+  const int c = (int)(i % vpr) * VEC;
+  float mu[VEC], sc[VEC], bt[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = mean[c + j];
+    sc[j] = rstd[c + j] * gamma[c + j];
+    bt[j] = beta[c + j];
+  }
   for (; i < total; i += stride) {
     long long r = i / vpr;
-    int c = (int)(i % vpr) * VEC;
     float v[VEC];
     loadv<T, VEC>(x + r * F + c, v);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float y = (v[j] - mean[c + j]) * rstd[c + j] * gamma[c + j] + beta[c + j];
+      float y = (v[j] - mu[j]) * sc[j] + bt[j];
       if (relu) y = fmaxf(y, 0.f);
       v[j] = beta_c * y;
     }
@@ -329,19 +338,27 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ do
   long long stride = (long long)gridDim.x * blockDim.x;
   long long total = N * vpr;
   float invN = 1.f / (float)N;
+  // per-channel parameters in registers (a thread keeps its channel vector across the loop: 256 % vpr == 0)
+  const int c = (int)(i % vpr) * VEC;
+  float mu[VEC], rs[VEC], gm[VEC], bt[VEC], m1[VEC], m2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mu[j] = mean[c + j]; rs[j] = rstd[c + j]; gm[j] = gamma[c + j]; bt[j] = beta[c + j];
+    m1[j] = training ? sums[c + j] * invN : 0.f;
+    m2[j] = training ? sums[F + c + j] * invN : 0.f;
+  }
   for (; i < total; i += stride) {
     long long r = i / vpr;
-    int c = (int)(i % vpr) * VEC;
     float v[VEC], g[VEC], o[VEC];
     loadv<T, VEC>(x + r * F + c, v);
     loadv<T, VEC>(dout + r * F + c, g);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float xh = (v[j] - mean[c + j]) * rstd[c + j];
-      float y = xh * gamma[c + j] + beta[c + j];
+      float xh = (v[j] - mu[j]) * rs[j];
+      float y = xh * gm[j] + bt[j];
       float dz = (relu && !(y > 0.f)) ? 0.f : beta_c * g[j];
-      float t = training ? dz - sums[c + j] * invN - xh * sums[F + c + j] * invN : dz;
-      o[j] = gamma[c + j] * rstd[c + j] * t;
+      float t = dz - m1[j] - xh * m2[j];
+      o[j] = gm[j] * rs[j] * t;
     }
     storev<T, VEC>(dx + r * F + c, o);
     if (dres) {

@@ -153,25 +153,29 @@ class _Linear(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
         dx = (g2 @ w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = weight_grad(g2, x2) if ctx.needs_input_grad[1] else None
-        db = g2.sum(0, dtype=torch.float32) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dw, db = weight_grad(g2, x2, want_b) if ctx.needs_input_grad[1] else (None, None)
+        if want_b and db is None:
+            db = g2.sum(0, dtype=torch.float32)
         return dx, dw, db, None, None
 
 
-def weight_grad(g2, x2):
-    """dW [M,N] fp32 = g2[R,M]^T x2[R,N].  Tall-skinny bf16 problems go to the split-row MFMA kernel
-    (tg_gemm_tn_bf16); small or fp32 ones to torch's GEMM."""
+def weight_grad(g2, x2, want_bias=False):
+    """(dW [M,N] fp32 = g2[R,M]^T x2[R,N], db [M] fp32 = column sums of g2 or None).  Tall-skinny bf16 problems go
+    to the split-row MFMA kernel (tg_gemm_tn_bf16, bias gradient from the same LDS tiles); small or fp32 ones to
+    torch's GEMM."""
     R, M = g2.shape
     N = x2.shape[1]
     if (g2.dtype == torch.bfloat16 and R >= 4096 and M % 8 == 0 and N % 8 == 0 and g2.stride(1) == 1
             and x2.stride(1) == 1 and g2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
             and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
         out = torch.empty(M, N, dtype=torch.float32, device=g2.device)
+        db = torch.empty(M, dtype=torch.float32, device=g2.device) if want_bias else None
         ws = _workspace(L.load().tg_gemm_tn_workspace_floats(R, M, N), g2.device)
-        L.call("tg_gemm_tn_bf16", g2.data_ptr(), x2.data_ptr(), L.ptr(out), L.ptr(ws), R, M, N, g2.stride(0),
-               x2.stride(0), L.stream())
-        return out
-    return (g2.t() @ x2).float()
+        L.call("tg_gemm_tn_bf16", g2.data_ptr(), x2.data_ptr(), L.ptr(out), L.ptr(db), L.ptr(ws), R, M, N,
+               g2.stride(0), x2.stride(0), L.stream())
+        return out, db
+    return (g2.t() @ x2).float(), None
 
 
 def shadow(p, dtype):

@@ -15,14 +15,15 @@ def test_weight_grad_gemm_matches_fp32_reference(R, M, N):
     # integer-valued bf16 operands: products and sums are exact in fp32 -> the MFMA layout is checked bit for bit
     g = torch.randint(-3, 4, (R, M), device=DEV).to(torch.bfloat16)
     x = torch.randint(-3, 4, (R, N), device=DEV).to(torch.bfloat16)
-    got = ops.weight_grad(g, x)
+    got, db = ops.weight_grad(g, x, True)
     want = g.double().t() @ x.double()
     assert got.dtype == torch.float32 and got.shape == (M, N)
     assert torch.equal(got.double(), want), (got.double() - want).abs().max().item()
+    assert torch.equal(db.double(), g.double().sum(0))
     # real-valued operands: fp32 accumulation over R rows
     g = torch.randn(R, M, device=DEV).to(torch.bfloat16)
     x = torch.randn(R, N, device=DEV).to(torch.bfloat16)
-    got = ops.weight_grad(g, x)
+    got, _ = ops.weight_grad(g, x)
     want = g.double().t() @ x.double()
     err = (got.double() - want).abs().max().item()
     assert err <= 2e-5 * R ** 0.5 * 4 + 1e-3, err
@@ -34,8 +35,9 @@ def test_weight_grad_gemm_strided_views():
     big = torch.randint(-2, 3, (R, 384), device=DEV).to(torch.bfloat16)
     g = big[:, 256:]                       # row stride 384, 16-byte aligned view
     x = torch.randint(-2, 3, (R, 64), device=DEV).to(torch.bfloat16)
-    got = ops.weight_grad(g, x)
+    got, db = ops.weight_grad(g, x, True)
     assert torch.equal(got.double(), g.double().t() @ x.double())
+    assert torch.equal(db.double(), g.double().sum(0))
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
