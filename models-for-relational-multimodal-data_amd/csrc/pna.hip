@@ -205,11 +205,11 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
     }
     float mean[VEC], sd[VEC];
     if (e > s) {
-      float inv = 1.f / (float)(e - s);
+      float cnt = (float)(e - s);   // true division (sum / count, as the reference's scatter-mean): exact on constants
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        mean[j] = s1[j] * inv;
-        float var = s2[j] * inv - mean[j] * mean[j];
+        mean[j] = s1[j] / cnt;
+        float var = s2[j] / cnt - mean[j] * mean[j];
         float t = sqrtf(fmaxf(var, STD_EPS));
         sd[j] = t <= sqrtf(STD_EPS) ? 0.f : t;
       }

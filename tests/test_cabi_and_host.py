@@ -1,0 +1,112 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tabgnn_hip.h declares; host logic of the product
+package (module construction, reference state-dict key names, launch plans, error behaviour) without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tabgnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tabgnn_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tabgnn_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)   # ctypes table mirrors the header
+    assert lib.tg_abi_version() == _lib.ABI_VERSION
+
+
+def test_abi_structs_match_header_layout():
+    from tabgnn_amd import _lib
+    assert ctypes.sizeof(_lib.EncCol) == 32 and ctypes.sizeof(_lib.EncDesc) == 8 + 16 * 32
+    assert ctypes.sizeof(_lib.EncPtrs) == 4 * 16 + 10 * 8
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the operators fail loudly instead of computing on the host."""
+    from tabgnn_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path|MI355X"):
+        ops.layer_norm(torch.zeros(4, 32), torch.ones(32), torch.zeros(32))
+    with pytest.raises(RuntimeError):
+        ops.SubgraphIndex.build(torch.zeros(2, 3, dtype=torch.int64), 4)
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    import tabgnn_amd as T
+    for case, kind in [("fused_c32_h8_l1", "fused"), ("fused_c32_h4_l2_rmp", "fused"), ("tabgnn_c32_h8_l2", "tabgnn")]:
+        z = np.load(os.path.join(ROOT, "tests", "golden", case + ".npz"))
+        cfg = json.loads(str(z["cfg"]))
+        deg = torch.tensor([3, 5, 2, 1])
+        C = cfg["C"]
+        if kind == "fused":
+            m = T.TABGNNFused(channels=C, num_layers=cfg["L"], deg=deg, node_dim=C, nhidden=C, edge_dim=cfg["ncols"] * C,
+                              reverse_mp=cfg["reverse_mp"], nhead=cfg["H"])
+            h = T.ClassifierHead(2, C)
+        else:
+            m = T.TABGNN(channels=C, num_layers=cfg["L"], deg=deg, node_dim=cfg["n_node_cols"] * C, nhidden=C,
+                         edge_dim=cfg["n_edge_cols"] * C, nhead=cfg["H"])
+            h = T.NodeClassificationHead(cfg["n_classes"], C)
+        sd = m.state_dict()
+        assert set(sd) == set(cfg["keys"])
+        assert all(list(sd[k].shape) == cfg["keys"][k] for k in sd)
+        assert set(h.state_dict()) == set(cfg["head_keys"])
+
+
+def test_constructor_error_behaviour_matches_reference():
+    import tabgnn_amd as T
+    with pytest.raises(ValueError, match="num_layers must be a positive integer"):     # fused.py:66-68
+        T.TABGNNFused(channels=32, num_layers=0, deg=torch.tensor([1, 1]), node_dim=32, nhidden=32, edge_dim=160)
+    with pytest.raises(ValueError, match="In degrees are not provided"):                 # utils.py:380-381
+        from tabgnn_amd import synthetic as S
+        cfg = S.make_config(32, 1, 8, 16)
+        cfg["in_degrees"] = None
+        T.TABGNNFusedS(cfg)
+
+
+def test_encoder_launch_plan_and_state_dict_names():
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    enc = T.StypeWiseFeatureEncoder(128, S.EDGE_STATS, S.EDGE_COLS)
+    keys = set(enc.state_dict())
+    assert {"encoder_dict.numerical.weight", "encoder_dict.numerical.mean", "encoder_dict.categorical.embs.0.weight",
+            "encoder_dict.categorical.embs.2.weight", "encoder_dict.timestamp.weight",
+            "encoder_dict.timestamp.min_year"} <= keys
+    plan = enc._plan
+    assert plan["ncols"] == 5 and len(plan["descs"]) == 1
+    kinds = [plan["descs"][0].col[i].kind for i in range(5)]
+    assert kinds == [0, 1, 1, 1, 2]                                   # numerical, categorical x3, timestamp
+    assert plan["acc_floats"][0] == (2 + 16 + 8 + 16 + 57) * 128
+    # a wide table (BASELINE config 5: 64 mixed columns, C=256) is split over several launches
+    st = T.stype
+    names = {st.numerical: [f"n{i}" for i in range(24)], st.categorical: [f"c{i}" for i in range(32)],
+             st.timestamp: [f"t{i}" for i in range(8)]}
+    stats = {**{f"n{i}": dict(mean=0., std=1.) for i in range(24)},
+             **{f"c{i}": dict(cardinality=2 + 37 * i) for i in range(32)},
+             **{f"t{i}": dict(min_year=2000) for i in range(8)}}
+    wide = T.StypeWiseFeatureEncoder(256, stats, names)
+    assert wide._plan["ncols"] == 64 and len(wide._plan["descs"]) >= 4
+    assert all(a * 4 <= 150 * 1024 for a in wide._plan["acc_floats"])
+
+
+def test_synthetic_batch_contract():
+    """Seed edges first, every node id present, int64 indices (ibm_transactions_for_aml.py:159-180)."""
+    from tabgnn_amd import synthetic as S
+    node_tf, ei, edge_tf, y = S.make_batch(200, seed=3)
+    assert ei.dtype == torch.int64 and ei.shape == (2, 10702) and node_tf.num_rows == 12797
+    assert torch.unique(ei).numel() == node_tf.num_rows and y.shape == (200,)
+    assert edge_tf.num_rows == ei.shape[1] and edge_tf.num_cols == 5
+    sub = edge_tf[:200, :]
+    assert sub.num_rows == 200
