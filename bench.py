@@ -164,6 +164,16 @@ def main():
     agg_ms = timer.mean_ms("tg_pna_aggregate_fwd")
     achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
     rows = E_mean + args.layers * args.batch_size
+    # HBM bytes per launch from the committed PMC passes (profiles/), valid only for the workload they were taken on
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        wl = pmc["workload"]
+        if (wl["batch_size"], wl["F"], wl["dtype"]) == (args.batch_size, F, args.dtype) and abs(wl["E"] - E_mean) < 1:
+            key = [k for k in pmc["kernels"] if "k_pna_aggregate_fwd" in k][0]
+            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "edges/sec per training step, fused AML supervised (TABGNNFused fwd+CE+bwd+Adam)",
         "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,7 +186,7 @@ def main():
                    "batch_size": args.batch_size, "edges_per_step": int(E_mean), "nodes_per_step": int(N_mean),
                    "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}"},
         "roofline": {"kernel": "k_pna_aggregate_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": agg_bytes, "avg_launch_ms": agg_ms,
                      "launches_timed": timer.count("tg_pna_aggregate_fwd"),
                      "bwd_avg_launch_ms": timer.mean_ms("tg_pna_aggregate_bwd")},
