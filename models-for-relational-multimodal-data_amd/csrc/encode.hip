@@ -134,29 +134,40 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
 #pragma unroll
       for (int rr = 0; rr < ENC_RCH; ++rr) gv[rr] = rr < nrows ? to_f<T>(gp[rr * rowstride]) : 0.f;   // 16 loads in flight
       if (c.kind == ENC_NUM || c.kind == ENC_REL) {
+        // all 16 raw values are fetched before any arithmetic (no branch between the loads: they fly together)
+        const bool isnum = c.kind == ENC_NUM;
+        const float* src = isnum ? p.num + r0 * p.nn + c.src_col : p.rel + r0 * p.nr + c.src_col;
+        const int sstride = isnum ? p.nn : p.nr;
+        float zv[ENC_RCH];
+#pragma unroll
+        for (int rr = 0; rr < ENC_RCH; ++rr) zv[rr] = rr < nrows ? src[rr * sstride] : 0.f;
+        const float mu = isnum ? p.num_mean[c.src_col] : 0.f, sd = isnum ? p.num_std[c.src_col] : 1.f;
         float aw = 0.f, ab = 0.f;
 #pragma unroll
         for (int rr = 0; rr < ENC_RCH; ++rr) {
-          if (rr < nrows) {
-            float z = c.kind == ENC_NUM
-                          ? (p.num[(r0 + rr) * p.nn + c.src_col] - p.num_mean[c.src_col]) / p.num_std[c.src_col]
-                          : p.rel[(r0 + rr) * p.nr + c.src_col];
-            if (!isnan(z)) { aw += gv[rr] * z; ab += gv[rr]; }
-          }
+          float z = (zv[rr] - mu) / sd;
+          bool ok = !isnan(z);
+          aw += ok ? gv[rr] * z : 0.f;
+          ab += ok ? gv[rr] : 0.f;
         }
         acc[c.acc_off + ch] += aw;
         acc[c.acc_off + C + ch] += ab;
       } else {
+        const long long* src = p.cat + r0 * p.nc + c.src_col;
+        int rowi[ENC_RCH];
 #pragma unroll
         for (int rr = 0; rr < ENC_RCH; ++rr) {
-          if (rr < nrows) {
-            long long idx = p.cat[(r0 + rr) * p.nc + c.src_col] + 1;
-            idx = idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx);
-            if (idx != 0) {  // padding_idx row receives no gradient
-              if (c.acc_off >= 0) acc[c.acc_off + (int)idx * C + ch] += gv[rr];
-              else atomicAdd(big_table_grad + ((long long)c.tab_off + idx) * C + ch, gv[rr]);
-            }
-          }
+          long long idx = rr < nrows ? src[rr * p.nc] + 1 : 0;
+          rowi[rr] = (int)(idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx));
+        }
+        if (c.acc_off >= 0) {
+          // predicated read-modify-write of the thread-owned LDS column; row 0 (padding_idx) only ever gets += 0
+#pragma unroll
+          for (int rr = 0; rr < ENC_RCH; ++rr) acc[c.acc_off + rowi[rr] * C + ch] += rowi[rr] != 0 ? gv[rr] : 0.f;
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < ENC_RCH; ++rr)
+            if (rowi[rr] != 0) atomicAdd(big_table_grad + ((long long)c.tab_off + rowi[rr]) * C + ch, gv[rr]);
         }
       }
     }

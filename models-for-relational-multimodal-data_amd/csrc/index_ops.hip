@@ -118,19 +118,87 @@ __global__ void k_fill(const int* __restrict__ key, long long M, int* __restrict
   }
 }
 
-// restore input order inside every segment (stable sort): rank by counting smaller ids
+// restore input order inside every segment (stable sort): rank by counting smaller ids.
+// Segments longer than RANK_HUB are queued for k_rank_hub (O(len^2) here would serialise on a hub node).
+constexpr int RANK_HUB = 512;
+constexpr int RANK_WIN_WORDS = 8192;                  // 64-bit words per window = 512Ki ids (64 KiB bitmap + 32 KiB prefix)
+constexpr int RANK_WIN_IDS = RANK_WIN_WORDS * 64;
+
 __global__ void k_rank(const int* __restrict__ key, const int* __restrict__ rowptr, const int* __restrict__ tmp,
-                       int* __restrict__ perm, long long M) {
+                       int* __restrict__ perm, long long M, int* __restrict__ hub /*[0]=count, [1..]=keys*/) {
   long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (; p < M; p += stride) {
     int me = tmp[p];
     int k = key[me];
     int s = rowptr[k], e = rowptr[k + 1];
+    if (e - s > RANK_HUB) {
+      if (p == s) hub[1 + atomicAdd(hub, 1)] = k;
+      continue;
+    }
     int rank = 0;
     if (e - s > 1)
       for (int q = s; q < e; ++q) rank += tmp[q] < me;
     perm[s + rank] = me;
+  }
+}
+
+// one 1024-thread block per hub segment: a bitmap of the member ids (ids are unique) lives in LDS, an exclusive
+// prefix of its popcounts gives every member its rank = number of smaller members.  O(len + M/64) per hub.
+__global__ void __launch_bounds__(1024) k_rank_hub(const int* __restrict__ rowptr, const int* __restrict__ tmp,
+                                                    int* __restrict__ perm, long long M, const int* __restrict__ hub) {
+  __shared__ unsigned long long bits[RANK_WIN_WORDS];
+  __shared__ unsigned pre[RANK_WIN_WORDS];
+  __shared__ unsigned wsum[16];
+  __shared__ unsigned carry;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nh = hub[0];
+  for (int hIdx = blockIdx.x; hIdx < nh; hIdx += gridDim.x) {
+    const int k = hub[1 + hIdx];
+    const int s = rowptr[k], e = rowptr[k + 1];
+    unsigned base = 0;
+    for (long long w0 = 0; w0 < M; w0 += RANK_WIN_IDS) {
+      for (int i = tid; i < RANK_WIN_WORDS; i += 1024) bits[i] = 0ull;
+      if (tid == 0) carry = 0;
+      __syncthreads();
+      for (int q = s + tid; q < e; q += 1024) {
+        long long id = (long long)tmp[q] - w0;
+        if (id >= 0 && id < RANK_WIN_IDS) atomicOr(&bits[id >> 6], 1ull << (id & 63));
+      }
+      __syncthreads();
+      // exclusive prefix of popcounts: 8 consecutive words per thread, wave scan, wave totals through LDS
+      unsigned loc[RANK_WIN_WORDS / 1024], run = 0;
+#pragma unroll
+      for (int j = 0; j < RANK_WIN_WORDS / 1024; ++j) {
+        loc[j] = run;
+        run += __popcll(bits[tid * (RANK_WIN_WORDS / 1024) + j]);
+      }
+      unsigned incl = run;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (lane == 63) wsum[wid] = incl;
+      __syncthreads();
+      unsigned woff = 0;
+      for (int w = 0; w < wid; ++w) woff += wsum[w];
+      unsigned excl = incl - run + woff;
+#pragma unroll
+      for (int j = 0; j < RANK_WIN_WORDS / 1024; ++j) pre[tid * (RANK_WIN_WORDS / 1024) + j] = excl + loc[j];
+      if (tid == 1023) carry = excl + run;            // members inside this window
+      __syncthreads();
+      for (int q = s + tid; q < e; q += 1024) {
+        int me = tmp[q];
+        long long id = (long long)me - w0;
+        if (id >= 0 && id < RANK_WIN_IDS) {
+          unsigned r = base + pre[id >> 6] + __popcll(bits[id >> 6] & ((1ull << (id & 63)) - 1ull));
+          perm[s + r] = me;
+        }
+      }
+      base += carry;
+      __syncthreads();
+    }
   }
 }
 
@@ -228,7 +296,7 @@ extern "C" int tg_ids_to_i32(const int64_t* ids, int64_t M, int32_t N, int32_t* 
 }
 
 extern "C" int64_t tg_csr_workspace_ints(int64_t M, int32_t N) {
-  return (int64_t)N + 1 + M + ceil_div((long long)N + 1, SCAN_CHUNK) + 16;
+  return (int64_t)N + 1 + M + ceil_div((long long)N + 1, SCAN_CHUNK) + 16 + (2 + M / RANK_HUB);
 }
 
 extern "C" int tg_csr_build(const int32_t* key, int64_t M, int32_t N, int32_t* rowptr, int32_t* perm, int32_t* work,
@@ -252,8 +320,14 @@ extern "C" int tg_csr_build(const int32_t* key, int64_t M, int32_t N, int32_t* r
   hipLaunchKernelGGL(k_scan_add, dim3(nchunks), dim3(SCAN_T), 0, st, rowptr, n1, totals, cursor);
   if (M > 0) {
     hipLaunchKernelGGL(k_fill, dim3(grid_cap(ceil_div(M, 256))), dim3(256), 0, st, key, (long long)M, cursor, tmp);
+    int* hub = totals + nchunks + 8;   // [2 + M / RANK_HUB]
+    if (hipMemsetAsync(hub, 0, sizeof(int), st) != hipSuccess) {
+      set_error("tg_csr_build: memset failed");
+      return 2;
+    }
     hipLaunchKernelGGL(k_rank, dim3(grid_cap(ceil_div(M, 256), 256 * 16)), dim3(256), 0, st, key, rowptr, tmp, perm,
-                       (long long)M);
+                       (long long)M, hub);
+    hipLaunchKernelGGL(k_rank_hub, dim3(128), dim3(1024), 0, st, rowptr, tmp, perm, (long long)M, hub);
   }
   TG_LAUNCH_CHECK();
   return 0;

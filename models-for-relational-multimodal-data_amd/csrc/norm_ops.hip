@@ -529,7 +529,7 @@ static int ln_geometry(int C, int vec, int& lpr, int& vpl) {
   return vpl <= 4 ? 0 : 1;
 }
 
-extern "C" int tg_ln_partials_floats(int64_t M, int32_t C) { return 512 * 3 * C; }
+extern "C" int tg_ln_partials_floats(int64_t M, int32_t C) { return 2048 * 3 * C; }
 
 #define LN_LAUNCH(KERN, VPLV, ...)                                                      \
   switch (VPLV) {                                                                       \
@@ -577,7 +577,7 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
     int lpr, vpl;
     TG_CHECK(ln_geometry(C, VEC, lpr, vpl) == 0, "tg_ln_bwd: unsupported width C=%d", C);
     int groups = LN_BLOCK / lpr;
-    grid = grid_cap(ceil_div(M, groups), 512);
+    grid = grid_cap(ceil_div(M, groups), 2048);
     size_t shm = (size_t)groups * 3 * C * sizeof(float);
     TG_CHECK(shm <= 160 * 1024, "tg_ln_bwd: LDS %zu too large", shm);
     LN_LAUNCH(k_ln_bwd, vpl, dim3(grid), dim3(LN_BLOCK), shm, st, (const T*)a, (const T*)b, bias_b, gamma, stats,
