@@ -89,7 +89,8 @@ int tg_ln_fwd(const void* a, const void* b, const float* bias_b, const float* ga
 int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* gamma, const float* stats,
               const void* dout, void* da, void* db, void* dres, float* dparams /*[3C]: dgamma,dbeta,dbias_b*/,
               float* partials, int64_t M, int32_t C, float alpha, float beta_c, float p_drop, uint64_t seed,
-              uint32_t rstream, int32_t dt, void* stream);
+              uint32_t rstream, int32_t accum_da /*1: da += (another branch's gradient is already there)*/,
+              int32_t dt, void* stream);
 
 /* ---- BatchNorm1d (+ReLU) with residual combine: out = alpha*res + beta_c*relu(BN(x))
  *      (torch_geometric BatchNorm -> BatchNorm1d; fused.py:214,252; tabgnn.py:172,188) ------------------- */

@@ -132,7 +132,13 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
       const T* gp = g + (r0 * ncols + c.out_col) * C + ch;
       float gv[ENC_RCH];
 #pragma unroll
-      for (int rr = 0; rr < ENC_RCH; ++rr) gv[rr] = rr < nrows ? to_f<T>(gp[rr * rowstride]) : 0.f;   // 16 loads in flight
+      // loads are UNCONDITIONAL (row index clamped into the chunk) so that all 16 fly together: a per-element
+      // "load or zero" on a runtime bound makes hipcc branch and wait around every load (guide §5, item 4c)
+      for (int rr = 0; rr < ENC_RCH; ++rr) {
+        int rc = rr < nrows ? rr : nrows - 1;
+        float t = to_f<T>(gp[rc * rowstride]);
+        gv[rr] = rr < nrows ? t : 0.f;
+      }
       if (c.kind == ENC_NUM || c.kind == ENC_REL) {
         // all 16 raw values are fetched before any arithmetic (no branch between the loads: they fly together)
         const bool isnum = c.kind == ENC_NUM;
@@ -140,7 +146,7 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
         const int sstride = isnum ? p.nn : p.nr;
         float zv[ENC_RCH];
 #pragma unroll
-        for (int rr = 0; rr < ENC_RCH; ++rr) zv[rr] = rr < nrows ? src[rr * sstride] : 0.f;
+        for (int rr = 0; rr < ENC_RCH; ++rr) zv[rr] = src[(rr < nrows ? rr : nrows - 1) * sstride];   // gv is 0 past nrows
         const float mu = isnum ? p.num_mean[c.src_col] : 0.f, sd = isnum ? p.num_std[c.src_col] : 1.f;
         float aw = 0.f, ab = 0.f;
 #pragma unroll
@@ -157,7 +163,7 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
         int rowi[ENC_RCH];
 #pragma unroll
         for (int rr = 0; rr < ENC_RCH; ++rr) {
-          long long idx = rr < nrows ? src[rr * p.nc] + 1 : 0;
+          long long idx = src[(rr < nrows ? rr : nrows - 1) * p.nc] + 1;                             // gv is 0 past nrows
           rowi[rr] = (int)(idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx));
         }
         if (c.acc_off >= 0) {

@@ -70,11 +70,16 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
   {                                                                                                           \
     int piece = tid + 256 * P, row = piece >> 4, ch = piece & 15;                                             \
     long long r = r0_ + row;                                                                                  \
+    /* unconditional loads from clamped (always valid) addresses, zeroed by select: no branch, no early wait */ \
     bool okr = r < r_end;                                                                                     \
-    RG = make_uint4(0, 0, 0, 0);                                                                              \
-    RX = make_uint4(0, 0, 0, 0);                                                                              \
-    if (okr && m0 + ch * 8 < M) RG = *reinterpret_cast<const uint4*>(G + r * ldg + m0 + ch * 8);             \
-    if (okr && n0 + ch * 8 < N) RX = *reinterpret_cast<const uint4*>(X + r * ldx + n0 + ch * 8);             \
+    long long rc_ = okr ? r : r_end - 1;                                                                      \
+    int mc_ = m0 + ch * 8 < M ? m0 + ch * 8 : M - 8;                                                          \
+    int nc_ = n0 + ch * 8 < N ? n0 + ch * 8 : N - 8;                                                          \
+    uint4 vg_ = *reinterpret_cast<const uint4*>(G + rc_ * ldg + mc_);                                         \
+    uint4 vx_ = *reinterpret_cast<const uint4*>(X + rc_ * ldx + nc_);                                         \
+    bool okg_ = okr && m0 + ch * 8 < M, okx_ = okr && n0 + ch * 8 < N;                                        \
+    RG = make_uint4(okg_ ? vg_.x : 0u, okg_ ? vg_.y : 0u, okg_ ? vg_.z : 0u, okg_ ? vg_.w : 0u);              \
+    RX = make_uint4(okx_ ? vx_.x : 0u, okx_ ? vx_.y : 0u, okx_ ? vx_.z : 0u, okx_ ? vx_.w : 0u);              \
   }
 #define load_tile(R0)                                                                                         \
   {                                                                                                           \

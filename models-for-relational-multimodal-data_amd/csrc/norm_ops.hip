@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
                                                       T* __restrict__ da, T* __restrict__ db, T* __restrict__ dres,
                                                       float* __restrict__ partials, long long M, int C, int lpr,
                                                       float alpha, float beta_c, unsigned thresh, float inv_keep,
-                                                      unsigned long long seed, unsigned rstream) {
+                                                      unsigned long long seed, unsigned rstream, int accum_da) {
   extern __shared__ float red[];  // [groups][3][C]
   const int groups = LN_BLOCK / lpr;
   const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
@@ -156,7 +156,15 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
         float d[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) d[j] = rstd * (gx[k][j] - m1 - xh[k][j] * m2);
-        storev<T, VEC>(da + row * C + c, d);
+        if (accum_da) {   // da already holds another branch's gradient of the same tensor: add instead of overwrite
+          float old[VEC], sum[VEC];
+          loadv<T, VEC>(da + row * C + c, old);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) sum[j] = old[j] + d[j];
+          storev<T, VEC>(da + row * C + c, sum);
+        } else {
+          storev<T, VEC>(da + row * C + c, d);
+        }
         if (b) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) { d[j] *= msk[k][j]; dbs[k][j] += d[j]; }
@@ -563,7 +571,7 @@ extern "C" int tg_ln_fwd(const void* a, const void* b, const float* bias_b, cons
 extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* gamma, const float* stats,
                          const void* dout, void* da, void* db, void* dres, float* dparams, float* partials, int64_t M,
                          int32_t C, float alpha, float beta_c, float p_drop, uint64_t seed, uint32_t rstream,
-                         int32_t dt, void* stream) {
+                         int32_t accum_da, int32_t dt, void* stream) {
   TG_CHECK(C % 8 == 0 && C <= 2048, "tg_ln_bwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
@@ -582,7 +590,7 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
     TG_CHECK(shm <= 160 * 1024, "tg_ln_bwd: LDS %zu too large", shm);
     LN_LAUNCH(k_ln_bwd, vpl, dim3(grid), dim3(LN_BLOCK), shm, st, (const T*)a, (const T*)b, bias_b, gamma, stats,
               (const T*)dout, (T*)da, (T*)db, (T*)dres, partials, (long long)M, C, lpr, alpha, beta_c, thresh, inv_keep,
-              (unsigned long long)seed, rstream);
+              (unsigned long long)seed, rstream, (int)accum_da);
   })
   hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 64)), dim3(256), 0, st, partials, grid, 3 * C, dparams);
   TG_LAUNCH_CHECK();

@@ -1,0 +1,140 @@
+"""The post-norm column-transformer layer as ONE autograd node with a hand-scheduled backward.
+
+Same kernels as the op-by-op composition in ``layers.ColumnTransformerLayer`` (torch ``nn.TransformerEncoderLayer``
+as configured at ``src/nn/models/fused.py:83-92``), optionally followed by the ``tab_norm`` LayerNorm and the
+residual combine every call site applies (``fused.py:160,164,249``; ``tabgnn.py:219``):
+
+    out = alpha * x + beta_c * LN_tab(encoder_layer(x))            (tail)   |   out = encoder_layer(x)
+
+Why one node: the layer input ``x`` and the intermediate ``x1`` each feed several consumers.  Scheduled by hand,
+their gradient branches accumulate in place (LayerNorm backward with ``accum_da``, GEMMs with beta = 1) instead
+of through separate elementwise add kernels over [rows*S, C] tensors, and intermediates are freed as soon as the
+schedule is past them.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _ln_fwd(a, b, bias_b, gamma, beta, res, alpha, beta_c, p, seed, rs, eps=1e-5):
+    C = a.shape[-1]
+    M = a.numel() // C
+    out = torch.empty_like(a)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=a.device)
+    L.call("tg_ln_fwd", L.ptr(a), L.ptr(b), L.ptr(bias_b), L.ptr(gamma), L.ptr(beta), L.ptr(res), L.ptr(out),
+           L.ptr(stats), M, C, eps, alpha, beta_c, p, seed, rs, L.dt(a), L.stream())
+    return out, stats
+
+
+def _ln_bwd(a, b, bias_b, gamma, stats, g, da, want_db, dres, alpha, beta_c, p, seed, rs, accum):
+    """Returns (db, dparams[3,C]); writes (or accumulates into) ``da`` and writes ``dres`` when given."""
+    C = a.shape[-1]
+    M = a.numel() // C
+    db = torch.empty_like(a) if want_db else None
+    dparams = torch.empty(3, C, dtype=torch.float32, device=a.device)
+    partials = torch.empty(L.load().tg_ln_partials_floats(M, C), dtype=torch.float32, device=a.device)
+    L.call("tg_ln_bwd", L.ptr(a), L.ptr(b), L.ptr(bias_b), L.ptr(gamma), L.ptr(stats), L.ptr(g), L.ptr(da), L.ptr(db),
+           L.ptr(dres), L.ptr(dparams), L.ptr(partials), M, C, alpha, beta_c, p, seed, rs, int(accum), L.dt(a),
+           L.stream())
+    return db, dparams
+
+
+class _EncoderLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nhead, p, tail, alpha, beta_c, w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2, gt, bt):
+        x = x.contiguous()
+        R, S, C = x.shape
+        T = R * S
+        dt = x.dtype
+        sh = lambda t: t if dt == torch.float32 else ops.shadow(t, dt)
+        lw_in, lb_in, lw_o, lw1, lb1, lw2 = sh(w_in), sh(b_in), sh(w_o), sh(w1), sh(b1), sh(w2)
+        seed = ops.DropoutRNG.seed
+        rs = [ops.DropoutRNG.next_stream() for _ in range(4)]          # attention, norm1, ffn, norm2
+        x2d = x.view(T, C)
+        qkv = torch.addmm(lb_in, x2d, lw_in.t())
+        o = torch.empty(T, C, dtype=dt, device=x.device)
+        lse = torch.empty(R, nhead, S, dtype=torch.float32, device=x.device)
+        L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, nhead, p, seed, rs[0], L.dt(x), L.stream())
+        y = o @ lw_o.t()
+        x1, st1 = _ln_fwd(x2d, y, b_o, g1, be1, None, 0.0, 1.0, p, seed, rs[1])
+        hpre = torch.addmm(lb1, x1, lw1.t())
+        h = torch.empty_like(hpre)
+        L.call("tg_act_dropout_fwd", L.ptr(hpre), L.ptr(h), hpre.numel(), 1, p, seed, rs[2], L.dt(x), L.stream())
+        y2 = h @ lw2.t()
+        x2, st2 = _ln_fwd(x1, y2, b2, g2, be2, None, 0.0, 1.0, p, seed, rs[3])
+        if tail:
+            out, st3 = _ln_fwd(x2, None, None, gt, bt, x2d if alpha != 0.0 else None, alpha, beta_c, 0.0, 0, 0)
+        else:
+            out, st3 = x2, None
+        ctx.save_for_backward(x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2,
+                              g1, g2, gt)
+        ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
+        return out.view(R, S, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2, g1, g2,
+         gt) = ctx.saved_tensors
+        R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
+        T = R * S
+        g = g.contiguous().view(T, C)
+        dgt = dbt = None
+        d_x = None
+        if tail:                                         # out = alpha*x + beta_c*LN_t(x2)
+            d_x2 = torch.empty_like(x2)
+            d_x = torch.empty_like(x2) if alpha != 0.0 else None
+            _, dp = _ln_bwd(x2, None, None, gt, st3, g, d_x2, False, d_x, alpha, beta_c, 0.0, 0, 0, False)
+            dgt, dbt = dp[0], dp[1]
+        else:
+            d_x2 = g
+        # x2 = LN2(x1 + drop(y2 + b2))
+        d_x1 = torch.empty_like(x1)
+        d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
+        del d_x2
+        dw2, _ = ops.weight_grad(d_y2, h)
+        d_h = d_y2 @ lw2
+        del d_y2
+        d_hpre = torch.empty_like(d_h)
+        L.call("tg_act_dropout_bwd", L.ptr(hpre), L.ptr(d_h), L.ptr(d_hpre), hpre.numel(), 1, p, seed, rs[2],
+               L.dt(hpre), L.stream())
+        del d_h
+        dw1, db1 = ops.weight_grad(d_hpre, x1, True)
+        if db1 is None:
+            db1 = d_hpre.sum(0, dtype=torch.float32)
+        d_x1.addmm_(d_hpre, lw1)                         # second consumer of x1: accumulated by the GEMM (beta = 1)
+        del d_hpre
+        # x1 = LN1(x + drop(y + b_o))
+        if d_x is None:
+            d_x = torch.empty_like(x1)
+            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], False)
+        else:
+            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], True)
+        del d_x1
+        dwo, _ = ops.weight_grad(d_y, o)
+        d_o = d_y @ lw_o
+        del d_y
+        d_qkv = torch.empty_like(qkv)
+        L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
+               L.dt(qkv), L.stream())
+        del d_o
+        dwin, dbin = ops.weight_grad(d_qkv, x2d, True)
+        if dbin is None:
+            dbin = d_qkv.sum(0, dtype=torch.float32)
+        d_x.addmm_(d_qkv, lw_in)                         # third consumer of x
+        return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],
+                dp1[0], dp1[1], dp2[0], dp2[1], dgt, dbt)
+
+
+def encoder_layer(x, layer, p, tail_norm=None, alpha=0.0, beta_c=1.0):
+    """``layer``: a ColumnTransformerLayer (parameter holder); ``tail_norm``: the LayerNorm applied after it."""
+    sa = layer.self_attn
+    tail = tail_norm is not None
+    gt = tail_norm.weight if tail else None
+    bt = tail_norm.bias if tail else None
+    return _EncoderLayerFn.apply(x, layer.nhead, float(p), tail, float(alpha), float(beta_c), sa.in_proj_weight,
+                                 sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.linear1.weight,
+                                 layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight,
+                                 layer.norm1.bias, layer.norm2.weight, layer.norm2.bias, gt, bt)

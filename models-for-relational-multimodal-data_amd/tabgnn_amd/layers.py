@@ -62,7 +62,13 @@ class ColumnTransformerLayer(nn.Module):
         self.norm1 = nn.LayerNorm(channels, eps=1e-5)
         self.norm2 = nn.LayerNorm(channels, eps=1e-5)
 
-    def forward(self, x):
+    def forward(self, x, tail_norm=None, alpha=0.0, beta_c=1.0):
+        """enc(x), or alpha*x + beta_c*tail_norm(enc(x)) — one autograd node (encoder_layer.py)."""
+        from .encoder_layer import encoder_layer
+        return encoder_layer(x, self, self.p if self.training else 0.0, tail_norm, alpha, beta_c)
+
+    def forward_unfused(self, x):
+        """Op-by-op composition of the same kernels (kept for the parity tests of the single operators)."""
         p = self.p if self.training else 0.0
         sa = self.self_attn
         qkv = ops.linear(x, sa.in_proj_weight, sa.in_proj_bias)

@@ -88,8 +88,7 @@ class FTTransformerPNAFusedLayer(nn.Module):
         g = ops.SubgraphIndex.build(edge_index, N)
         p = self.p if self.training else 0.0
         # x_tab + LN(enc(x_tab)) / 2   (sic, fused.py:249)
-        t = self.tab_conv(x_tab)
-        x_tab = ops.layer_norm(t, self.tab_norm.weight, self.tab_norm.bias, res=x_tab, alpha=1.0, beta_c=0.5)
+        x_tab = self.tab_conv(x_tab, self.tab_norm, 1.0, 0.5)
         # (x_gnn + relu(BN(PNA))) / 2   (fused.py:252)
         conv = self.gnn_conv(x_gnn, g, edge_attr)
         x_gnn = self.gnn_norm(conv, res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
@@ -161,9 +160,9 @@ class TABGNNFused(nn.Module):
         x_gnn = ops.linear(x.reshape(-1, self.node_dim), self.node_emb.weight, self.node_emb.bias)
 
         t0 = prepend_cls(self.cls_embedding, target_edge_attr)
-        target = ops.layer_norm(self.tab_conv(t0), tn.weight, tn.bias)                       # fused.py:160
+        target = self.tab_conv(t0, tn, 0.0, 1.0)                                             # fused.py:160
         e0 = prepend_cls(self.cls_embedding, edge_attr)
-        e = ops.layer_norm(self.tab_conv(e0), tn.weight, tn.bias, res=e0, alpha=0.5, beta_c=0.5)   # :164
+        e = self.tab_conv(e0, tn, 0.5, 0.5)                                                  # :164
         e = ops.linear(e.reshape(-1, self.edge_dim), self.edge_emb.weight, self.edge_emb.bias)     # :165-166
 
         x_tab = target
@@ -190,8 +189,7 @@ class FTTransformerLayer(nn.Module):
         self.tab_norm.reset_parameters()
 
     def forward(self, x_tab):                                                               # tabgnn.py:218-219
-        return ops.layer_norm(self.tab_conv(x_tab), self.tab_norm.weight, self.tab_norm.bias, res=x_tab, alpha=0.5,
-                              beta_c=0.5)
+        return self.tab_conv(x_tab, self.tab_norm, 0.5, 0.5)
 
 
 class PNALayer(nn.Module):

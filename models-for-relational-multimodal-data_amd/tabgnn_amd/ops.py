@@ -259,7 +259,7 @@ class _LayerNorm(torch.autograd.Function):
         partials = _workspace(L.load().tg_ln_partials_floats(M, C), a.device)
         L.call("tg_ln_bwd", L.ptr(a), L.ptr(b), L.ptr(bias_b), L.ptr(gamma), L.ptr(stats), L.ptr(g), L.ptr(da),
                L.ptr(db), L.ptr(dres), L.ptr(dparams), L.ptr(partials), M, C, alpha, beta_c, p_drop, ctx.seed, ctx.rs,
-               L.dt(a), L.stream())
+               0, L.dt(a), L.stream())
         dbias = dparams[2] if bias_b is not None else None
         return da, db, dbias, dparams[0], dparams[1], dres, None, None, None, None
 
