@@ -25,6 +25,19 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_fwd(const T* __restrict__ a, co
   long long row = (long long)blockIdx.x * groups + threadIdx.x / lpr;
   const long long rstride = (long long)gridDim.x * groups;
   const int nvec = C / VEC;
+  // a thread keeps its channel vectors for every row it visits: per-channel parameters live in registers
+  float gmr[VPL][VEC], btr[VPL][VEC], bsr[VPL][VEC];
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    int vi = gl + k * lpr;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      bool ok = vi < nvec;
+      gmr[k][j] = ok ? gamma[vi * VEC + j] : 0.f;
+      btr[k][j] = ok ? beta[vi * VEC + j] : 0.f;
+      bsr[k][j] = (ok && bias_b) ? bias_b[vi * VEC + j] : 0.f;
+    }
+  }
   for (; row < M; row += rstride) {  // lpr divides 64, M rows: whole groups iterate together
     float x[VPL][VEC];
     float s = 0.f;
@@ -37,11 +50,11 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_fwd(const T* __restrict__ a, co
         if (b) {
           float t[VEC];
           loadv<T, VEC>(b + row * C + c, t);
+          const unsigned long long e0 = (unsigned long long)(row * C + c);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float u = t[j] + (bias_b ? bias_b[c + j] : 0.f);
-            if (thresh) u *= drop_scale(seed, rstream, (unsigned long long)(row * C + c + j), thresh, inv_keep);
-            x[k][j] += u;
+          for (int j = 0; j < VEC; ++j) {   // branch-free: the mask is a select, so nothing splits the loads
+            float m = drop_scale(seed, rstream, e0 + j, thresh, inv_keep);
+            x[k][j] += (t[j] + bsr[k][j]) * (thresh ? m : 1.f);
           }
         }
 #pragma unroll
@@ -72,7 +85,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_fwd(const T* __restrict__ a, co
         int c = vi * VEC;
         float y[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) y[j] = beta_c * ((x[k][j] - mu) * rstd * gamma[c + j] + beta[c + j]);
+        for (int j = 0; j < VEC; ++j) y[j] = beta_c * ((x[k][j] - mu) * rstd * gmr[k][j] + btr[k][j]);
         if (res) {
           float r[VEC];
           loadv<T, VEC>(res + row * C + c, r);
@@ -106,6 +119,17 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
   for (int k = 0; k < VPL; ++k)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { dg[k][j] = 0.f; dbt[k][j] = 0.f; dbs[k][j] = 0.f; }
+  float gmr[VPL][VEC], bsr[VPL][VEC];   // per-channel parameters in registers (fixed channel vectors per thread)
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    int vi = gl + k * lpr;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      bool ok = vi < nvec;
+      gmr[k][j] = ok ? gamma[vi * VEC + j] : 0.f;
+      bsr[k][j] = (ok && bias_b) ? bias_b[vi * VEC + j] : 0.f;
+    }
+  }
   for (; row < M; row += rstride) {
     float mu = stats[2 * row], rstd = stats[2 * row + 1];
     float xh[VPL][VEC], gx[VPL][VEC], msk[VPL][VEC];
@@ -120,11 +144,13 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
         if (b) {
           float t[VEC];
           loadv<T, VEC>(b + row * C + c, t);
+          const unsigned long long e0 = (unsigned long long)(row * C + c);
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
-            float m = thresh ? drop_scale(seed, rstream, (unsigned long long)(row * C + c + j), thresh, inv_keep) : 1.f;
+          for (int j = 0; j < VEC; ++j) {   // branch-free (select), see k_ln_fwd
+            float m = drop_scale(seed, rstream, e0 + j, thresh, inv_keep);
+            m = thresh ? m : 1.f;
             msk[k][j] = m;
-            x[j] += (t[j] + (bias_b ? bias_b[c + j] : 0.f)) * m;
+            x[j] += (t[j] + bsr[k][j]) * m;
           }
         }
         loadv<T, VEC>(dout + row * C + c, g);
@@ -140,7 +166,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
           xh[k][j] = (x[j] - mu) * rstd;
           dg[k][j] += gj * xh[k][j];
           dbt[k][j] += gj;
-          gx[k][j] = gj * gamma[c + j];
+          gx[k][j] = gj * gmr[k][j];
           s1 += gx[k][j];
           s2 += gx[k][j] * xh[k][j];
         }
