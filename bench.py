@@ -97,8 +97,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("TABGNN_FORCE_ALLREDUCE") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
@@ -116,7 +119,7 @@ def main():
     model = T.TABGNNFusedS(cfg).to(dev).train()
     flat = T.FlatParams(model, shadow_dtype=cdt)
     opt = T.FusedAdam(flat, lr=cfg["lr"])
-    ddp = T.DataParallel(model, flat) if world > 1 else None
+    ddp = T.DataParallel(model, flat) if use_dist else None
     loss_w = torch.tensor(cfg["loss_weights"], device=dev)
 
     batches = [S.make_batch(args.batch_size, seed=42 + rank * 1000 + i, device=dev)
@@ -135,25 +138,24 @@ def main():
     run(args.warmup, 0)
     timer = ops.KernelTimer()
     ops.KernelTimer.active = timer
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     edges = run(args.steps, args.warmup)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.KernelTimer.active = None
 
     tot = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         tmax = tot.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tot.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, edges = float(tmax[0]), float(tsum[1])
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # roofline of the PNA multi-aggregation forward: E_n*(F*b + 4) read + N*4F*b written per launch
@@ -195,7 +197,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(model.state_dict(), args.nhead, args.cpu_batch_size, args.cpu_steps,
                                            cfg["lr"], cfg["loss_weights"])
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

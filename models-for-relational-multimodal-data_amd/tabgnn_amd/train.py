@@ -84,7 +84,10 @@ class DataParallel:
         self.module, self.flat = module, flat
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket = int(bucket_mb * (1 << 20) // 4)
-        if self.world > 1:
+        # TABGNN_FORCE_ALLREDUCE=1 runs the collective path even with one rank (smoke test of the RCCL plumbing)
+        import os
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("TABGNN_FORCE_ALLREDUCE") == "1")
+        if self.active:
             dist.broadcast(flat.flat, src=0)
             if sync_buffers:
                 for b in module.buffers():
@@ -93,7 +96,7 @@ class DataParallel:
 
     def all_reduce_grads(self):
         """Sum over ranks, bucketed (async, in flight together); the 1/world factor is folded into the optimiser."""
-        if self.world == 1:
+        if not self.active:
             return 1.0
         g = self.flat.grad
         works = [dist.all_reduce(g[i:i + self.bucket], op=dist.ReduceOp.SUM, async_op=True)
