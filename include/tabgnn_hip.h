@@ -127,8 +127,9 @@ int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t*
                     const int32_t* rpB, const int32_t* pmB, int32_t seedB, const void* relu_src, void* dx, int32_t N,
                     int32_t F, int32_t* hub_work, int32_t dt, void* stream);
 /* mean|max|min|std of messages h[E,F] per destination -> agg[N,4F]  (PNAConv.aggregate, "the SpMM") */
+/* perm == NULL: h rows are already in CSR (destination-sorted) order (E = number of rows of h) */
 int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const int32_t* perm, void* agg, int32_t N, int32_t F,
-                         int32_t dt, void* stream);
+                         int64_t E, int32_t dt, void* stream);
 int tg_pna_aggregate_bwd(const void* h, const void* agg, const void* dagg, const int32_t* rowptr, const int32_t* perm,
                          void* dh, int32_t N, int32_t F, int32_t dt, void* stream);
 /* degree scalers applied after the post GEMM: out = xw + G0 + amp*G1 + att*G2 (DegreeScalerAggregation) */

@@ -81,6 +81,13 @@ template <> struct V16<bf16_t> {
 template <typename T, int VEC> __device__ __forceinline__ void loadv(const T* p, float (&o)[VEC]) {
   if constexpr (VEC == V16<T>::N) {
     V16<T>::load(p, o);
+  } else if constexpr (sizeof(T) == 2 && VEC == 2) {   // 4-byte access: 2 bf16
+    unsigned r = *reinterpret_cast<const unsigned*>(p);
+    o[0] = __uint_as_float(r << 16); o[1] = __uint_as_float(r & 0xffff0000u);
+  } else if constexpr (sizeof(T) == 2 && VEC == 4) {   // 8-byte access: 4 bf16
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = to_f<T>(p[i]);
@@ -89,6 +96,13 @@ template <typename T, int VEC> __device__ __forceinline__ void loadv(const T* p,
 template <typename T, int VEC> __device__ __forceinline__ void storev(T* p, const float (&o)[VEC]) {
   if constexpr (VEC == V16<T>::N) {
     V16<T>::store(p, o);
+  } else if constexpr (sizeof(T) == 2 && VEC == 2) {
+    *reinterpret_cast<unsigned*>(p) = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+  } else if constexpr (sizeof(T) == 2 && VEC == 4) {
+    uint2 w;
+    w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+    w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = w;
   } else {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) p[i] = from_f<T>(o[i]);

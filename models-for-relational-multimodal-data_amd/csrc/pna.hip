@@ -169,7 +169,9 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
 // 16-byte loads of whole message rows in CSR order, single pass for sum, sum of squares, max, min.
 constexpr float STD_EPS = 1e-5f;
 
-template <typename T, int VEC>
+// SORTED: the messages are already in CSR (destination-sorted) order — row q of h IS position q of the CSR, so the
+// perm indirection disappears and consecutive destinations read consecutive rows (a pure stream).
+template <typename T, int VEC, bool SORTED>
 __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__ h, const int* __restrict__ rowptr,
                                                             const int* __restrict__ perm, T* __restrict__ agg, int N,
                                                             int F) {
@@ -184,9 +186,25 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; mx[j] = -INFINITY; mn[j] = INFINITY; }
     int q = s;
+    // long segments (the few high in-degree destinations set the kernel's tail): eight rows in flight, summed in
+    // CSR order as always
+    for (; q + 7 < e; q += 8) {
+      int r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = SORTED ? q + u : perm[q + u];
+      float v[8][VEC];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) loadv<T, VEC>(h + (long long)r[u] * F + c, v[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          s1[j] += v[u][j]; s2[j] += v[u][j] * v[u][j]; mx[j] = fmaxf(mx[j], v[u][j]); mn[j] = fminf(mn[j], v[u][j]);
+        }
+    }
     for (; q + 1 < e; q += 2) {  // two rows in flight
       float a[VEC], b[VEC];
-      int r0 = perm[q], r1 = perm[q + 1];
+      int r0 = SORTED ? q : perm[q], r1 = SORTED ? q + 1 : perm[q + 1];
       loadv<T, VEC>(h + (long long)r0 * F + c, a);
       loadv<T, VEC>(h + (long long)r1 * F + c, b);
 #pragma unroll
@@ -197,7 +215,7 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
     }
     if (q < e) {
       float a[VEC];
-      loadv<T, VEC>(h + (long long)perm[q] * F + c, a);
+      loadv<T, VEC>(h + (long long)(SORTED ? q : perm[q]) * F + c, a);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         s1[j] += a[j]; s2[j] += a[j] * a[j]; mx[j] = fmaxf(mx[j], a[j]); mn[j] = fminf(mn[j], a[j]);
@@ -227,7 +245,7 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
 
 // backward: dh[e] = g_mean/cnt + [h==max] g_max/ties + [h==min] g_min/ties + g_std (h-mean)/(cnt*std)
 // (ties share the gradient evenly, as torch.scatter_reduce amax/amin backward does)
-template <typename T, int VEC>
+template <typename T, int VEC, bool SORTED>
 __global__ void __launch_bounds__(256) k_pna_aggregate_bwd(const T* __restrict__ h, const T* __restrict__ agg,
                                                             const T* __restrict__ dagg, const int* __restrict__ rowptr,
                                                             const int* __restrict__ perm, T* __restrict__ dh, int N,
@@ -250,9 +268,19 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_bwd(const T* __restrict__
     if (e - s > 1) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { tx[j] = 0.f; tn[j] = 0.f; }
-      for (int q = s; q < e; ++q) {
+      int q = s;
+      for (; q + 3 < e; q += 4) {   // four rows in flight (high in-degree destinations set the tail)
+        float v[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) loadv<T, VEC>(h + (long long)(SORTED ? q + u : perm[q + u]) * F + c, v[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { tx[j] += (v[u][j] == mx[j]); tn[j] += (v[u][j] == mn[j]); }
+      }
+      for (; q < e; ++q) {
         float v[VEC];
-        loadv<T, VEC>(h + (long long)perm[q] * F + c, v);
+        loadv<T, VEC>(h + (long long)(SORTED ? q : perm[q]) * F + c, v);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { tx[j] += (v[j] == mx[j]); tn[j] += (v[j] == mn[j]); }
       }
@@ -267,8 +295,23 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_bwd(const T* __restrict__
       gn[j] = gn[j] / fmaxf(tn[j], 1.f);
       gs[j] = sd[j] > 0.f ? gs[j] * inv / sd[j] : 0.f;
     }
-    for (int q = s; q < e; ++q) {
-      int row = perm[q];
+    int q = s;
+    for (; q + 3 < e; q += 4) {
+      int row[4];
+      float v[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { row[u] = SORTED ? q + u : perm[q + u]; loadv<T, VEC>(h + (long long)row[u] * F + c, v[u]); }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          o[j] = gm[j] + (v[u][j] == mx[j] ? gx[j] : 0.f) + (v[u][j] == mn[j] ? gn[j] : 0.f) + gs[j] * (v[u][j] - mean[j]);
+        storev<T, VEC>(dh + (long long)row[u] * F + c, o);
+      }
+    }
+    for (; q < e; ++q) {
+      int row = SORTED ? q : perm[q];
       float v[VEC], o[VEC];
       loadv<T, VEC>(h + (long long)row * F + c, v);
 #pragma unroll
@@ -390,12 +433,25 @@ extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, con
 }
 
 extern "C" int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const int32_t* perm, void* agg, int32_t N,
-                                    int32_t F, int32_t dt, void* stream) {
+                                    int32_t F, int64_t E, int32_t dt, void* stream) {
   TG_CHECK(F % 8 == 0 && N > 0, "tg_pna_aggregate_fwd: F must be a multiple of 8 (F=%d)", F);
+  if (dt == BF16 && !perm && 256 % (F / 4) == 0) {
+    // destination-sorted bf16 messages: 8-byte lanes (2x the lanes per destination) measured fastest on MI355X
+    // (155 us vs 179 us with 16-byte lanes at N=524k, F=128: the kernel is latency-, not byte-bound per wave)
+    long long total = (long long)N * (F / 4);
+    hipLaunchKernelGGL((k_pna_aggregate_fwd<bf16_t, 4, true>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
+                       dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, rowptr, perm, (bf16_t*)agg, N, F);
+    TG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dt, {
     long long total = (long long)N * (F / VEC);
-    hipLaunchKernelGGL((k_pna_aggregate_fwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)), dim3(256), 0,
-                       (hipStream_t)stream, (const T*)h, rowptr, perm, (T*)agg, N, F);
+    if (perm)
+      hipLaunchKernelGGL((k_pna_aggregate_fwd<T, VEC, false>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
+                         dim3(256), 0, (hipStream_t)stream, (const T*)h, rowptr, perm, (T*)agg, N, F);
+    else
+      hipLaunchKernelGGL((k_pna_aggregate_fwd<T, VEC, true>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
+                         dim3(256), 0, (hipStream_t)stream, (const T*)h, rowptr, perm, (T*)agg, N, F);
   })
   TG_LAUNCH_CHECK();
   return 0;
@@ -406,8 +462,14 @@ extern "C" int tg_pna_aggregate_bwd(const void* h, const void* agg, const void* 
   TG_CHECK(F % 8 == 0 && N > 0, "tg_pna_aggregate_bwd: F must be a multiple of 8 (F=%d)", F);
   DISPATCH_T(dt, {
     long long total = (long long)N * (F / VEC);
-    hipLaunchKernelGGL((k_pna_aggregate_bwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)), dim3(256), 0,
-                       (hipStream_t)stream, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm, (T*)dh, N, F);
+    if (perm)
+      hipLaunchKernelGGL((k_pna_aggregate_bwd<T, VEC, false>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
+                         dim3(256), 0, (hipStream_t)stream, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm,
+                         (T*)dh, N, F);
+    else
+      hipLaunchKernelGGL((k_pna_aggregate_bwd<T, VEC, true>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
+                         dim3(256), 0, (hipStream_t)stream, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm,
+                         (T*)dh, N, F);
   })
   TG_LAUNCH_CHECK();
   return 0;

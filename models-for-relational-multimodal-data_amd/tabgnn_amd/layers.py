@@ -145,8 +145,9 @@ class PNAConv(nn.Module):
         w3 = pre.weight[:, 2 * F:] @ self.edge_encoder.weight
         w_msg = torch.cat([pre.weight[:, :2 * F], w3], dim=1)
         b_msg = pre.bias + pre.weight[:, 2 * F:] @ self.edge_encoder.bias
-        h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst"), w_msg, b_msg)
-        agg = ops.pna_aggregate(h, g)                                   # [N,4F]
+        # messages are produced directly in destination-sorted order: the aggregation then streams contiguous rows
+        h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst_sorted"), w_msg, b_msg)
+        agg = ops.pna_aggregate(h, g, sorted_rows=True)                 # [N,4F]
         # lin(post([x, agg, amp*agg, att*agg])) = x Wx^T + b + (agg Wid^T) + amp (agg Wamp^T) + att (agg Watt^T)
         w_eff = self.lin.weight @ post.weight                            # [F,13F]
         b_eff = self.lin.weight @ post.bias + self.lin.bias

@@ -113,6 +113,20 @@ class SubgraphIndex:
         """The graph with every edge reversed (``edge_index.flipud()``, src/nn/gnn/pna.py:40)."""
         return SubgraphIndex(self.dst, self.src, self.by_src, self.by_dst, self.N)
 
+    def sorted_view(self):
+        """Index arrays for laying the messages out in destination-sorted (CSR) order, so the aggregation streams
+        contiguous rows with no indirection: row k of the sorted layout is edge ``perm[k]``."""
+        sv = getattr(self, "_sorted", None)
+        if sv is None:
+            perm = self.by_dst[1][:self.E].long()
+            inv = torch.empty(self.E, dtype=torch.int32, device=perm.device)
+            inv[perm] = torch.arange(self.E, dtype=torch.int32, device=perm.device)
+            sv = dict(perm=self.by_dst[1], dst=self.dst[perm].contiguous(), src=self.src[perm].contiguous(), inv=inv,
+                      arange=torch.arange(max(self.E, 1), dtype=torch.int32, device=perm.device),
+                      src_to_sorted=inv[self.by_src[1][:self.E].long()].contiguous())
+            self._sorted = sv
+        return sv
+
 
 class SeedIndex:
     """Seed edges ``target_edge_index [2,B]``: int32 endpoints and the CSR over the 2B endpoint slots
@@ -384,10 +398,16 @@ class _EdgeGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, e, graph, first):
         # first == "dst": [x[dst], x[src], e] (message, x_i = target);  first == "src": [x[src], x[dst], e]
+        # first == "dst_sorted": as "dst" but row k is edge perm[k] (destination-sorted layout for the aggregation)
         x, e = x.contiguous(), e.contiguous()
         F = x.shape[1]
-        ia, ib = (graph.dst, graph.src) if first == "dst" else (graph.src, graph.dst)
-        out = _gather3([(x, ia, F, 0), (x, ib, F, 0), (e, None, e.shape[1], 0)], e.shape[0], x.dtype, x.device)
+        if first == "dst_sorted":
+            sv = graph.sorted_view()
+            parts = [(x, sv["dst"], F, 0), (x, sv["src"], F, 0), (e, sv["perm"], e.shape[1], 0)]
+        else:
+            ia, ib = (graph.dst, graph.src) if first == "dst" else (graph.src, graph.dst)
+            parts = [(x, ia, F, 0), (x, ib, F, 0), (e, None, e.shape[1], 0)]
+        out = _gather3(parts, e.shape[0], x.dtype, x.device)
         ctx.graph, ctx.first, ctx.F, ctx.We = graph, first, F, e.shape[1]
         return out
 
@@ -395,12 +415,21 @@ class _EdgeGather(torch.autograd.Function):
     def backward(ctx, g):
         g = g.contiguous()
         graph, F = ctx.graph, ctx.F
-        csr_a, csr_b = (graph.by_dst, graph.by_src) if ctx.first == "dst" else (graph.by_src, graph.by_dst)
+        if ctx.first == "dst_sorted":
+            sv = graph.sorted_view()
+            csr_a, csr_b = (graph.by_dst[0], sv["arange"]), (graph.by_src[0], sv["src_to_sorted"])
+        else:
+            csr_a, csr_b = (graph.by_dst, graph.by_src) if ctx.first == "dst" else (graph.by_src, graph.by_dst)
         dx = torch.empty(graph.N, F, dtype=g.dtype, device=g.device)
         hub = torch.empty(L.load().tg_segment_hub_ints(2 * graph.E), dtype=torch.int32, device=g.device)
         L.call("tg_segment_sum2", L.ptr(g), g.shape[1], 0, L.ptr(csr_a[0]), L.ptr(csr_a[1]), F, L.ptr(csr_b[0]),
                L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.ptr(hub), L.dt(g), L.stream())
-        de = g[:, 2 * F:].contiguous()
+        if ctx.first == "dst_sorted":          # de[edge] = g[inv[edge], 2F:]: one row gather back to edge order
+            tail = g[:, 2 * F:]
+            de = _gather3([(tail, sv["inv"], ctx.We, 0), (tail, None, 0, 0), (tail, None, 0, 0)], g.shape[0], g.dtype,
+                          g.device)
+        else:
+            de = g[:, 2 * F:].contiguous()
         return dx, de, None, None
 
 
@@ -462,12 +491,15 @@ class _PNAAggregate(torch.autograd.Function):
     """messages h [E,F] -> [N,4F] = mean | max | min | std per destination."""
 
     @staticmethod
-    def forward(ctx, h, graph):
+    def forward(ctx, h, graph, sorted_rows):
         h = h.contiguous()
         E, F = h.shape
         rowptr, perm = graph.by_dst
+        if sorted_rows:          # h rows already in CSR order: no indirection (perm = NULL selects the streaming kernel)
+            perm = None
+        ctx.sorted_rows = sorted_rows
         agg = torch.empty(graph.N, 4 * F, dtype=h.dtype, device=h.device)
-        _launch("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rowptr), L.ptr(perm), L.ptr(agg), graph.N, F, L.dt(h),
+        _launch("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rowptr), L.ptr(perm), L.ptr(agg), graph.N, F, E, L.dt(h),
                 L.stream())
         ctx.save_for_backward(h, agg)
         ctx.graph = graph
@@ -477,14 +509,17 @@ class _PNAAggregate(torch.autograd.Function):
     def backward(ctx, g):
         h, agg = ctx.saved_tensors
         rowptr, perm = ctx.graph.by_dst
+        if ctx.sorted_rows:
+            perm = None
         dh = torch.empty_like(h)
         _launch("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(g.contiguous()), L.ptr(rowptr), L.ptr(perm),
                 L.ptr(dh), ctx.graph.N, h.shape[1], L.dt(h), L.stream())
-        return dh, None
+        return dh, None, None
 
 
-def pna_aggregate(h, graph):
-    return _PNAAggregate.apply(h, graph)
+def pna_aggregate(h, graph, sorted_rows=False):
+    """h [E,F] -> [N,4F].  ``sorted_rows``: h is laid out in destination-sorted order (``edge_gather(..., "dst_sorted")``)."""
+    return _PNAAggregate.apply(h, graph, bool(sorted_rows))
 
 
 class _ScaleCombine(torch.autograd.Function):
