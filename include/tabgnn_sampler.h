@@ -1,0 +1,28 @@
+/* tabgnn_sampler.h — C ABI of libtabgnn_sampler.so: host-side (CPU, OpenMP) k-hop neighbour sampler + relabel for
+ * edge-seeded mini-batches.  SURVEY.md §8f rank 1: replaces, per mini-batch,
+ *   sample_neighbors  src/datasets/ibm_transactions_for_aml.py:61-112 (PyG NeighborSampler.sample_from_edges,
+ *                     built at src/datasets/util/graph.py:38,46,53) and
+ *   get_graph_inputs  src/datasets/ibm_transactions_for_aml.py:159-180 (sorted-unique relabel through a Python dict).
+ * All pointers are HOST pointers.  Returns 0 / non-NULL on success; tg_sampler_last_error() has the message. */
+#ifndef TABGNN_SAMPLER_H_
+#define TABGNN_SAMPLER_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+const char* tg_sampler_last_error(void);
+/* src/dst: int64 [E] node ids in [0, num_nodes); the edge id is the position.  Builds the in-edge CSC once. */
+void* tg_sampler_create(const int64_t* src, const int64_t* dst, int64_t E, int64_t num_nodes);
+void tg_sampler_destroy(void* handle);
+int64_t tg_sampler_num_edges(void* handle);
+int64_t tg_sampler_max_edges(int64_t B, const int32_t* fanout, int32_t hops);
+/* fanout[h] < 0 = take every in-edge.  out_edge_index is [2, cap] (row stride cap) with LOCAL node ids;
+ * out_nodes = sorted global ids of the n_nodes subgraph nodes; seed edges occupy the first B output slots. */
+int tg_sampler_sample(void* handle, const int64_t* seed_src, const int64_t* seed_dst, const int64_t* seed_eid, int64_t B,
+                      const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
+                      int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, int64_t* n_edges,
+                      int64_t* n_nodes);
+#ifdef __cplusplus
+}
+#endif
+#endif

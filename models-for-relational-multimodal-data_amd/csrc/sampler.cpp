@@ -1,0 +1,231 @@
+// Host-side k-hop neighbour sampler + relabel for edge-seeded mini-batches.
+//
+// Replaces, on the CPU and multi-threaded, what the reference does per mini-batch in Python:
+//   * sample_neighbors           src/datasets/ibm_transactions_for_aml.py:61-112
+//     (torch_geometric NeighborSampler.sample_from_edges, built at src/datasets/util/graph.py:38,46,53 with
+//      num_neighbors=[100,100], directional, without replacement; seed edges first, in order, and sampled edges
+//      that ARE seed edges dropped: ibm…py:102-110),
+//   * get_graph_inputs           ibm…py:159-180  (nodes = sorted unique endpoints, O(E) Python dict relabel).
+//
+// Semantics kept: hop h expands every node of the current frontier once, drawing min(in-degree, fanout[h]) of its
+// incoming edges uniformly without replacement; new source nodes form the next frontier; output = seed edges (in
+// the given order) followed by the sampled non-seed edges in sampling order; node ids are relabelled to their
+// rank among the sorted unique endpoints.  The draw of node v at hop h depends only on (seed, h, v): results are
+// identical for any thread count (the reference's sampler is unseeded; only distributional parity is possible).
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct Graph {
+  int64_t num_nodes = 0, num_edges = 0;
+  std::vector<int64_t> colptr;   // [num_nodes+1]  in-edges of node v: colptr[v]..colptr[v+1]
+  std::vector<int64_t> in_src;   // source node of each in-edge (CSC order)
+  std::vector<int64_t> in_eid;   // original edge id of each in-edge
+  // per-handle scratch (one sample() call at a time per handle): visited stamps and local ids, O(1) per touch
+  std::vector<uint32_t> mark;    // [num_nodes]  mark[v] == stamp  <=>  v is in the current subgraph
+  std::vector<int64_t> local;    // [num_nodes]  local id of v (valid where marked)
+  uint32_t stamp = 0;
+};
+
+inline uint64_t splitmix64(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+inline uint64_t bounded(uint64_t& s, uint64_t n) {   // unbiased enough for sampling (n << 2^64): multiply-shift
+  return (uint64_t)(((unsigned __int128)splitmix64(s) * n) >> 64);
+}
+
+// k distinct positions out of [0, deg) (Floyd), appended in increasing position order for determinism
+void sample_positions(int64_t deg, int64_t k, uint64_t& rng, std::vector<int64_t>& out) {
+  out.clear();
+  if (deg <= k) {
+    for (int64_t i = 0; i < deg; ++i) out.push_back(i);
+    return;
+  }
+  std::unordered_set<int64_t> chosen;
+  chosen.reserve((size_t)k * 2);
+  for (int64_t j = deg - k; j < deg; ++j) {
+    int64_t t = (int64_t)bounded(rng, (uint64_t)j + 1);
+    if (!chosen.insert(t).second) chosen.insert(j);
+  }
+  out.assign(chosen.begin(), chosen.end());
+  std::sort(out.begin(), out.end());
+}
+
+thread_local char g_err[256] = "";
+
+}  // namespace
+
+extern "C" {
+
+const char* tg_sampler_last_error(void) { return g_err; }
+
+// src/dst: int64 [E] global node ids in [0, num_nodes); edge id = position.  Returns an opaque handle (NULL on error).
+void* tg_sampler_create(const int64_t* src, const int64_t* dst, int64_t E, int64_t num_nodes) {
+  if (E < 0 || num_nodes <= 0) {
+    snprintf(g_err, sizeof(g_err), "tg_sampler_create: bad sizes E=%lld N=%lld", (long long)E, (long long)num_nodes);
+    return nullptr;
+  }
+  for (int64_t e = 0; e < E; ++e)
+    if (src[e] < 0 || src[e] >= num_nodes || dst[e] < 0 || dst[e] >= num_nodes) {
+      snprintf(g_err, sizeof(g_err), "tg_sampler_create: edge %lld has a node id outside [0, %lld)", (long long)e,
+               (long long)num_nodes);
+      return nullptr;
+    }
+  Graph* g = new Graph();
+  g->num_nodes = num_nodes;
+  g->num_edges = E;
+  g->colptr.assign((size_t)num_nodes + 1, 0);
+  for (int64_t e = 0; e < E; ++e) g->colptr[(size_t)dst[e] + 1]++;
+  for (int64_t v = 0; v < num_nodes; ++v) g->colptr[(size_t)v + 1] += g->colptr[(size_t)v];
+  g->in_src.resize((size_t)E);
+  g->in_eid.resize((size_t)E);
+  g->mark.assign((size_t)num_nodes, 0u);
+  g->local.assign((size_t)num_nodes, 0);
+  std::vector<int64_t> cur(g->colptr.begin(), g->colptr.end() - 1);
+  for (int64_t e = 0; e < E; ++e) {   // stable: in-edges of a node stay in edge-id order
+    int64_t p = cur[(size_t)dst[e]]++;
+    g->in_src[(size_t)p] = src[e];
+    g->in_eid[(size_t)p] = e;
+  }
+  return g;
+}
+
+void tg_sampler_destroy(void* h) { delete (Graph*)h; }
+
+int64_t tg_sampler_num_edges(void* h) { return ((Graph*)h)->num_edges; }
+
+// Upper bound of output edges for B seed edges: B + sum over hops of (frontier bound * fanout)
+int64_t tg_sampler_max_edges(int64_t B, const int32_t* fanout, int32_t hops) {
+  int64_t frontier = 2 * B, total = B;
+  for (int h = 0; h < hops; ++h) {
+    int64_t e = frontier * (int64_t)fanout[h];
+    total += e;
+    frontier = e;
+  }
+  return total;
+}
+
+// Outputs (caller-allocated, capacity `cap` edges / 2*cap nodes):
+//   out_eid [n_edges]           global edge ids, seed edges first
+//   out_edge_index [2, cap]     LOCAL node ids (row 0 = src at [0..n_edges), row 1 = dst at [cap..cap+n_edges))
+//   out_nodes [n_nodes]         sorted global node ids (local id = position)
+// Returns 0, or non-zero with tg_sampler_last_error().
+int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst, const int64_t* seed_eid, int64_t B,
+                      const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
+                      int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, int64_t* n_edges,
+                      int64_t* n_nodes) {
+  Graph& g = *(Graph*)h;
+  if (B <= 0 || hops < 0 || cap < B) {
+    snprintf(g_err, sizeof(g_err), "tg_sampler_sample: bad arguments B=%lld hops=%d cap=%lld", (long long)B, hops,
+             (long long)cap);
+    return 1;
+  }
+  std::vector<int64_t> e_src, e_dst, e_id;
+  if (++g.stamp == 0) {            // stamp wrapped: clear the marks once every 2^32 calls
+    std::fill(g.mark.begin(), g.mark.end(), 0u);
+    g.stamp = 1;
+  }
+  const uint32_t stamp = g.stamp;
+  std::unordered_set<int64_t> seed_ids;
+  seed_ids.reserve((size_t)B * 2);
+  for (int64_t i = 0; i < B; ++i) {
+    if (seed_src[i] < 0 || seed_src[i] >= g.num_nodes || seed_dst[i] < 0 || seed_dst[i] >= g.num_nodes) {
+      snprintf(g_err, sizeof(g_err), "tg_sampler_sample: seed edge %lld has a node id out of range", (long long)i);
+      return 1;
+    }
+    e_src.push_back(seed_src[i]); e_dst.push_back(seed_dst[i]); e_id.push_back(seed_eid[i]);
+    seed_ids.insert(seed_eid[i]);
+  }
+  // frontier 0 = sorted unique seed endpoints (torch.cat([src, dst]).unique())
+  std::vector<int64_t> frontier(e_src.begin(), e_src.end());
+  frontier.insert(frontier.end(), e_dst.begin(), e_dst.end());
+  std::sort(frontier.begin(), frontier.end());
+  frontier.erase(std::unique(frontier.begin(), frontier.end()), frontier.end());
+  std::vector<int64_t> touched(frontier);          // every node of the subgraph, in first-appearance order
+  for (int64_t v : frontier) g.mark[(size_t)v] = stamp;
+
+#ifdef _OPENMP
+  const int nthreads = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  const int nthreads = 1;
+#endif
+  for (int hop = 0; hop < hops; ++hop) {
+    const int64_t nf = (int64_t)frontier.size();
+    const int64_t k = fanout[hop];
+    // pass 1: counts -> offsets (deterministic layout in frontier order)
+    std::vector<int64_t> off((size_t)nf + 1, 0);
+    for (int64_t i = 0; i < nf; ++i) {
+      int64_t deg = g.colptr[(size_t)frontier[(size_t)i] + 1] - g.colptr[(size_t)frontier[(size_t)i]];
+      off[(size_t)i + 1] = off[(size_t)i] + (k < 0 ? deg : std::min(deg, k));
+    }
+    const int64_t tot = off[(size_t)nf];
+    std::vector<int64_t> h_src((size_t)tot), h_dst((size_t)tot), h_id((size_t)tot);
+#pragma omp parallel num_threads(nthreads) if (nf >= 4096)
+    {
+      std::vector<int64_t> pos;
+#pragma omp for schedule(dynamic, 64)
+      for (int64_t i = 0; i < nf; ++i) {
+        const int64_t v = frontier[(size_t)i];
+        const int64_t base = g.colptr[(size_t)v], deg = g.colptr[(size_t)v + 1] - base;
+        uint64_t rng = rng_seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(v + 1));
+        sample_positions(deg, k < 0 ? deg : k, rng, pos);
+        int64_t o = off[(size_t)i];
+        for (int64_t p : pos) {
+          h_src[(size_t)o] = g.in_src[(size_t)(base + p)];
+          h_dst[(size_t)o] = v;
+          h_id[(size_t)o] = g.in_eid[(size_t)(base + p)];
+          ++o;
+        }
+      }
+    }
+    // serial merge: drop seed edges, grow the next frontier in first-appearance order
+    std::vector<int64_t> next;
+    for (int64_t j = 0; j < tot; ++j) {
+      if (!seed_ids.count(h_id[(size_t)j])) {
+        if ((int64_t)e_id.size() >= cap) {
+          snprintf(g_err, sizeof(g_err), "tg_sampler_sample: output capacity %lld exceeded", (long long)cap);
+          return 2;
+        }
+        e_src.push_back(h_src[(size_t)j]); e_dst.push_back(h_dst[(size_t)j]); e_id.push_back(h_id[(size_t)j]);
+      }
+      const int64_t u = h_src[(size_t)j];
+      if (g.mark[(size_t)u] != stamp) {
+        g.mark[(size_t)u] = stamp;
+        next.push_back(u);
+        touched.push_back(u);
+      }
+    }
+    frontier.swap(next);
+  }
+
+  // relabel: every endpoint is a touched node (seed endpoints, expanded destinations, sampled sources);
+  // sorted unique endpoints (torch.unique) = sorted touched list, local id = rank, looked up through g.local
+  const int64_t ne = (int64_t)e_id.size();
+  std::sort(touched.begin(), touched.end());
+  const int64_t nn = (int64_t)touched.size();
+  for (int64_t i = 0; i < nn; ++i) g.local[(size_t)touched[(size_t)i]] = i;
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (ne >= 65536)
+  for (int64_t j = 0; j < ne; ++j) {
+    out_eid[j] = e_id[(size_t)j];
+    out_edge_index[j] = g.local[(size_t)e_src[(size_t)j]];
+    out_edge_index[cap + j] = g.local[(size_t)e_dst[(size_t)j]];
+  }
+  std::memcpy(out_nodes, touched.data(), (size_t)nn * sizeof(int64_t));
+  *n_edges = ne;
+  *n_nodes = nn;
+  return 0;
+}
+
+}  // extern "C"

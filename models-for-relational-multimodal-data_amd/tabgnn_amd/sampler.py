@@ -1,0 +1,129 @@
+"""Host-side input pipeline pieces either side of the hot path:
+
+* ``NeighborSampler`` — native (C++/OpenMP, ``libtabgnn_sampler.so``) k-hop edge-seeded sampler + relabel replacing
+  ``sample_neighbors`` / the dict relabel of ``get_graph_inputs``
+  (``src/datasets/ibm_transactions_for_aml.py:61-112,159-180``; PyG ``NeighborSampler`` built at
+  ``src/datasets/util/graph.py:38,46,53``).
+* ``ColumnStore`` — columnar raw edge/node tables (optionally resident in HBM) with batch row gather: the
+  ``TensorFrame.__getitem__`` calls of ``get_graph_inputs`` (``ibm…py:163,168``), so a mini-batch is assembled as
+  ``(node_tf, edge_index, edge_tf, y)`` exactly as ``main.py:48`` receives it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from .frame import TensorFrame
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtabgnn_sampler.so")
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: build it with `make -C models-for-relational-multimodal-data_amd`")
+        lib = C.CDLL(_LIB_PATH)
+        i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        lib.tg_sampler_last_error.restype = C.c_char_p
+        lib.tg_sampler_create.argtypes = [i64p, i64p, C.c_int64, C.c_int64]
+        lib.tg_sampler_create.restype = C.c_void_p
+        lib.tg_sampler_destroy.argtypes = [C.c_void_p]
+        lib.tg_sampler_num_edges.argtypes = [C.c_void_p]
+        lib.tg_sampler_num_edges.restype = C.c_int64
+        lib.tg_sampler_max_edges.argtypes = [C.c_int64, i32p, C.c_int32]
+        lib.tg_sampler_max_edges.restype = C.c_int64
+        lib.tg_sampler_sample.argtypes = [C.c_void_p, i64p, i64p, i64p, C.c_int64, i32p, C.c_int32, C.c_uint64,
+                                          C.c_int32, C.c_int64, i64p, i64p, i64p, i64p, i64p]
+        lib.tg_sampler_sample.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def _p64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class NeighborSampler:
+    """k-hop sampler over the in-edges of a directed graph; edge id = position in ``edge_index``."""
+
+    def __init__(self, edge_index, num_nodes, num_neighbors=(100, 100), num_threads=0):
+        lib = _load()
+        ei = np.ascontiguousarray(np.asarray(edge_index, dtype=np.int64))
+        if ei.ndim != 2 or ei.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        self._src, self._dst = np.ascontiguousarray(ei[0]), np.ascontiguousarray(ei[1])
+        self.num_nodes, self.num_edges = int(num_nodes), ei.shape[1]
+        self.fanout = np.asarray(list(num_neighbors), dtype=np.int32)
+        self.num_threads = int(num_threads)
+        self._h = lib.tg_sampler_create(_p64(self._src), _p64(self._dst), self.num_edges, self.num_nodes)
+        if not self._h:
+            raise ValueError(lib.tg_sampler_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _lib is not None:
+            _lib.tg_sampler_destroy(self._h)
+            self._h = None
+
+    def sample(self, seed_eids, rng_seed=0):
+        """-> (eid int64 [E_out] (seed edges first, in order), edge_index int64 [2, E_out] LOCAL ids,
+        nodes int64 [N_out] sorted global ids)."""
+        lib = _load()
+        seeds = np.ascontiguousarray(np.asarray(seed_eids, dtype=np.int64))
+        B = seeds.shape[0]
+        if B == 0:
+            raise ValueError("need at least one seed edge")
+        if seeds.min() < 0 or seeds.max() >= self.num_edges:
+            raise ValueError("seed edge id out of range")
+        s_src, s_dst = np.ascontiguousarray(self._src[seeds]), np.ascontiguousarray(self._dst[seeds])
+        fan = self.fanout
+        bound = lib.tg_sampler_max_edges(B, fan.ctypes.data_as(C.POINTER(C.c_int32)), len(fan)) if (fan >= 0).all() \
+            else self.num_edges + B
+        cap = int(min(bound, self.num_edges + B))
+        out_eid = np.empty(cap, dtype=np.int64)
+        out_ei = np.empty((2, cap), dtype=np.int64)
+        out_nodes = np.empty(2 * cap, dtype=np.int64)
+        ne, nn = C.c_int64(0), C.c_int64(0)
+        rc = lib.tg_sampler_sample(self._h, _p64(s_src), _p64(s_dst), _p64(seeds), B,
+                                   fan.ctypes.data_as(C.POINTER(C.c_int32)), len(fan), int(rng_seed) & (2 ** 64 - 1),
+                                   self.num_threads, cap, _p64(out_eid), _p64(out_ei), _p64(out_nodes), C.byref(ne),
+                                   C.byref(nn))
+        if rc != 0:
+            raise RuntimeError(lib.tg_sampler_last_error().decode())
+        ne, nn = ne.value, nn.value
+        return (torch.from_numpy(out_eid[:ne].copy()), torch.from_numpy(np.ascontiguousarray(out_ei[:, :ne])),
+                torch.from_numpy(out_nodes[:nn].copy()))
+
+
+class ColumnStore:
+    """Raw edge table (dict stype -> tensor [E_total, ...]) + labels, node table (dict stype -> [V, ...]); tensors may
+    live on the host or on the MI355X (then the per-batch gather runs on the device and nothing crosses PCIe but ids)."""
+
+    def __init__(self, edge_feats, edge_cols, node_feats, node_cols, labels):
+        self.edge_feats, self.edge_cols = edge_feats, edge_cols
+        self.node_feats, self.node_cols = node_feats, node_cols
+        self.labels = labels
+
+    def to(self, device):
+        return ColumnStore({k: v.to(device) for k, v in self.edge_feats.items()}, self.edge_cols,
+                           {k: v.to(device) for k, v in self.node_feats.items()}, self.node_cols,
+                           self.labels.to(device))
+
+    @property
+    def device(self):
+        return self.labels.device
+
+    def graph_inputs(self, sampler: NeighborSampler, seed_eids, rng_seed=0):
+        """``get_graph_inputs`` (ibm…py:159-180): (node_tf, edge_index, edge_tf, y) with the seed edges first."""
+        eid, edge_index, nodes = sampler.sample(seed_eids, rng_seed)
+        dev = self.device
+        eid_d, nodes_d = eid.to(dev), nodes.to(dev)
+        edge_tf = TensorFrame({k: v.index_select(0, eid_d) for k, v in self.edge_feats.items()}, self.edge_cols)
+        node_tf = TensorFrame({k: v.index_select(0, nodes_d) for k, v in self.node_feats.items()}, self.node_cols)
+        y = self.labels.index_select(0, eid_d[:len(seed_eids)])
+        return node_tf, edge_index.to(dev), edge_tf, y

@@ -1,0 +1,98 @@
+"""CPU: native neighbour sampler + relabel (libtabgnn_sampler.so) — exact k-hop neighbourhood when the fan-out covers
+every in-edge, contract properties under real sampling (seed edges first and in order, no seed edge repeated, fan-out
+respected per expanded node, relabel = rank among sorted unique endpoints), determinism across thread counts."""
+import numpy as np
+import pytest
+import torch
+
+from tabgnn_amd.sampler import ColumnStore, NeighborSampler
+from tabgnn_amd import synthetic as S
+from tabgnn_amd.frame import stype
+
+
+def _graph(n=300, e=4000, seed=0):
+    rs = np.random.RandomState(seed)
+    src = rs.randint(0, n, e)
+    dst = (rs.zipf(1.6, e) - 1) % n            # heavy-tailed in-degree
+    return np.stack([src, dst]).astype(np.int64), n
+
+
+def _khop_reference(ei, seeds, hops):
+    """Exact directed k-hop in-neighbourhood (every in-edge taken), in the sampler's output order."""
+    src, dst = ei
+    frontier = np.unique(np.concatenate([src[seeds], dst[seeds]]))
+    visited = set(frontier.tolist())
+    seed_set = set(seeds.tolist())
+    out = list(seeds)
+    order = np.argsort(dst, kind="stable")
+    ptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=ei.max() + 1))])
+    for _ in range(hops):
+        nxt = []
+        for v in frontier:
+            for e in order[ptr[v]:ptr[v + 1]]:
+                if e not in seed_set:
+                    out.append(e)
+                if src[e] not in visited:
+                    visited.add(src[e]); nxt.append(src[e])
+        frontier = np.array(nxt, dtype=np.int64)
+    return np.array(out, dtype=np.int64)
+
+
+def test_full_fanout_equals_exact_khop_neighbourhood():
+    ei, n = _graph()
+    s = NeighborSampler(ei, n, num_neighbors=(-1, -1))
+    seeds = np.array([5, 17, 900, 901, 3999, 17 + 1], dtype=np.int64)
+    eid, edge_index, nodes = s.sample(seeds)
+    want = _khop_reference(ei, seeds, 2)
+    assert np.array_equal(eid.numpy(), want)
+    glob = nodes.numpy()[edge_index.numpy()]                       # local -> global round trip
+    assert np.array_equal(glob[0], ei[0][want]) and np.array_equal(glob[1], ei[1][want])
+    assert np.array_equal(nodes.numpy(), np.unique(np.concatenate([ei[0][want], ei[1][want]])))
+
+
+def test_sampling_contract_and_thread_invariance():
+    ei, n = _graph(2000, 60000, seed=3)
+    seeds = np.random.RandomState(1).choice(60000, 200, replace=False).astype(np.int64)
+    outs = []
+    for threads in (1, 4):
+        s = NeighborSampler(ei, n, num_neighbors=(10, 5), num_threads=threads)
+        outs.append(s.sample(seeds, rng_seed=42))
+    eid, edge_index, nodes = outs[0]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))             # same result for any thread count
+    eid_np = eid.numpy()
+    assert np.array_equal(eid_np[:200], seeds)                                   # seed edges first, in order
+    assert len(np.unique(eid_np)) == len(eid_np)                                 # no edge twice (seed edges dropped)
+    sampled = eid_np[200:]
+    # every sampled edge enters a node that was expanded, at most max(fanout) in-edges kept per destination
+    per_dst = np.bincount(ei[1][sampled], minlength=n)
+    assert per_dst.max() <= 10
+    glob = nodes.numpy()[edge_index.numpy()]
+    assert np.array_equal(glob[0], ei[0][eid_np]) and np.array_equal(glob[1], ei[1][eid_np])
+    assert np.all(np.diff(nodes.numpy()) > 0)
+    other = NeighborSampler(ei, n, num_neighbors=(10, 5)).sample(seeds, rng_seed=43)
+    assert not torch.equal(other[0], eid)                                        # the seed matters
+
+
+def test_sampler_rejects_bad_input():
+    ei, n = _graph()
+    with pytest.raises(ValueError):
+        NeighborSampler(np.array([[0, 1], [1, n]]), n)
+    s = NeighborSampler(ei, n)
+    with pytest.raises(ValueError):
+        s.sample(np.array([ei.shape[1]]))
+
+
+def test_column_store_assembles_the_batch_contract():
+    """(node_tf, edge_index, edge_tf, y) with seed rows first — what main.py:48 receives."""
+    ei, n = _graph(500, 8000, seed=5)
+    num, cat, ts = S.edge_table(8000, seed=1)
+    labels = torch.from_numpy((np.arange(8000) % 7 == 0).astype(np.int64))
+    store = ColumnStore({stype.numerical: torch.from_numpy(num), stype.categorical: torch.from_numpy(cat),
+                         stype.timestamp: torch.from_numpy(ts)}, S.EDGE_COLS,
+                        {stype.relation: torch.ones(n, 1)}, S.NODE_COLS, labels)
+    sampler = NeighborSampler(ei, n, num_neighbors=(20, 10))
+    seeds = np.arange(100, 164, dtype=np.int64)
+    node_tf, edge_index, edge_tf, y = store.graph_inputs(sampler, seeds, rng_seed=9)
+    assert torch.equal(y, labels[100:164]) and edge_index.shape[0] == 2
+    assert edge_tf.num_rows == edge_index.shape[1] and node_tf.num_rows == int(edge_index.max()) + 1
+    assert torch.equal(edge_tf.feat_dict[stype.categorical][:64], torch.from_numpy(cat[100:164]))
