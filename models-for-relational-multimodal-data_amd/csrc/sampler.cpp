@@ -31,6 +31,7 @@ struct Graph {
   std::vector<int64_t> in_src;   // source node of each in-edge (CSC order)
   std::vector<int64_t> in_eid;   // original edge id of each in-edge
   // per-handle scratch (one sample() call at a time per handle): visited stamps and local ids, O(1) per touch
+  std::vector<uint32_t> emark;   // [num_edges]  emark[e] == stamp <=> e is a seed edge of the current call
   std::vector<uint32_t> mark;    // [num_nodes]  mark[v] == stamp  <=>  v is in the current subgraph
   std::vector<int64_t> local;    // [num_nodes]  local id of v (valid where marked)
   uint32_t stamp = 0;
@@ -135,18 +136,18 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
   std::vector<int64_t> e_src, e_dst, e_id;
   if (++g.stamp == 0) {            // stamp wrapped: clear the marks once every 2^32 calls
     std::fill(g.mark.begin(), g.mark.end(), 0u);
+    std::fill(g.emark.begin(), g.emark.end(), 0u);
     g.stamp = 1;
   }
   const uint32_t stamp = g.stamp;
-  std::unordered_set<int64_t> seed_ids;
-  seed_ids.reserve((size_t)B * 2);
+  if (g.emark.size() != (size_t)g.num_edges) g.emark.assign((size_t)g.num_edges, 0u);
   for (int64_t i = 0; i < B; ++i) {
     if (seed_src[i] < 0 || seed_src[i] >= g.num_nodes || seed_dst[i] < 0 || seed_dst[i] >= g.num_nodes) {
       snprintf(g_err, sizeof(g_err), "tg_sampler_sample: seed edge %lld has a node id out of range", (long long)i);
       return 1;
     }
     e_src.push_back(seed_src[i]); e_dst.push_back(seed_dst[i]); e_id.push_back(seed_eid[i]);
-    seed_ids.insert(seed_eid[i]);
+    if (seed_eid[i] >= 0 && seed_eid[i] < g.num_edges) g.emark[(size_t)seed_eid[i]] = stamp;
   }
   // frontier 0 = sorted unique seed endpoints (torch.cat([src, dst]).unique())
   std::vector<int64_t> frontier(e_src.begin(), e_src.end());
@@ -193,7 +194,7 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
     // serial merge: drop seed edges, grow the next frontier in first-appearance order
     std::vector<int64_t> next;
     for (int64_t j = 0; j < tot; ++j) {
-      if (!seed_ids.count(h_id[(size_t)j])) {
+      if (g.emark[(size_t)h_id[(size_t)j]] != stamp) {
         if ((int64_t)e_id.size() >= cap) {
           snprintf(g_err, sizeof(g_err), "tg_sampler_sample: output capacity %lld exceeded", (long long)cap);
           return 2;
@@ -213,8 +214,14 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
   // relabel: every endpoint is a touched node (seed endpoints, expanded destinations, sampled sources);
   // sorted unique endpoints (torch.unique) = sorted touched list, local id = rank, looked up through g.local
   const int64_t ne = (int64_t)e_id.size();
-  std::sort(touched.begin(), touched.end());
   const int64_t nn = (int64_t)touched.size();
+  if (nn * 16 > g.num_nodes) {     // dense subgraph: one pass over the mark array beats sorting
+    int64_t w = 0;
+    for (int64_t v = 0; v < g.num_nodes; ++v)
+      if (g.mark[(size_t)v] == stamp) touched[(size_t)w++] = v;
+  } else {
+    std::sort(touched.begin(), touched.end());
+  }
   for (int64_t i = 0; i < nn; ++i) g.local[(size_t)touched[(size_t)i]] = i;
 #pragma omp parallel for num_threads(nthreads) schedule(static) if (ne >= 65536)
   for (int64_t j = 0; j < ne; ++j) {

@@ -1,6 +1,8 @@
 """CPU: native neighbour sampler + relabel (libtabgnn_sampler.so) — exact k-hop neighbourhood when the fan-out covers
 every in-edge, contract properties under real sampling (seed edges first and in order, no seed edge repeated, fan-out
 respected per expanded node, relabel = rank among sorted unique endpoints), determinism across thread counts."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -96,3 +98,15 @@ def test_column_store_assembles_the_batch_contract():
     assert torch.equal(y, labels[100:164]) and edge_index.shape[0] == 2
     assert edge_tf.num_rows == edge_index.shape[1] and node_tf.num_rows == int(edge_index.max()) + 1
     assert torch.equal(edge_tf.feat_dict[stype.categorical][:64], torch.from_numpy(cat[100:164]))
+
+
+def test_sampler_library_exports_every_declared_symbol():
+    import ctypes, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "tabgnn_sampler.h")).read()
+    names = sorted(set(re.findall(r"\b(tg_sampler_\w+)\s*\(", text)))
+    assert len(names) >= 6
+    from tabgnn_amd import sampler as S
+    lib = ctypes.CDLL(S._LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tabgnn_sampler.h but not exported"
