@@ -127,3 +127,30 @@ class ColumnStore:
         node_tf = TensorFrame({k: v.index_select(0, nodes_d) for k, v in self.node_feats.items()}, self.node_cols)
         y = self.labels.index_select(0, eid_d[:len(seed_eids)])
         return node_tf, edge_index.to(dev), edge_tf, y
+
+
+class ShardedSeedLoader:
+    """Seed-edge mini-batches for rank r of `world`: one shuffle of the train edge ids per epoch (same permutation on
+    every rank: seeded by `seed + epoch`), rank r takes every world-th id, full batches only — the reference's
+    ``DataLoader(train_ids, batch_size, shuffle=True)`` (``src/datasets/util/graph.py:38-53``) made rank-disjoint,
+    and without the short last batch ``TABGNNFusedS.forward`` would mis-slice (``utils.py:355-356``)."""
+
+    def __init__(self, seed_ids, batch_size, rank=0, world=1, seed=0):
+        self.ids = np.ascontiguousarray(np.asarray(seed_ids, dtype=np.int64))
+        self.batch_size, self.rank, self.world, self.seed = int(batch_size), int(rank), int(world), int(seed)
+        if not 0 <= self.rank < self.world:
+            raise ValueError("rank must be in [0, world)")
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return (len(self.ids) // self.world) // self.batch_size
+
+    def __iter__(self):
+        perm = np.random.default_rng(self.seed + self.epoch).permutation(len(self.ids))
+        per_rank = len(self.ids) // self.world                      # equal share on every rank (tail ids dropped)
+        mine = self.ids[perm[self.rank:per_rank * self.world:self.world]]
+        for i in range(len(self)):
+            yield mine[i * self.batch_size:(i + 1) * self.batch_size]

@@ -87,6 +87,8 @@ class DataParallel:
         # TABGNN_FORCE_ALLREDUCE=1 runs the collective path even with one rank (smoke test of the RCCL plumbing)
         import os
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("TABGNN_FORCE_ALLREDUCE") == "1")
+        if dist.is_initialized():       # per-rank dropout stream (seed + rank): ranks never share a mask
+            ops.DropoutRNG.seed = (ops.DropoutRNG.seed + 0x9E3779B97F4A7C15 * dist.get_rank()) & ((1 << 64) - 1)
         if self.active:
             dist.broadcast(flat.flat, src=0)
             if sync_buffers:

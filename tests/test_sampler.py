@@ -110,3 +110,16 @@ def test_sampler_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(S._LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/tabgnn_sampler.h but not exported"
+
+
+def test_sharded_seed_loader_is_rank_disjoint_and_full_batches():
+    from tabgnn_amd.sampler import ShardedSeedLoader
+    ids = np.arange(1000, 2003)
+    per_rank = [np.concatenate(list(ShardedSeedLoader(ids, 50, rank=r, world=4, seed=7))) for r in range(4)]
+    assert all(len(p) == 250 for p in per_rank)                                  # 5 full batches of 50 each
+    allv = np.concatenate(per_rank)
+    assert len(np.unique(allv)) == 1000 and np.isin(allv, ids).all()             # disjoint across ranks
+    again = np.concatenate(list(ShardedSeedLoader(ids, 50, rank=1, world=4, seed=7)))
+    assert np.array_equal(again, per_rank[1])                                    # deterministic per (seed, epoch)
+    ld = ShardedSeedLoader(ids, 50, rank=1, world=4, seed=7); ld.set_epoch(1)
+    assert not np.array_equal(np.concatenate(list(ld)), per_rank[1])             # reshuffled each epoch
