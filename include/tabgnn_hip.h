@@ -147,7 +147,9 @@ int tg_seed_pool_bwd(const void* g, const int32_t* tei, const int32_t* rowptr, v
  *      out[M,N] (fp32) = G[R,M]^T X[R,N], bf16 operands, split over row slabs, deterministic slab sum ------- */
 int64_t tg_gemm_tn_workspace_floats(int64_t R, int32_t M, int32_t N);
 int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* colsum /*[M] bias grad, optional*/,
-                    float* workspace, int64_t R, int32_t M, int32_t N, int64_t ldg, int64_t ldx, void* stream);
+                    float* workspace, int64_t R, int32_t M, int32_t N, int64_t ldg, int64_t ldx,
+                    int32_t accumulate /*1: out += , colsum += (gradient accumulation, .grad semantics)*/,
+                    void* stream);
 
 /* ---- train-step tail (main.py:70-75,335-336) ------------------------------------------------------------ */
 int tg_weighted_ce_fwd(const void* logits, const int64_t* y, const float* w, int64_t B, int32_t K,

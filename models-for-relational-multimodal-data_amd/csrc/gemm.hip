@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
 // out[i] = sum_s partial[s][i]: 256 threads = 16 float4 columns x 16 slab strips, four loads in flight per
 // thread, strips combined through LDS in strip order (deterministic)
 __global__ void __launch_bounds__(256) k_sum_slabs(const float* __restrict__ partial, int nslab, long long mn,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, int accumulate) {
   __shared__ float4 red[16][16];
   const int col = threadIdx.x & 15, strip = threadIdx.x >> 4;
   const long long i = ((long long)blockIdx.x * 16 + col) * 4;
@@ -200,10 +200,15 @@ __global__ void __launch_bounds__(256) k_sum_slabs(const float* __restrict__ par
   if (strip == 0 && i < mn) {
     float4 r = red[0][col];
     for (int k = 1; k < 16; ++k) { float4 v = red[k][col]; r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w; }
-    if (i + 4 <= mn) *reinterpret_cast<float4*>(out + i) = r;
-    else {
+    if (i + 4 <= mn) {
+      if (accumulate) {   // gradient accumulation straight into the caller's (flat) gradient buffer
+        float4 o = *reinterpret_cast<const float4*>(out + i);
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+      }
+      *reinterpret_cast<float4*>(out + i) = r;
+    } else {
       float e[4] = {r.x, r.y, r.z, r.w};
-      for (int k = 0; k < 4; ++k) if (i + k < mn) out[i + k] = e[k];
+      for (int k = 0; k < 4; ++k) if (i + k < mn) out[i + k] = accumulate ? out[i + k] + e[k] : e[k];
     }
   }
 }
@@ -232,12 +237,13 @@ extern "C" int64_t tg_gemm_tn_workspace_floats(int64_t R, int32_t M, int32_t N) 
 // out[M,N] (fp32) = G[R,M]^T X[R,N];  G, X bf16 with row strides ldg, ldx (elements, multiples of 8)
 // colsum (optional, fp32 [M]) = column sums of G = the bias gradient of the same Linear
 extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* colsum, float* workspace, int64_t R,
-                               int32_t M, int32_t N, int64_t ldg, int64_t ldx, void* stream) {
+                               int32_t M, int32_t N, int64_t ldg, int64_t ldx, int32_t accumulate, void* stream) {
   TG_CHECK(R > 0 && M > 0 && N > 0, "tg_gemm_tn_bf16: empty problem");
   TG_CHECK(M % 8 == 0 && N % 8 == 0 && ldg % 8 == 0 && ldx % 8 == 0,
            "tg_gemm_tn_bf16: M, N and row strides must be multiples of 8 (M=%d N=%d)", M, N);
-  TG_CHECK((reinterpret_cast<uintptr_t>(G) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0,
-           "tg_gemm_tn_bf16: operands must be 16-byte aligned");
+  TG_CHECK((reinterpret_cast<uintptr_t>(G) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+           "tg_gemm_tn_bf16: operands and output must be 16-byte aligned");
   int tm, tn, nslab;
   long long rps;
   tn_geometry(R, M, N, tm, tn, nslab, rps);
@@ -246,10 +252,10 @@ extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* 
                      (const unsigned short*)X, workspace, colsum ? workspace + (long long)nslab * M * N : nullptr,
                      (long long)R, M, N, (long long)ldg, (long long)ldx, rps);
   long long mn = (long long)M * N;
-  hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(mn, 4), 16)), dim3(256), 0, st, workspace, nslab, mn, out);
+  hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(mn, 4), 16)), dim3(256), 0, st, workspace, nslab, mn, out, accumulate);
   if (colsum) {
     float* cs = workspace + (long long)nslab * mn;
-    hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(M, 4), 16)), dim3(256), 0, st, cs, nslab, (long long)M, colsum);
+    hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(M, 4), 16)), dim3(256), 0, st, cs, nslab, (long long)M, colsum, accumulate);
   }
   TG_LAUNCH_CHECK();
   return 0;

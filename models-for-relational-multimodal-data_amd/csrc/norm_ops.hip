@@ -222,29 +222,36 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
 }
 
 // out[i] = sum_blk partials[blk][i]   (i < width)
-// 256 threads = 64 columns x 4 strips of blocks; four loads in flight per thread; strips meet in LDS in strip order
-__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partials, int nblk, int width,
-                                                          float* __restrict__ out) {
-  __shared__ float red[4][64];
+// The launch is a handful of blocks (width/64), so it is pure latency: 1024 threads = 64 columns x 16 strips of
+// blocks, eight independent loads in flight per thread; strips meet in LDS in strip order (deterministic).
+constexpr int RP_STRIPS = 16;
+__global__ void __launch_bounds__(1024) k_reduce_partials(const float* __restrict__ partials, int nblk, int width,
+                                                           float* __restrict__ out) {
+  __shared__ float red[RP_STRIPS][64];
   const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   float t = 0.f;
   if (col < width) {
-    int per = (nblk + 3) / 4, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    const int per = (nblk + RP_STRIPS - 1) / RP_STRIPS, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
     int b = b0;
-    for (; b + 3 < b1; b += 4) {
-      t0 += partials[(long long)b * width + col];
-      t1 += partials[(long long)(b + 1) * width + col];
-      t2 += partials[(long long)(b + 2) * width + col];
-      t3 += partials[(long long)(b + 3) * width + col];
+    for (; b + 7 < b1; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += partials[(long long)(b + u) * width + col];
     }
-    for (; b < b1; ++b) t0 += partials[(long long)b * width + col];
-    t = (t0 + t1) + (t2 + t3);
+    for (; b < b1; ++b) acc[0] += partials[(long long)b * width + col];
+    t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   }
   red[strip][lane] = t;
   __syncthreads();
-  if (strip == 0 && col < width) out[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (strip == 0 && col < width) {
+    float r = 0.f;
+#pragma unroll
+    for (int u = 0; u < RP_STRIPS; ++u) r += red[u][lane];
+    out[col] = r;
+  }
 }
 
 // ------------------------------------------------------------------ BatchNorm (+ReLU, + residual average)
@@ -618,7 +625,7 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
               (const T*)dout, (T*)da, (T*)db, (T*)dres, partials, (long long)M, C, lpr, alpha, beta_c, thresh, inv_keep,
               (unsigned long long)seed, rstream, (int)accum_da);
   })
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 64)), dim3(256), 0, st, partials, grid, 3 * C, dparams);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 64)), dim3(1024), 0, st, partials, grid, 3 * C, dparams);
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -642,7 +649,7 @@ extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* ga
       hipLaunchKernelGGL((k_col_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)nullptr,
                          (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, partials, (long long)N, F, 0);
       float* sums = partials + (size_t)512 * 2 * F;
-      hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(256), 0, st, partials, grid, 2 * F, sums);
+      hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, sums);
       hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, st, sums, 1, (long long)N, F, eps,
                          momentum, mean, rstd, running_mean, running_var);
     } else {
@@ -671,7 +678,7 @@ extern "C" int tg_bn_act_res_bwd(const void* x, const void* dout, const float* g
     size_t shm = (size_t)groups * 2 * F * sizeof(float);
     hipLaunchKernelGGL((k_bn_bwd_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)dout, mean,
                        rstd, gamma, beta, partials, (long long)N, F, relu, beta_c);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(256), 0, st, partials, grid, 2 * F, dparams);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, dparams);
     long long total = (long long)N * (F / VEC);
     hipLaunchKernelGGL((k_bn_bwd_apply<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, st, (const T*)x,
                        (const T*)dout, mean, rstd, gamma, beta, dparams, (T*)dx, (T*)dres, (long long)N, F, relu,

@@ -133,21 +133,39 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     if (gi < groups) {
       int sA = rpA[n], eA = rpA[n + 1];
-      for (int q = sA + gi; q < eA; q += groups) {
-        int row = pmA[q], off = offA;
-        if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
-        float t[VEC];
-        loadv<T, VEC>(g + (long long)row * gstride + off + c, t);
+      // eight rows in flight per lane group (clamped index + select: no load sits behind a branch); a 12.8k-row
+      // hub is 25 dependent rounds instead of 200
+      for (int q = sA + gi; q < eA; q += groups * 8) {
+        float t[8][VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+        for (int u = 0; u < 8; ++u) {
+          const int qq = q + u * groups;
+          int row = pmA[qq < eA ? qq : q], off = offA;
+          if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
+          loadv<T, VEC>(g + (long long)row * gstride + off + c, t[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = q + u * groups < eA;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] += ok ? t[u][j] : 0.f;
+        }
       }
       if (rpB) {
         int sB = rpB[n], eB = rpB[n + 1];
-        for (int q = sB + gi; q < eB; q += groups) {
-          float t[VEC];
-          loadv<T, VEC>(g + (long long)pmB[q] * gstride + offB + c, t);
+        for (int q = sB + gi; q < eB; q += groups * 8) {
+          float t[8][VEC];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+          for (int u = 0; u < 8; ++u) {
+            const int qq = q + u * groups;
+            loadv<T, VEC>(g + (long long)pmB[qq < eB ? qq : q] * gstride + offB + c, t[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool ok = q + u * groups < eB;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += ok ? t[u][j] : 0.f;
+          }
         }
       }
 #pragma unroll

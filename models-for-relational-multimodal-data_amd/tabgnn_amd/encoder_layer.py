@@ -72,6 +72,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2,
                               g1, g2, gt)
         ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
+        isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
+        ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2))   # weight gradients accumulate in place
         return out.view(R, S, C)
 
     @staticmethod
@@ -79,6 +81,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         (x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2, g1, g2,
          gt) = ctx.saved_tensors
         R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
+        p_in, pb_in, p_o, p_1, pb_1, p_2 = ctx.params
         T = R * S
         g = g.contiguous().view(T, C)
         dgt = dbt = None
@@ -94,15 +97,15 @@ class _EncoderLayerFn(torch.autograd.Function):
         d_x1 = torch.empty_like(x1)
         d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
         del d_x2
-        dw2, _ = ops.weight_grad(d_y2, h)
+        dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
         d_h = d_y2 @ lw2
         del d_y2
         d_hpre = torch.empty_like(d_h)
         L.call("tg_act_dropout_bwd", L.ptr(hpre), L.ptr(d_h), L.ptr(d_hpre), hpre.numel(), 1, p, seed, rs[2],
                L.dt(hpre), L.stream())
         del d_h
-        dw1, db1 = ops.weight_grad(d_hpre, x1, True)
-        if db1 is None:
+        dw1, db1 = ops.weight_grad(d_hpre, x1, True, p_1, pb_1)
+        if db1 is None and dw1 is not None:
             db1 = d_hpre.sum(0, dtype=torch.float32)
         d_x1.addmm_(d_hpre, lw1)                         # second consumer of x1: accumulated by the GEMM (beta = 1)
         del d_hpre
@@ -113,15 +116,15 @@ class _EncoderLayerFn(torch.autograd.Function):
         else:
             d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], True)
         del d_x1
-        dwo, _ = ops.weight_grad(d_y, o)
+        dwo, _ = ops.weight_grad(d_y, o, False, p_o)
         d_o = d_y @ lw_o
         del d_y
         d_qkv = torch.empty_like(qkv)
         L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
                L.dt(qkv), L.stream())
         del d_o
-        dwin, dbin = ops.weight_grad(d_qkv, x2d, True)
-        if dbin is None:
+        dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
+        if dbin is None and dwin is not None:
             dbin = d_qkv.sum(0, dtype=torch.float32)
         d_x.addmm_(d_qkv, lw_in)                         # third consumer of x
         return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],

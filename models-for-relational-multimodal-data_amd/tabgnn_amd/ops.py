@@ -160,6 +160,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
+        ctx.params = (weight, bias)
         return y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
@@ -168,27 +169,56 @@ class _Linear(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         dx = (g2 @ w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        dw, db = weight_grad(g2, x2, want_b) if ctx.needs_input_grad[1] else (None, None)
-        if want_b and db is None:
-            db = g2.sum(0, dtype=torch.float32)
+        wparam, bparam = ctx.params
+        if ctx.needs_input_grad[1]:
+            dw, db = weight_grad(g2, x2, want_b, wparam if isinstance(wparam, torch.nn.Parameter) else None,
+                                 bparam if isinstance(bparam, torch.nn.Parameter) else None)
+            if want_b and db is None and dw is not None:   # (None, None) = both accumulated in place
+                db = g2.sum(0, dtype=torch.float32)
+        else:
+            dw, db = None, (g2.sum(0, dtype=torch.float32) if want_b else None)
         return dx, dw, db, None, None
 
 
-def weight_grad(g2, x2, want_bias=False):
+def _grad_target(p):
+    """The parameter's existing fp32 gradient buffer (a FlatParams view) when a kernel may accumulate into it."""
+    if p is None:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() % 16 != 0:
+        return None
+    return g
+
+
+def weight_grad(g2, x2, want_bias=False, wparam=None, bparam=None):
     """(dW [M,N] fp32 = g2[R,M]^T x2[R,N], db [M] fp32 = column sums of g2 or None).  Tall-skinny bf16 problems go
     to the split-row MFMA kernel (tg_gemm_tn_bf16, bias gradient from the same LDS tiles); small or fp32 ones to
-    torch's GEMM."""
+    torch's GEMM.  When ``wparam`` (``bparam``) already owns a gradient buffer, the result is ACCUMULATED into it by
+    the kernel (``.grad +=`` semantics, no autograd AccumulateGrad add afterwards) and None is returned in its place."""
     R, M = g2.shape
     N = x2.shape[1]
+    wg = _grad_target(wparam)
+    bg = _grad_target(bparam) if want_bias else None
+    if wg is not None and wg.shape != (M, N):
+        wg = None
     if (g2.dtype == torch.bfloat16 and R >= 4096 and M % 8 == 0 and N % 8 == 0 and g2.stride(1) == 1
             and x2.stride(1) == 1 and g2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
             and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
-        out = torch.empty(M, N, dtype=torch.float32, device=g2.device)
-        db = torch.empty(M, dtype=torch.float32, device=g2.device) if want_bias else None
+        acc = wg is not None and (not want_bias or bg is not None)
+        out = wg if acc else torch.empty(M, N, dtype=torch.float32, device=g2.device)
+        db = (bg if acc else torch.empty(M, dtype=torch.float32, device=g2.device)) if want_bias else None
         ws = _workspace(L.load().tg_gemm_tn_workspace_floats(R, M, N), g2.device)
         L.call("tg_gemm_tn_bf16", g2.data_ptr(), x2.data_ptr(), L.ptr(out), L.ptr(db), L.ptr(ws), R, M, N,
-               g2.stride(0), x2.stride(0), L.stream())
-        return out, db
+               g2.stride(0), x2.stride(0), int(acc), L.stream())
+        return (None, None) if acc else (out, db)
+    if wg is not None and wg.dtype == g2.dtype:          # fp32 parity mode: one GEMM with beta = 1
+        wg.addmm_(g2.t(), x2)
+        if not want_bias:
+            return None, None
+        if bg is not None:
+            bg.add_(g2.sum(0))
+            return None, None
+        return None, g2.sum(0, dtype=torch.float32)
     return (g2.t() @ x2).float(), None
 
 

@@ -63,3 +63,24 @@ def test_edge_gather_backward_with_hub_nodes(dtype):
     want.index_add_(0, ei[0], go[:, F:2 * F].double())
     assert torch.equal(x.grad.double(), want.to(dtype).double())
     assert torch.equal(e.grad, go[:, 2 * F:])
+
+
+@pytest.mark.gpu
+def test_weight_grad_accumulates_into_existing_grad_buffer():
+    """.grad += semantics in the kernel: with a gradient buffer present the result is added to it (twice here) and
+    (None, None) comes back, so autograd's AccumulateGrad add never runs."""
+    import torch
+    from tabgnn_amd import ops
+    torch.manual_seed(3)
+    R, M, N = 9000, 128, 384
+    g = torch.randn(R, M, device="cuda").bfloat16()
+    x = torch.randn(R, N, device="cuda").bfloat16()
+    w = torch.nn.Parameter(torch.zeros(M, N, device="cuda"))
+    b = torch.nn.Parameter(torch.zeros(M, device="cuda"))
+    w.grad = torch.full((M, N), 0.5, device="cuda")
+    b.grad = torch.full((M,), -1.0, device="cuda")
+    for _ in range(2):
+        assert ops.weight_grad(g, x, True, w, b) == (None, None)
+    ref = g.float().t() @ x.float()
+    assert torch.allclose(w.grad, 0.5 + 2 * ref, rtol=1e-3, atol=1e-2)
+    assert torch.allclose(b.grad, -1.0 + 2 * g.float().sum(0), rtol=1e-3, atol=1e-2)
