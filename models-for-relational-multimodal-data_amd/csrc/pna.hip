@@ -278,6 +278,10 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
 // Blocks whose range does not fit the tile (hub destinations) read their rows straight from HBM.
 // Measured at N=524k, F=128 inside the bench step (us): NPB/tile KB 64/32: 144, 64/16: 138, 32/16: 133, 32/20: 131,
 // 16/8: 139, 8/8: 162; wave-private tiles (no block barrier) 8 per wave: 135; unstaged per-destination kernel: 158.
+// A persistent variant (2048 workgroups walking tiles, next tile's rows prefetched into registers under the current
+// tile's reduction) measured 180 us: on gfx9 stores and loads share vmcnt, so waiting for the prefetched rows also
+// drains the stores issued after them and every tile pays a store round trip; one tile per workgroup keeps all
+// loads ahead of all stores and lets the hardware overlap workgroups instead.
 constexpr int AGG_NPB = 32;
 template <typename T, int VEC, int NPB>
 __global__ void __launch_bounds__(256) k_pna_aggregate_fwd_staged(const T* __restrict__ h, const int* __restrict__ rowptr,
