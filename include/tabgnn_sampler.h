@@ -22,6 +22,15 @@ int tg_sampler_sample(void* handle, const int64_t* seed_src, const int64_t* seed
                       const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
                       int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, int64_t* n_edges,
                       int64_t* n_nodes);
+/* Negative edges for link-prediction pre-training: replaces generate_negative_samples
+ * (src/primitives/negative_sampling/negative_sampling.cpp:10-81; pybind11 binding :78-81; caller
+ * src/utils/batch_processing.py:145).  edge_index (src,dst)[E] and the B positive edges use the same compact local
+ * node ids; out_src/out_dst hold B * 2*floor(k/2) edges: per positive edge (s,d) floor(k/2) edges (s,c) then
+ * floor(k/2) edges (c,d) with c uniform over the nodes that are neither s, d nor a neighbour of either.
+ * k <= 0 -> error 1 with the reference's message ("num_neg_samples must be greater than 0", :13-15). */
+int tg_negative_sample(const int64_t* src, const int64_t* dst, int64_t E, const int64_t* pos_src,
+                       const int64_t* pos_dst, int64_t B, int32_t num_neg_samples, uint64_t seed, int32_t num_threads,
+                       int64_t* out_src, int64_t* out_dst);
 #ifdef __cplusplus
 }
 #endif

@@ -235,4 +235,91 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Negative edges for link-prediction pre-training: replaces generate_negative_samples
+// (src/primitives/negative_sampling/negative_sampling.cpp:10-81, called at src/utils/batch_processing.py:145).
+// Reference semantics kept: candidates are node ids 0..V-1 with V = number of distinct ids in edge_index (ids are
+// assumed compact, negative_sampling.cpp:34); for positive edge (s,d) a candidate is rejected when it is s, d or
+// an (undirected) neighbour of s or d (:40-44); floor(k/2) accepted candidates c give (s,c), then floor(k/2) give
+// (c,d) (:60-75); k <= 0 is an error (:13-15).  Differences: seedable (draws depend only on (seed, edge, slot), so
+// any thread count gives the same edges; the reference seeds from std::random_device), multi-threaded over
+// positive edges, and an edge whose exclusion set covers every node is reported instead of spinning forever.
+int tg_negative_sample(const int64_t* src, const int64_t* dst, int64_t E, const int64_t* pos_src,
+                       const int64_t* pos_dst, int64_t B, int32_t num_neg_samples, uint64_t seed, int32_t num_threads,
+                       int64_t* out_src, int64_t* out_dst) {
+  if (num_neg_samples <= 0) {
+    snprintf(g_err, sizeof(g_err), "num_neg_samples must be greater than 0");
+    return 1;
+  }
+  if (E <= 0 || B < 0) {
+    snprintf(g_err, sizeof(g_err), "tg_negative_sample: bad sizes E=%lld B=%lld", (long long)E, (long long)B);
+    return 1;
+  }
+  int64_t maxid = -1;
+  for (int64_t e = 0; e < E; ++e) {
+    if (src[e] < 0 || dst[e] < 0) {
+      snprintf(g_err, sizeof(g_err), "tg_negative_sample: negative node id at edge %lld", (long long)e);
+      return 1;
+    }
+    maxid = std::max(maxid, std::max(src[e], dst[e]));
+  }
+  for (int64_t i = 0; i < B; ++i)
+    if (pos_src[i] < 0 || pos_dst[i] < 0 || pos_src[i] > maxid || pos_dst[i] > maxid) {
+      snprintf(g_err, sizeof(g_err), "tg_negative_sample: positive edge %lld has a node outside edge_index", (long long)i);
+      return 1;
+    }
+  const int64_t span = maxid + 1;
+  // undirected adjacency (CSR over both directions; duplicates are harmless for a membership test)
+  std::vector<int64_t> ptr((size_t)span + 1, 0);
+  for (int64_t e = 0; e < E; ++e) { ptr[(size_t)src[e] + 1]++; ptr[(size_t)dst[e] + 1]++; }
+  int64_t V = 0;                                        // |nodeset| (negative_sampling.cpp:21-29,34)
+  for (int64_t v = 0; v < span; ++v) { V += ptr[(size_t)v + 1] > 0; ptr[(size_t)v + 1] += ptr[(size_t)v]; }
+  std::vector<int64_t> adj((size_t)2 * E), cur(ptr.begin(), ptr.end() - 1);
+  for (int64_t e = 0; e < E; ++e) {
+    adj[(size_t)cur[(size_t)src[e]]++] = dst[e];
+    adj[(size_t)cur[(size_t)dst[e]]++] = src[e];
+  }
+  const int64_t half = num_neg_samples / 2, per = 2 * half;
+  int failed = 0;
+#ifdef _OPENMP
+  const int nthreads = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  const int nthreads = 1;
+#endif
+#pragma omp parallel num_threads(nthreads) if (B * per >= 16384)
+  {
+    std::vector<uint32_t> mark((size_t)span, 0u);      // per-thread stamp array: mark[v] == stamp <=> v unavailable
+    uint32_t stamp = 0;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t i = 0; i < B; ++i) {
+      const int64_t s = pos_src[i], d = pos_dst[i];
+      ++stamp;
+      int64_t blocked = 0;
+      auto block = [&](int64_t v) { if (v < V && mark[(size_t)v] != stamp) { mark[(size_t)v] = stamp; ++blocked; } };
+      block(s); block(d);
+      for (int64_t q = ptr[(size_t)s]; q < ptr[(size_t)s + 1]; ++q) block(adj[(size_t)q]);
+      for (int64_t q = ptr[(size_t)d]; q < ptr[(size_t)d + 1]; ++q) block(adj[(size_t)q]);
+      if (blocked >= V) {                              // nothing left to draw (the reference would never return)
+#pragma omp atomic write
+        failed = 1;
+        for (int64_t j = 0; j < per; ++j) { out_src[i * per + j] = s; out_dst[i * per + j] = d; }
+        continue;
+      }
+      uint64_t rng = seed ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1));
+      for (int64_t j = 0; j < per; ++j) {
+        int64_t c;
+        do { c = (int64_t)bounded(rng, (uint64_t)V); } while (mark[(size_t)c] == stamp);
+        const bool corrupt_dst = j < half;             // first half keeps the source, second half the destination
+        out_src[i * per + j] = corrupt_dst ? s : c;
+        out_dst[i * per + j] = corrupt_dst ? c : d;
+      }
+    }
+  }
+  if (failed) {
+    snprintf(g_err, sizeof(g_err), "tg_negative_sample: a positive edge excludes every node (no negative exists)");
+    return 2;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -154,3 +154,33 @@ class ShardedSeedLoader:
         mine = self.ids[perm[self.rank:per_rank * self.world:self.world]]
         for i in range(len(self)):
             yield mine[i * self.batch_size:(i + 1) * self.batch_size]
+
+
+def generate_negative_samples(edge_index, pos_edge_index, num_neg_samples, seed=0, num_threads=0):
+    """Drop-in for the reference's pybind11 ``negative_sampling.generate_negative_samples(edge_index, pos_edge_index,
+    num_neg_samples)`` (``negative_sampling.cpp:10-12,78-81``; call site ``src/utils/batch_processing.py:145``):
+    same argument meaning (2 x E and 2 x B nested lists, arrays or tensors of local node ids), same
+    ``ValueError`` for ``num_neg_samples <= 0``, same output layout — returned as an int64 tensor ``[2, B*2*(k//2)]``
+    instead of nested lists — plus a ``seed`` (the reference is unseeded)."""
+    lib = _load()
+    if not hasattr(lib.tg_negative_sample, "_bound"):
+        i64p = C.POINTER(C.c_int64)
+        lib.tg_negative_sample.argtypes = [i64p, i64p, C.c_int64, i64p, i64p, C.c_int64, C.c_int32, C.c_uint64,
+                                           C.c_int32, i64p, i64p]
+        lib.tg_negative_sample.restype = C.c_int
+        lib.tg_negative_sample._bound = True
+    as_np = lambda a: np.ascontiguousarray(a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a), dtype=np.int64)
+    ei, pos = as_np(edge_index), as_np(pos_edge_index)
+    if ei.ndim != 2 or ei.shape[0] != 2 or pos.ndim != 2 or pos.shape[0] != 2:
+        raise ValueError("edge_index and pos_edge_index must be [2, E] and [2, B]")
+    k = int(num_neg_samples)
+    B, per = pos.shape[1], 2 * (max(k, 0) // 2)
+    out = np.empty((2, B * per), dtype=np.int64)
+    src, dst, ps, pd = (np.ascontiguousarray(a) for a in (ei[0], ei[1], pos[0], pos[1]))
+    rc = lib.tg_negative_sample(_p64(src), _p64(dst), ei.shape[1], _p64(ps), _p64(pd), B, k,
+                                int(seed) & (2 ** 64 - 1), int(num_threads), _p64(out[0]), _p64(out[1]))
+    if rc == 1:
+        raise ValueError(lib.tg_sampler_last_error().decode())
+    if rc != 0:
+        raise RuntimeError(lib.tg_sampler_last_error().decode())
+    return torch.from_numpy(out)
