@@ -11,7 +11,8 @@ _lib.load()
 from .encoders import (EmbeddingEncoder, LinearEncoder, ProjectionEncoder,  # noqa: E402
                        StypeWiseFeatureEncoder, TimestampEncoder)
 from .frame import TensorFrame, stype  # noqa: E402
-from .heads import ClassifierHead, NodeClassificationHead  # noqa: E402
+from .heads import ClassifierHead, LinkPredHead, MCMHead, NodeClassificationHead, SelfSupervisedHead  # noqa: E402
+from .losses import SSLoss  # noqa: E402
 from .layers import BatchNorm, ColumnTransformerLayer, PNAConv, PNAConvHetero  # noqa: E402
 from .models import (TABGNN, FTTransformerLayer, FTTransformerPNAFusedLayer, PNALayer,  # noqa: E402
                      TABGNNFused)

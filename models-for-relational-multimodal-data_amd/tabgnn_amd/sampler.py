@@ -128,6 +128,22 @@ class ColumnStore:
         y = self.labels.index_select(0, eid_d[:len(seed_eids)])
         return node_tf, edge_index.to(dev), edge_tf, y
 
+    def lp_inputs(self, sampler: NeighborSampler, seed_eids, num_neg_samples=64, rng_seed=0):
+        """``lp_inputs`` (``src/utils/batch_processing.py:104-147``) for link-prediction pre-training:
+        (node_tf, edge_index, edge_tf, neigh_edge_index, neigh_edge_tf, target_edge_index, target_edge_tf) where the
+        targets are the B positive (seed) edges followed by the sampled negatives, and every positive's raw row is
+        repeated ``num_neg_samples`` times (contiguously) behind the positives' rows for its negatives."""
+        node_tf, edge_index, edge_tf, _ = self.graph_inputs(sampler, seed_eids, rng_seed)
+        B = len(seed_eids)
+        pos = edge_index[:, :B]
+        neg = generate_negative_samples(edge_index, pos, num_neg_samples, seed=rng_seed).to(edge_index.device)
+        rep = torch.arange(B, device=edge_index.device).repeat_interleave(int(num_neg_samples))
+        rows = torch.cat([torch.arange(B, device=edge_index.device), rep])
+        target_tf = TensorFrame({k: v.index_select(0, rows) for k, v in edge_tf.feat_dict.items()}, self.edge_cols)
+        keep = torch.arange(B, edge_index.shape[1], device=edge_index.device)
+        neigh_tf = TensorFrame({k: v.index_select(0, keep) for k, v in edge_tf.feat_dict.items()}, self.edge_cols)
+        return (node_tf, edge_index, edge_tf, edge_index[:, B:], neigh_tf, torch.cat([pos, neg], dim=1), target_tf)
+
 
 class ShardedSeedLoader:
     """Seed-edge mini-batches for rank r of `world`: one shuffle of the train edge ids per epoch (same permutation on

@@ -6,11 +6,13 @@ import datasets/LLM code that cannot load here, so ``src``, ``src.nn``, ``src.nn
 ``src.nn.gnn`` are pre-registered as bare namespace modules, and the two absent third-party
 packages are represented by ``oracle.pyg_restate`` (``PNAConv``/``BatchNorm``/``Linear`` — parity
 unpinned) plus a type-annotation-only ``StypeWiseFeatureEncoder`` name.  The reference's
-``fused.py``, ``tabgnn.py``, ``pna.py`` and ``decoder.py`` then execute unmodified.
+``fused.py``, ``tabgnn.py``, ``pna.py``, ``decoder.py``, ``src/nn/decoder/self_supervised.py`` and
+``src/utils/loss.py`` then execute unmodified.
 """
 from __future__ import annotations
 
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -51,6 +53,12 @@ def load_reference():
     tabgnn = importlib.import_module("src.nn.models.tabgnn")
     pna = importlib.import_module("src.nn.gnn.pna")
     dec = importlib.import_module("src.nn.gnn.decoder")
-    return {"TABGNNFused": fused.TABGNNFused, "FTTransformerPNAFusedLayer": fused.FTTransformerPNAFusedLayer,
+    _ns("src.nn.decoder", f"{REF}/src/nn/decoder")
+    ssl = importlib.import_module("src.nn.decoder.self_supervised")
+    spec = importlib.util.spec_from_file_location("tabgnn_ref_loss", f"{REF}/src/utils/loss.py")   # pure torch file
+    loss = importlib.util.module_from_spec(spec); spec.loader.exec_module(loss)
+    extra = {"LinkPredHead": dec.LinkPredHead, "MCMHead": ssl.MCMHead, "SelfSupervisedHead": ssl.SelfSupervisedHead,
+             "SSLoss": loss.SSLoss}
+    return {**extra, "TABGNNFused": fused.TABGNNFused, "FTTransformerPNAFusedLayer": fused.FTTransformerPNAFusedLayer,
             "TABGNN": tabgnn.TABGNN, "PNAConvHetero": pna.PNAConvHetero,
             "ClassifierHead": dec.ClassifierHead, "NodeClassificationHead": dec.NodeClassificationHead}

@@ -123,3 +123,26 @@ def test_sharded_seed_loader_is_rank_disjoint_and_full_batches():
     assert np.array_equal(again, per_rank[1])                                    # deterministic per (seed, epoch)
     ld = ShardedSeedLoader(ids, 50, rank=1, world=4, seed=7); ld.set_epoch(1)
     assert not np.array_equal(np.concatenate(list(ld)), per_rank[1])             # reshuffled each epoch
+
+
+def test_lp_inputs_assembles_positive_and_negative_targets():
+    """lp_inputs (batch_processing.py:104-147): targets = B positives then the negatives; attribute rows of the
+    negatives are their positive's row repeated num_neg_samples times."""
+    ei, n = _graph(500, 8000, seed=6)
+    num, cat, ts = S.edge_table(8000, seed=2)
+    store = ColumnStore({stype.numerical: torch.from_numpy(num), stype.categorical: torch.from_numpy(cat),
+                         stype.timestamp: torch.from_numpy(ts)}, S.EDGE_COLS,
+                        {stype.relation: torch.ones(n, 1)}, S.NODE_COLS, torch.zeros(8000, dtype=torch.long))
+    sampler = NeighborSampler(ei, n, num_neighbors=(5, 5))
+    seeds = np.arange(40, 56, dtype=np.int64)
+    node_tf, edge_index, edge_tf, nei, ntf, tei, ttf = store.lp_inputs(sampler, seeds, num_neg_samples=6, rng_seed=3)
+    B, k = 16, 6
+    assert tei.shape == (2, B + B * k) and torch.equal(tei[:, :B], edge_index[:, :B])
+    assert nei.shape[1] == edge_index.shape[1] - B and ntf.num_rows == nei.shape[1]
+    assert ttf.num_rows == B + B * k
+    c = ttf.feat_dict[stype.categorical]
+    assert torch.equal(c[:B], torch.from_numpy(cat[40:56]))
+    assert torch.equal(c[B:], torch.from_numpy(cat[40:56]).repeat_interleave(k, 0))
+    negs = tei[:, B:].reshape(2, B, 2, k // 2)
+    assert torch.equal(negs[0, :, 0, :], tei[0, :B, None].expand(B, k // 2))      # first half keeps the source
+    assert torch.equal(negs[1, :, 1, :], tei[1, :B, None].expand(B, k // 2))      # second half the destination
