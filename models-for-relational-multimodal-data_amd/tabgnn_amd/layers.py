@@ -121,12 +121,16 @@ class PNAConv(nn.Module):
     def __init__(self, in_channels, out_channels, aggregators, scalers, deg, edge_dim=None, towers=1, pre_layers=1,
                  post_layers=1, divide_input=False, **kw):
         super().__init__()
-        if (list(aggregators) != ["mean", "max", "min", "std"]
+        if (sorted(aggregators) != ["max", "mean", "min", "std"]
                 or list(scalers) != ["identity", "amplification", "attenuation"] or towers != 1 or pre_layers != 1
                 or post_layers != 1 or divide_input or edge_dim is None or in_channels != out_channels):
-            raise ValueError("PNAConv: only the reference's configuration (fused.py:200-207) is implemented")
+            raise ValueError("PNAConv: only the reference's configurations (fused.py:200-207, pna.py:59-72: the four "
+                             "aggregators in either order, three scalers, one tower) are implemented")
         F = in_channels
         self.F = F
+        # the aggregation kernel writes [mean|max|min|std]; agg_order[k] = position of that aggregator in the
+        # module's own list (pna.py uses ['mean','min','max','std']), i.e. which column block of post_nn it owns
+        self.agg_order = [list(aggregators).index(a) for a in ("mean", "max", "min", "std")]
         self.aggr_module = _DegreeScalerBuffers(deg)
         self.edge_encoder = nn.Linear(edge_dim, F)
         self.pre_nns = nn.ModuleList([nn.Sequential(nn.Linear(3 * F, F))])
@@ -152,7 +156,11 @@ class PNAConv(nn.Module):
         w_eff = self.lin.weight @ post.weight                            # [F,13F]
         b_eff = self.lin.weight @ post.bias + self.lin.bias
         xw = ops.linear(x, w_eff[:, :F], b_eff)
-        w_st = torch.cat([w_eff[:, F:5 * F], w_eff[:, 5 * F:9 * F], w_eff[:, 9 * F:]], dim=0)   # [3F,4F]
+        if self.agg_order == [0, 1, 2, 3]:
+            w_st = torch.cat([w_eff[:, F:5 * F], w_eff[:, 5 * F:9 * F], w_eff[:, 9 * F:]], dim=0)   # [3F,4F]
+        else:                                                           # column blocks re-ordered to the kernel's layout
+            blk = lambda sc, j: w_eff[:, F + (sc * 4 + j) * F:F + (sc * 4 + j + 1) * F]
+            w_st = torch.cat([torch.cat([blk(sc, j) for j in self.agg_order], dim=1) for sc in range(3)], dim=0)
         G = ops.linear(agg, w_st, None)
         return ops.pna_scale_combine(xw, G, g, self.aggr_module.avg_deg_log)
 

@@ -257,3 +257,129 @@ class TABGNN(nn.Module):
         for layer in self.gnn_backbone:
             x, e = layer(x, g, e)
         return x, e
+
+
+# --------------------------------------------------------------------------------------- sibling backbones (8f rank 4)
+
+
+class FTTransformerPNAInterleavedLayer(nn.Module):
+    """``src/nn/models/inteleaved.py:165-227``: column attention over EVERY edge row, then a PNA layer on the CLS token
+    of each edge row (the edge embedding), which is written back into the row."""
+
+    def __init__(self, channels, nhead, feedforward_channels=None, dropout=0.5, activation="relu", nhidden=128, deg=None,
+                 reverse_mp=False):
+        super().__init__()
+        self.channels, self.nhidden = channels, nhidden
+        self.tab_conv = ColumnTransformerLayer(channels, nhead, feedforward_channels, dropout, activation)
+        self.tab_norm = nn.LayerNorm(channels)
+        self.gnn_conv = _make_conv(nhidden, deg, reverse_mp)
+        self.gnn_norm = BatchNorm(nhidden)
+        self.gnn_edge_update = nn.Sequential(nn.Linear(3 * nhidden, nhidden), nn.ReLU(), nn.Linear(nhidden, nhidden))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _xavier_matrices(self.tab_conv)
+        self.tab_norm.reset_parameters()
+        self.gnn_conv.reset_parameters()
+        self.gnn_norm.reset_parameters()
+        _xavier_matrices(self.gnn_edge_update)
+
+    def forward(self, x_gnn, edge_index, edge_attr):
+        g = ops.SubgraphIndex.build(edge_index, x_gnn.shape[0])
+        edge_attr = self.tab_conv(edge_attr, self.tab_norm, 1.0, 0.5)          # e + LN(enc(e)) / 2   (sic, :217)
+        cls = edge_attr[:, 0, :].contiguous()
+        x_gnn = self.gnn_norm(self.gnn_conv(x_gnn, g, cls), res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
+        up0, up2 = self.gnn_edge_update[0], self.gnn_edge_update[2]
+        m = ops.act_dropout(ops.linear(ops.edge_gather(x_gnn, cls, g, "src"), up0.weight, up0.bias), "relu", 0.0)
+        cls = ops.axpby(cls, ops.linear(m, up2.weight, up2.bias), 0.5, 0.5)
+        return x_gnn, torch.cat([cls.unsqueeze(1), edge_attr[:, 1:, :]], dim=1)
+
+
+class TABGNNInterleaved(nn.Module):
+    """``TABGNNInterleaved`` (``src/nn/models/inteleaved.py:27-163``), ``--model tabgnninterleaved``
+    (``utils.py:306-320``): same parameter names as the reference (``cls_embedding, node_emb, edge_emb, tab_conv,
+    tab_norm, backbone.{i}.*``; ``edge_emb`` is constructed but unused there too)."""
+
+    def __init__(self, channels: int, num_layers: int, encoder=None, deg=None, node_dim: int = 1, nhidden: int = 128,
+                 edge_dim: int = None, reverse_mp: bool = False, feedforward_channels: Optional[int] = None,
+                 nhead: int = 8, dropout: float = 0.5, activation: str = "relu") -> None:
+        super().__init__()
+        if num_layers <= 0:
+            raise ValueError(f"num_layers must be a positive integer (got {num_layers})")
+        self.channels, self.nhidden, self.node_dim = channels, nhidden, node_dim
+        self.edge_dim = edge_dim + channels
+        self.encoder, self.reverse_mp = encoder, reverse_mp
+        self.cls_embedding = nn.Parameter(torch.empty(channels))
+        self.node_emb = nn.Linear(node_dim, nhidden)
+        self.edge_emb = nn.Linear(self.edge_dim, nhidden)
+        self.tab_conv = ColumnTransformerLayer(channels, nhead, feedforward_channels, dropout, activation)
+        self.tab_norm = nn.LayerNorm(channels)
+        self.backbone = nn.ModuleList([
+            FTTransformerPNAInterleavedLayer(channels, nhead, feedforward_channels, dropout, activation, nhidden, deg,
+                                             reverse_mp) for _ in range(num_layers)])
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.normal_(self.cls_embedding, std=0.01)
+        self.node_emb.reset_parameters()
+        self.edge_emb.reset_parameters()
+        self.tab_norm.reset_parameters()
+        _xavier_matrices(self.tab_conv)
+        for layer in self.backbone:
+            layer.reset_parameters()
+
+    def get_shared_params(self):
+        groups = [self.encoder.parameters() if self.encoder is not None else [], self.tab_conv.parameters(),
+                  self.tab_norm.parameters(), [self.cls_embedding], self.node_emb.parameters(),
+                  self.edge_emb.parameters(), self.backbone.parameters()]
+        return [p for grp in groups for p in grp]
+
+    def zero_grad_shared_params(self):
+        for p in self.get_shared_params():
+            if p.grad is not None:
+                p.grad.data.zero_()
+
+    def forward(self, x, edge_index, edge_attr):
+        """x [N, n_node_feats, C]; edge_attr [E, ncols, C] -> (x_gnn [N,F], x_edge [E,C])   (inteleaved.py:140-163)."""
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        x_gnn = ops.linear(x.reshape(-1, self.node_dim), self.node_emb.weight, self.node_emb.bias)
+        e0 = self.tab_conv(prepend_cls(self.cls_embedding, edge_attr), self.tab_norm, 0.5, 0.5)
+        e = e0
+        for layer in self.backbone:
+            x_gnn, e = layer(x_gnn, g, e)
+        x_edge = ops.axpby(e[:, 0, :].contiguous(), e0[:, 0, :].contiguous(), 0.5, 0.5)
+        return x_gnn, x_edge
+
+
+class PNAS(nn.Module):
+    """``PNAS`` (``src/nn/gnn/pna.py:48-97``), ``--model pna``: node/edge embeddings then L x {PNA + BatchNorm + residual
+    average; edge update ``e + MLP/2``}.  Parameter names ``node_emb, edge_emb, convs.{i}, emlps.{i}, batch_norms.{i}``;
+    note the aggregator order ['mean','min','max','std'] (:59), honoured through the post-projection columns."""
+
+    def __init__(self, num_features, num_gnn_layers, n_classes=2, n_hidden=128, edge_updates=True, edge_dim=None,
+                 dropout=0.0, final_dropout=0.5, deg=None, reverse_mp=False):
+        super().__init__()
+        self.n_hidden, self.num_gnn_layers, self.edge_updates = n_hidden, num_gnn_layers, edge_updates
+        self.final_dropout, self.reverse_mp = final_dropout, reverse_mp
+        kw = dict(in_channels=n_hidden, out_channels=n_hidden, aggregators=["mean", "min", "max", "std"], scalers=_SCAL,
+                  deg=deg, edge_dim=n_hidden, towers=1, pre_layers=1, post_layers=1, divide_input=False)
+        self.node_emb = nn.Linear(num_features, n_hidden)
+        self.edge_emb = nn.Linear(edge_dim, n_hidden)
+        self.convs, self.emlps, self.batch_norms = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for _ in range(num_gnn_layers):
+            self.convs.append(PNAConvHetero(n_hidden=n_hidden, **kw) if reverse_mp else PNAConv(**kw))
+            if edge_updates:
+                self.emlps.append(nn.Sequential(nn.Linear(3 * n_hidden, n_hidden), nn.ReLU(), nn.Linear(n_hidden, n_hidden)))
+            self.batch_norms.append(BatchNorm(n_hidden))
+
+    def forward(self, x, edge_index, edge_attr):
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        x = ops.linear(x.reshape(x.shape[0], -1), self.node_emb.weight, self.node_emb.bias)
+        e = ops.linear(edge_attr.reshape(edge_attr.shape[0], -1), self.edge_emb.weight, self.edge_emb.bias)
+        for i in range(self.num_gnn_layers):
+            x = self.batch_norms[i](self.convs[i](x, g, e), res=x, relu=True, alpha=0.5, beta_c=0.5)
+            if self.edge_updates:
+                up0, up2 = self.emlps[i][0], self.emlps[i][2]
+                m = ops.act_dropout(ops.linear(ops.edge_gather(x, e, g, "src"), up0.weight, up0.bias), "relu", 0.0)
+                e = ops.axpby(e, ops.linear(m, up2.weight, up2.bias), 1.0, 0.5)
+        return x, e

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .heads import ClassifierHead, NodeClassificationHead
-from .models import TABGNN, TABGNNFused
+from .models import PNAS, TABGNN, TABGNNFused, TABGNNInterleaved
 
 
 def degree_histogram(in_degrees):
@@ -79,10 +79,49 @@ class TABGNNS(nn.Module):
         e_dim = config["num_edge_features"] * config["n_hidden"]
         if config.get("in_degrees") is None:
             raise ValueError("In degrees are not provided for PNA model!")
-        self.model = TABGNN(node_dim=n_dim, nhidden=config["n_hidden"], channels=config["n_hidden"],
-                            num_layers=config["n_gnn_layers"], edge_dim=e_dim,
-                            deg=degree_histogram(config["in_degrees"]), reverse_mp=config.get("reverse_mp", False),
-                            nhead=config.get("nhead", 8), dropout=config.get("backbone_dropout", 0.5))
+        name = config.get("model", "tabgnn")
+        if name not in ("tabgnn", "tabgnninterleaved"):
+            raise ValueError("Invalid model name!")                                            # utils.py:321-322
+        cls = TABGNN if name == "tabgnn" else TABGNNInterleaved                              # utils.py:292-320
+        self.model = cls(node_dim=n_dim, nhidden=config["n_hidden"], channels=config["n_hidden"],
+                         num_layers=config["n_gnn_layers"], edge_dim=e_dim,
+                         deg=degree_histogram(config["in_degrees"]), reverse_mp=config.get("reverse_mp", False),
+                         nhead=config.get("nhead", 8), dropout=config.get("backbone_dropout", 0.5))
+        if config["task"] == "edge_classification":
+            self.decoder = ClassifierHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
+        else:
+            self.decoder = NodeClassificationHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
+
+    def forward(self, x, edge_index, edge_attr):
+        x, _ = self.node_encoder(x)
+        edge_attr, _ = self.edge_encoder(edge_attr)
+        x, edge_attr = self.model(x, edge_index, edge_attr)
+        if self.config["task"] == "edge_classification":
+            bs = self.batch_size
+            return self.decoder(x, edge_index[:, :bs].contiguous(), edge_attr[:bs].contiguous())
+        return self.decoder(x)
+
+
+
+class GNN(nn.Module):
+    """``utils.py:111-233`` for ``--model pna`` (``PNAS``): encoders -> backbone -> head on the first ``batch_size``
+    (seed) edges, or on the nodes.  The reference's other GNN variants (gin / cpna / cpnatab) are not built."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.batch_size = config["batch_size"]
+        self.node_encoder = config["node_encoder"]
+        self.edge_encoder = config["edge_encoder"]
+        if config.get("model", "pna") != "pna":
+            raise ValueError("Invalid model name!")
+        if config.get("in_degrees") is None:
+            raise ValueError("In degrees are not provided for PNA model!")
+        n_dim = config["num_node_features"] * config["n_hidden"]
+        e_dim = config["num_edge_features"] * config["n_hidden"]
+        self.model = PNAS(num_features=n_dim, n_hidden=config["n_hidden"], num_gnn_layers=config["n_gnn_layers"],
+                          edge_dim=e_dim, deg=degree_histogram(config["in_degrees"]),
+                          edge_updates=config.get("emlps", True), reverse_mp=config.get("reverse_mp", False))
         if config["task"] == "edge_classification":
             self.decoder = ClassifierHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
         else:

@@ -37,7 +37,7 @@ def avg_degree_stats(deg_hist: torch.Tensor):
     return lin, log
 
 
-def multi_aggregate(h, dst, num_nodes):
+def multi_aggregate(h, dst, num_nodes, order=AGGREGATORS):
     """mean/max/min/std of messages ``h [E,F]`` per destination -> ``[N,4F]`` and ``deg [N]``.
 
     mean = sum / max(cnt,1); max/min over incoming (empty -> 0, ``include_self=False``);
@@ -55,7 +55,8 @@ def multi_aggregate(h, dst, num_nodes):
     var = s2 / denom - mean * mean
     std = var.clamp(min=1e-5).sqrt()
     std = std.masked_fill(std <= math.sqrt(1e-5), 0.0)
-    return torch.cat([mean, mx, mn, std], dim=1), cnt
+    by_name = {"mean": mean, "max": mx, "min": mn, "std": std}
+    return torch.cat([by_name[a] for a in order], dim=1), cnt   # PyG concatenates in the module's aggregator order
 
 
 def degree_scale(agg, deg, avg_deg_log):
@@ -66,7 +67,7 @@ def degree_scale(agg, deg, avg_deg_log):
     return torch.cat([agg, agg * amp, agg * att], dim=1)
 
 
-def pna_conv(x, edge_index, edge_attr, sd, pfx):
+def pna_conv(x, edge_index, edge_attr, sd, pfx, aggregators=AGGREGATORS):
     """One ``PNAConv.forward``: x [N,F], edge_index int64 [2,E] (row 0 = source j, row 1 = target i),
     edge_attr [E,F] -> [N,F]."""
     N = x.shape[0]
@@ -74,25 +75,25 @@ def pna_conv(x, edge_index, edge_attr, sd, pfx):
     e = edge_attr @ sd[pfx + "edge_encoder.weight"].t() + sd[pfx + "edge_encoder.bias"]
     h = torch.cat([x[dst], x[src], e], dim=-1)                       # [x_i, x_j, e]
     h = h @ sd[pfx + "pre_nns.0.0.weight"].t() + sd[pfx + "pre_nns.0.0.bias"]
-    agg, deg = multi_aggregate(h, dst, N)
+    agg, deg = multi_aggregate(h, dst, N, aggregators)
     out = degree_scale(agg, deg, sd[pfx + "aggr_module.avg_deg_log"])
     out = torch.cat([x, out], dim=-1)                                 # [N,13F]
     out = out @ sd[pfx + "post_nns.0.0.weight"].t() + sd[pfx + "post_nns.0.0.bias"]
     return out @ sd[pfx + "lin.weight"].t() + sd[pfx + "lin.bias"]
 
 
-def pna_conv_hetero(x, edge_index, edge_attr, sd, pfx):
+def pna_conv_hetero(x, edge_index, edge_attr, sd, pfx, aggregators=AGGREGATORS):
     """``PNAConvHetero.forward`` (src/nn/gnn/pna.py:38-46): forward conv + conv on flipped edges,
     then ``lin([x, a_in, a_out])``."""
-    a_in = pna_conv(x, edge_index, edge_attr, sd, pfx + "conv_forw.")
-    a_out = pna_conv(x, edge_index.flipud(), edge_attr, sd, pfx + "conv_back.")
+    a_in = pna_conv(x, edge_index, edge_attr, sd, pfx + "conv_forw.", aggregators)
+    a_out = pna_conv(x, edge_index.flipud(), edge_attr, sd, pfx + "conv_back.", aggregators)
     return torch.cat([x, a_in, a_out], dim=1) @ sd[pfx + "lin.weight"].t() + sd[pfx + "lin.bias"]
 
 
-def gnn_conv(x, edge_index, edge_attr, sd, pfx):
+def gnn_conv(x, edge_index, edge_attr, sd, pfx, aggregators=AGGREGATORS):
     if (pfx + "conv_forw.lin.weight") in sd:
-        return pna_conv_hetero(x, edge_index, edge_attr, sd, pfx)
-    return pna_conv(x, edge_index, edge_attr, sd, pfx)
+        return pna_conv_hetero(x, edge_index, edge_attr, sd, pfx, aggregators)
+    return pna_conv(x, edge_index, edge_attr, sd, pfx, aggregators)
 
 
 def batch_norm(x, sd, pfx, training, momentum=0.1, eps=1e-5, update_stats=True):

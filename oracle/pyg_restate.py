@@ -35,7 +35,8 @@ class PNAConv(nn.Module):
                  pre_layers=1, post_layers=1, divide_input=False, **kw):
         super().__init__()
         assert towers == 1 and pre_layers == 1 and post_layers == 1 and not divide_input
-        assert tuple(aggregators) == P.AGGREGATORS and tuple(scalers) == P.SCALERS
+        assert sorted(aggregators) == sorted(P.AGGREGATORS) and tuple(scalers) == P.SCALERS
+        self.aggregators = tuple(aggregators)
         assert edge_dim is not None and in_channels == out_channels
         F_ = in_channels
         self.aggr_module = _AggrModule(deg)
@@ -50,7 +51,7 @@ class PNAConv(nn.Module):
                 m.reset_parameters()
 
     def forward(self, x, edge_index, edge_attr=None):
-        return P.pna_conv(x, edge_index, edge_attr, dict(self.state_dict(keep_vars=True)), "")
+        return P.pna_conv(x, edge_index, edge_attr, dict(self.state_dict(keep_vars=True)), "", self.aggregators)
 
 
 class BatchNorm(nn.Module):

@@ -57,7 +57,8 @@ def load_reference():
     ssl = importlib.import_module("src.nn.decoder.self_supervised")
     spec = importlib.util.spec_from_file_location("tabgnn_ref_loss", f"{REF}/src/utils/loss.py")   # pure torch file
     loss = importlib.util.module_from_spec(spec); spec.loader.exec_module(loss)
-    extra = {"LinkPredHead": dec.LinkPredHead, "MCMHead": ssl.MCMHead, "SelfSupervisedHead": ssl.SelfSupervisedHead,
+    inter = importlib.import_module("src.nn.models.inteleaved")
+    extra = {"TABGNNInterleaved": inter.TABGNNInterleaved, "PNAS": pna.PNAS, "LinkPredHead": dec.LinkPredHead, "MCMHead": ssl.MCMHead, "SelfSupervisedHead": ssl.SelfSupervisedHead,
              "SSLoss": loss.SSLoss}
     return {**extra, "TABGNNFused": fused.TABGNNFused, "FTTransformerPNAFusedLayer": fused.FTTransformerPNAFusedLayer,
             "TABGNN": tabgnn.TABGNN, "PNAConvHetero": pna.PNAConvHetero,
