@@ -1,0 +1,219 @@
+// Forward / input-gradient GEMM of the Linears on the path, with the elementwise tail fused:
+//     Y[R,N] (bf16) = epilogue( X[R,K] W[N,K]^T )      R = table rows x columns / edges / nodes (10^5..10^7),
+//                                                       K, N in {128, 384, 512, 768}: "tall-skinny NT".
+// The op is HBM-bound (R*(K+N)*2 bytes; ~1 FLOP/byte-pair at K = 128), so the design goal is a clean row stream:
+//   * one 256-thread workgroup per 128-row x 128-column output tile; 64 KiB LDS -> two workgroups per CU overlap
+//     one's loads with the other's MFMAs and stores (no in-wave prefetch across the stores: loads and stores share
+//     vmcnt on gfx9, so a prefetched load would be waited for together with every store issued after it),
+//   * X rows and W rows are both contiguous along k, which is exactly what the MFMA 32x32x16 fragments want
+//     (8 consecutive k of one row per lane): 16-byte global loads -> XOR-swizzled row-major LDS image ->
+//     plain 16-byte ds_read fragments, no transposes anywhere,
+//   * A := W tile (M dim = output feature n), B := X tile (N dim = row r), so every lane ends up with 4 consecutive
+//     n of ONE row r per accumulator group: bias / ReLU / dropout / residual are applied in registers, packed to
+//     4 x bf16 and staged through LDS (the dead X image) so that HBM sees whole 256-byte row stores,
+//   * K > 128 loops over 128-wide k chunks with the next chunk's global loads in flight under the MFMAs
+//     (no stores in between), W chunks come from L2.
+// Epilogue (flags): + bias[n] (fp32) | ReLU | dropout(p; counter RNG on the element index r*N+n, the same stream the
+// stand-alone act_dropout kernels use, so their backward applies unchanged) | += existing Y (gradient accumulation).
+#include "common.hpp"
+#include "../../include/tabgnn_hip.h"
+
+namespace tg {
+
+typedef __bf16 nt_v8bf __attribute__((ext_vector_type(8)));
+typedef float nt_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NT_BM = 128, NT_BN = 128, NT_BK = 128;
+constexpr int NT_TILE_BYTES = 128 * 256;          // 128 rows x 128 bf16
+
+__device__ __forceinline__ int nt_off(int row, int ch) {      // byte offset of 16-byte chunk ch of tile row `row`
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__device__ __forceinline__ nt_v8bf nt_frag(const char* tile, int row, int ch) {
+  uint4 v = *reinterpret_cast<const uint4*>(tile + nt_off(row, ch));
+  return __builtin_bit_cast(nt_v8bf, v);
+}
+
+enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4 };
+
+__global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* __restrict__ X,
+                                                           const unsigned short* __restrict__ W,
+                                                           const float* __restrict__ bias, unsigned short* __restrict__ Y,
+                                                           long long R, int N, int K, long long ldx, long long ldy,
+                                                           int flags, unsigned thresh, float inv_keep,
+                                                           unsigned long long seed, unsigned rstream,
+                                                           long long row_base /* RNG index of row 0 */) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * NT_TILE_BYTES];   // [X image | W image] = 64 KiB
+  char* xs = lds;
+  char* ws = lds + NT_TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2.  The
+  // N/128 column tiles of one row tile get consecutive slots of the SAME XCD, so they run together there and the
+  // row tile's X rows are read from HBM once and from that L2 afterwards.
+  const int ncol = N / NT_BN;
+  const long long slot = blockIdx.x >> 3;
+  const long long row_tile = (slot / ncol) * 8 + (blockIdx.x & 7);
+  if (row_tile * NT_BM >= R) return;
+  const int n0 = (int)(slot % ncol) * NT_BN;
+  const long long r0 = row_tile * NT_BM;
+  const int wn = wave >> 1, wr = wave & 1;           // wave tile: 64 n x 64 r
+
+  nt_f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  // staging map: piece = tid + 256*p (p = 0..7) -> tile row = piece >> 4 (0..127), 16-byte chunk = piece & 15.
+  // Named registers, not arrays: an array written in one unrolled loop and read in another lands in scratch.
+  uint4 rx0, rx1, rx2, rx3, rx4, rx5, rx6, rx7, rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7;
+  const long long rlast = R - 1;
+  const int st_row = tid >> 4, st_ch = tid & 15;              // piece p: row st_row + 16*p, chunk st_ch
+#define NT_LOAD1(P, RX, RW, K0)                                                                       \
+  {                                                                                                   \
+    const int row = st_row + 16 * (P);                                                                \
+    const long long r = r0 + row < rlast ? r0 + row : rlast;   /* clamped: rows past R are never stored */ \
+    RX = *reinterpret_cast<const uint4*>(X + r * ldx + (K0) + st_ch * 8);                             \
+    RW = *reinterpret_cast<const uint4*>(W + (long long)(n0 + row) * K + (K0) + st_ch * 8);           \
+  }
+#define NT_LOAD(K0)                                                                                   \
+  NT_LOAD1(0, rx0, rw0, K0) NT_LOAD1(1, rx1, rw1, K0) NT_LOAD1(2, rx2, rw2, K0) NT_LOAD1(3, rx3, rw3, K0) \
+  NT_LOAD1(4, rx4, rw4, K0) NT_LOAD1(5, rx5, rw5, K0) NT_LOAD1(6, rx6, rw6, K0) NT_LOAD1(7, rx7, rw7, K0)
+#define NT_STORE1(P, RX, RW)                                                                          \
+  {                                                                                                   \
+    const int off = nt_off(st_row + 16 * (P), st_ch);                                                 \
+    *reinterpret_cast<uint4*>(xs + off) = RX;                                                         \
+    *reinterpret_cast<uint4*>(ws + off) = RW;                                                         \
+  }
+#define NT_STORE()                                                                                    \
+  NT_STORE1(0, rx0, rw0) NT_STORE1(1, rx1, rw1) NT_STORE1(2, rx2, rw2) NT_STORE1(3, rx3, rw3)         \
+  NT_STORE1(4, rx4, rw4) NT_STORE1(5, rx5, rw5) NT_STORE1(6, rx6, rw6) NT_STORE1(7, rx7, rw7)
+
+  // this lane's 32 bias values (features wn*64 + a*32 + 8g + 4*(lane>>5) + j), fetched under the first row loads
+  float bv[2][4][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) t = *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5));
+      bv[a][g][0] = t.x; bv[a][g][1] = t.y; bv[a][g][2] = t.z; bv[a][g][3] = t.w;
+    }
+
+#define NT_MFMA_CHUNK()                                                                               \
+  _Pragma("unroll") for (int ks = 0; ks < NT_BK / 16; ++ks) {                                         \
+    const int ch = ks * 2 + (lane >> 5), rr = lane & 31;                                              \
+    nt_v8bf a0 = nt_frag(ws, wn * 64 + rr, ch), a1 = nt_frag(ws, wn * 64 + 32 + rr, ch);             \
+    nt_v8bf b0 = nt_frag(xs, wr * 64 + rr, ch), b1 = nt_frag(xs, wr * 64 + 32 + rr, ch);             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);                  \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);                  \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);                  \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);                  \
+  }
+
+  // The last k chunk is peeled off the loop so that EVERY load in the loop body is unconditional and in bounds:
+  // with `if (more) load(next)` hipcc hoisted 14 of the 16 next-chunk loads out of the guard (speculative reads
+  // 256 bytes past each row; a fault when the operand ends on its mapping's last page).
+  NT_LOAD(0)
+  int k0 = 0;
+  for (; k0 + NT_BK < K; k0 += NT_BK) {
+    NT_STORE()                                        // waits for the chunk's loads; registers free again
+    __syncthreads();
+    NT_LOAD(k0 + NT_BK)                               // next k chunk's loads fly under this chunk's MFMAs
+    NT_MFMA_CHUNK()
+    __syncthreads();                                  // both images consumed
+  }
+  NT_STORE()
+  __syncthreads();
+  NT_MFMA_CHUNK()
+  __syncthreads();
+
+  // epilogue in registers.  C/D map of a 32x32 tile: column (-> row r) = lane & 31,
+  // row (-> feature n) = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5): 4 consecutive n per register group
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int rl = wr * 64 + b * 32 + (lane & 31);          // row within the tile
+      const long long r = r0 + rl;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5);   // feature within the tile (multiple of 4)
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = acc[a][b][4 * g + j];
+          u += bv[a][g][j];
+          if (flags & NT_RELU) u = fmaxf(u, 0.f);
+          if (flags & NT_DROPOUT)
+            u *= drop_scale(seed, rstream, (unsigned long long)((row_base + r) * (long long)N + n0 + nl + j), thresh,
+                            inv_keep);
+          v[j] = u;
+        }
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(xs + nt_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;   // the X image is dead: output tile
+      }
+    }
+  __syncthreads();
+  // whole-row stores: piece -> (row, 16-byte chunk)
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int piece = tid + 256 * p, row = piece >> 4, ch = piece & 15;
+    const long long r = r0 + row;
+    if (r < R) {
+      uint4 o = *reinterpret_cast<const uint4*>(xs + nt_off(row, ch));
+      unsigned short* dst = Y + r * ldy + n0 + ch * 8;
+      if (flags & NT_ACCUM) {
+        const uint4 old = *reinterpret_cast<const uint4*>(dst);
+        const unsigned ow[4] = {old.x, old.y, old.z, old.w};
+        unsigned nw[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo = __uint_as_float(ow[j] << 16) + __uint_as_float(nw[j] << 16);
+          float hi = __uint_as_float(ow[j] & 0xffff0000u) + __uint_as_float(nw[j] & 0xffff0000u);
+          nw[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        }
+        o = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+      }
+      *reinterpret_cast<uint4*>(dst) = o;
+    }
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+// Y[R,N] = epilogue(X[R,K] W[N,K]^T);  X, W, Y bf16, bias fp32 [N] or NULL.  Requires N % 128 == 0, K % 128 == 0,
+// ldx/ldy multiples of 8, 16-byte aligned operands (tg_gemm_nt_supported tells).  flags: 1 ReLU, 2 dropout, 4 Y += .
+extern "C" int32_t tg_gemm_nt_supported(int64_t R, int32_t N, int32_t K) {
+  return R > 0 && N > 0 && K > 0 && N % NT_BN == 0 && K % NT_BK == 0;
+}
+
+extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, void* Y, int64_t R, int32_t N, int32_t K,
+                               int64_t ldx, int64_t ldy, int32_t flags, float p_drop, uint64_t seed, uint32_t rstream,
+                               void* stream) {
+  TG_CHECK(tg_gemm_nt_supported(R, N, K), "tg_gemm_nt_bf16: need N %% 128 == 0 and K %% 128 == 0 (R=%lld N=%d K=%d)",
+           (long long)R, N, K);
+  TG_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldy >= N, "tg_gemm_nt_bf16: bad row strides");
+  TG_CHECK((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
+           "tg_gemm_nt_bf16: operands must be 16-byte aligned");
+  TG_CHECK(!(flags & NT_DROPOUT) || ldy == N, "tg_gemm_nt_bf16: dropout needs a contiguous output (ldy == N)");
+  unsigned thresh = (flags & NT_DROPOUT) && p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  if (!thresh) flags &= ~NT_DROPOUT;
+  const long long row_tiles = (R + NT_BM - 1) / NT_BM;
+  const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
+  TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
+  hipLaunchKernelGGL(k_gemm_nt_bf16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)X, (const unsigned short*)W, bias, (unsigned short*)Y, (long long)R, N, K,
+                     (long long)ldx, (long long)ldy, flags, thresh, inv_keep, (unsigned long long)seed, rstream, 0LL);
+  TG_LAUNCH_CHECK();
+  return 0;
+}

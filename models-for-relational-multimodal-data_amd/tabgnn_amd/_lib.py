@@ -55,6 +55,8 @@ SIGNATURES = {
     "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "tg_seed_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "tg_gemm_tn_workspace_floats": [_i64, _i32, _i32],
+    "tg_gemm_nt_supported": [_i64, _i32, _i32],
+    "tg_gemm_nt_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _f32, _u64, _u32, _vp],
     "tg_gemm_tn_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
     "tg_weighted_ce_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "tg_weighted_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
@@ -104,8 +106,18 @@ def load():
     return lib
 
 
+_TRACE = os.environ.get("TABGNN_TRACE_CALLS") == "1"      # debugging aid: name every launch and wait for it
+
+
 def call(name, *args):
     lib = load()
+    if _TRACE:
+        print("tg call", name, flush=True)
+        rc = getattr(lib, name)(*args)
+        torch.cuda.synchronize()
+        if rc != 0:
+            raise RuntimeError(f"{name} failed ({rc}): {lib.tg_last_error().decode()}")
+        return
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {lib.tg_last_error().decode()}")

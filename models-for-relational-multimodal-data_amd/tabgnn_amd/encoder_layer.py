@@ -54,16 +54,23 @@ class _EncoderLayerFn(torch.autograd.Function):
         seed = ops.DropoutRNG.seed
         rs = [ops.DropoutRNG.next_stream() for _ in range(4)]          # attention, norm1, ffn, norm2
         x2d = x.view(T, C)
-        qkv = torch.addmm(lb_in, x2d, lw_in.t())
+        # projections on the hand-written MFMA kernel when the shapes allow (bf16, d_model = feed-forward = 128);
+        # its epilogue applies bias and, for linear1, ReLU + dropout, so the pre-activation never exists
+        nt = C == 128 and lw1.shape[0] == 128 and ops.nt_ok(x2d, 3 * C, C)     # every GEMM of the layer qualifies
+        qkv = ops.gemm_nt(x2d, lw_in, b_in.detach()) if nt else torch.addmm(lb_in, x2d, lw_in.t())
         o = torch.empty(T, C, dtype=dt, device=x.device)
         lse = torch.empty(R, nhead, S, dtype=torch.float32, device=x.device)
         L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, nhead, p, seed, rs[0], L.dt(x), L.stream())
-        y = o @ lw_o.t()
+        y = ops.gemm_nt(o, lw_o) if nt else o @ lw_o.t()
         x1, st1 = _ln_fwd(x2d, y, b_o, g1, be1, None, 0.0, 1.0, p, seed, rs[1])
-        hpre = torch.addmm(lb1, x1, lw1.t())
-        h = torch.empty_like(hpre)
-        L.call("tg_act_dropout_fwd", L.ptr(hpre), L.ptr(h), hpre.numel(), 1, p, seed, rs[2], L.dt(x), L.stream())
-        y2 = h @ lw2.t()
+        if nt:      # h = drop(relu(x1 W1^T + b1)) in one pass; the backward gates on h > 0 (kept AND active)
+            h = ops.gemm_nt(x1, lw1, b1.detach(), ops.NT_RELU | ops.NT_DROPOUT, p, seed, rs[2])
+            hpre = h
+        else:
+            hpre = torch.addmm(lb1, x1, lw1.t())
+            h = torch.empty_like(hpre)
+            L.call("tg_act_dropout_fwd", L.ptr(hpre), L.ptr(h), hpre.numel(), 1, p, seed, rs[2], L.dt(x), L.stream())
+        y2 = ops.gemm_nt(h, lw2) if nt else h @ lw2.t()
         x2, st2 = _ln_fwd(x1, y2, b2, g2, be2, None, 0.0, 1.0, p, seed, rs[3])
         if tail:
             out, st3 = _ln_fwd(x2, None, None, gt, bt, x2d if alpha != 0.0 else None, alpha, beta_c, 0.0, 0, 0)
@@ -72,6 +79,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2,
                               g1, g2, gt)
         ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
+        ctx.nt = nt
         isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
         ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2))   # weight gradients accumulate in place
         return out.view(R, S, C)
@@ -98,7 +106,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
         del d_x2
         dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
-        d_h = d_y2 @ lw2
+        nt = ctx.nt
+        d_h = ops.gemm_nt(d_y2, lw2.t()) if nt else d_y2 @ lw2
         del d_y2
         d_hpre = torch.empty_like(d_h)
         L.call("tg_act_dropout_bwd", L.ptr(hpre), L.ptr(d_h), L.ptr(d_hpre), hpre.numel(), 1, p, seed, rs[2],
@@ -107,7 +116,10 @@ class _EncoderLayerFn(torch.autograd.Function):
         dw1, db1 = ops.weight_grad(d_hpre, x1, True, p_1, pb_1)
         if db1 is None and dw1 is not None:
             db1 = d_hpre.sum(0, dtype=torch.float32)
-        d_x1.addmm_(d_hpre, lw1)                         # second consumer of x1: accumulated by the GEMM (beta = 1)
+        if nt:                                           # second consumer of x1: accumulated by the GEMM (beta = 1)
+            ops.gemm_nt(d_hpre, lw1.t(), None, ops.NT_ACCUM, out=d_x1)
+        else:
+            d_x1.addmm_(d_hpre, lw1)
         del d_hpre
         # x1 = LN1(x + drop(y + b_o))
         if d_x is None:
@@ -117,7 +129,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], True)
         del d_x1
         dwo, _ = ops.weight_grad(d_y, o, False, p_o)
-        d_o = d_y @ lw_o
+        d_o = ops.gemm_nt(d_y, lw_o.t()) if nt else d_y @ lw_o
         del d_y
         d_qkv = torch.empty_like(qkv)
         L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
@@ -126,7 +138,10 @@ class _EncoderLayerFn(torch.autograd.Function):
         dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
         if dbin is None and dwin is not None:
             dbin = d_qkv.sum(0, dtype=torch.float32)
-        d_x.addmm_(d_qkv, lw_in)                         # third consumer of x
+        if nt:                                           # third consumer of x
+            ops.gemm_nt(d_qkv, lw_in.t(), None, ops.NT_ACCUM, out=d_x)
+        else:
+            d_x.addmm_(d_qkv, lw_in)
         return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],
                 dp1[0], dp1[1], dp2[0], dp2[1], dgt, dbt)
 

@@ -147,16 +147,45 @@ class SeedIndex:
 # --------------------------------------------------------------------------- dense projection
 
 
+NT_RELU, NT_DROPOUT, NT_ACCUM = 1, 2, 4
+
+
+def nt_ok(x2, N, K):
+    """Shapes the hand-written MFMA GEMM (tg_gemm_nt_bf16) takes: bf16 rows, N and K multiples of 128; measured at or
+    above the library GEMM for N == 128 (any K) and for the QKV shape (K == 128, N == 384)."""
+    return (x2.dtype == torch.bfloat16 and x2.is_cuda and N % 128 == 0 and K % 128 == 0 and x2.shape[0] > 0
+            and (N == 128 or (K == 128 and N <= 384)) and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
+            and x2.data_ptr() % 16 == 0)
+
+
+def gemm_nt(x2, w, bias=None, flags=0, p=0.0, seed=0, rs=0, out=None):
+    """out[R,N] = epilogue(x2[R,K] w[N,K]^T)  (bf16; bias fp32 [N]; flags NT_RELU | NT_DROPOUT | NT_ACCUM)."""
+    R, K = x2.shape
+    N = w.shape[0]
+    w = w.contiguous()
+    if out is None:
+        out = torch.empty(R, N, dtype=x2.dtype, device=x2.device)
+    if bias is not None and bias.dtype != torch.float32:
+        bias = bias.float()
+    L.call("tg_gemm_nt_bf16", x2.data_ptr(), L.ptr(w), L.ptr(bias), L.ptr(out), R, N, K, x2.stride(0), out.stride(0),
+            int(flags), float(p), int(seed), int(rs), L.stream())
+    return out
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b.  GEMM by torch (hipBLASLt); W/b are fp32 masters, ``w_lp``/``b_lp`` their
-    compute-dtype shadows (bf16 mode).  Weight gradients are returned in fp32."""
+    """y = x W^T + b.  bf16 problems of the shapes ``nt_ok`` lists run on the hand-written MFMA kernel
+    (tg_gemm_nt_bf16), the rest on torch's library GEMM; W/b are fp32 masters, ``w_lp``/``b_lp`` their compute-dtype
+    shadows (bf16 mode).  Weight gradients are returned in fp32 (or accumulated in place, see weight_grad)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, w_lp, b_lp):
         w = weight if w_lp is None else w_lp
         b = bias if b_lp is None else b_lp
         x2 = x.reshape(-1, x.shape[-1])
-        y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
+        if nt_ok(x2, w.shape[0], w.shape[1]) and w.dtype == x2.dtype:
+            y = gemm_nt(x2, w, bias.detach() if bias is not None else None)
+        else:
+            y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
         ctx.xshape = x.shape
@@ -167,7 +196,12 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         x2, w = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
-        dx = (g2 @ w).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        elif g2.is_contiguous() and nt_ok(g2, w.shape[1], w.shape[0]) and w.dtype == g2.dtype:
+            dx = gemm_nt(g2, w.t()).reshape(ctx.xshape)          # dX = G W = G (W^T)^T: W^T [K,N] is the NT weight
+        else:
+            dx = (g2 @ w).reshape(ctx.xshape)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         wparam, bparam = ctx.params
         if ctx.needs_input_grad[1]:

@@ -84,3 +84,34 @@ def test_weight_grad_accumulates_into_existing_grad_buffer():
     ref = g.float().t() @ x.float()
     assert torch.allclose(w.grad, 0.5 + 2 * ref, rtol=1e-3, atol=1e-2)
     assert torch.allclose(b.grad, -1.0 + 2 * g.float().sum(0), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("R,N,K,flags", [(128, 128, 128, 0), (1000, 128, 128, 1), (4133, 384, 128, 0), (2500, 128, 384, 4),
+                                         (777, 128, 768, 1), (3000, 384, 512, 0), (5000, 128, 128, 3),
+                                         (49152, 128, 128, 0)])   # 12 MiB operands end on their mapping's last page
+def test_gemm_nt_fused_epilogue_matches_fp32_reference(R, N, K, flags):
+    """tg_gemm_nt_bf16: Y = epilogue(X W^T): bias, ReLU, dropout (same counter stream as tg_act_dropout_fwd, so the
+    fused output equals act_dropout applied to the un-fused product), accumulation into an existing Y; ragged R."""
+    from tabgnn_amd import _lib as L
+    torch.manual_seed(R + N)
+    x = (torch.randn(R, K, device=DEV) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=DEV) * 0.1).bfloat16()
+    b = torch.randn(N, device=DEV)
+    y0 = torch.randn(R, N, device=DEV).bfloat16()
+    y = y0.clone() if flags & 4 else torch.full((R, N), float("nan"), device=DEV).bfloat16()
+    p, seed, rs = 0.5, 1234567, 7
+    L.call("tg_gemm_nt_bf16", L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), R, N, K, K, N, flags, p, seed, rs, L.stream())
+    ref = x.float() @ w.float().t() + b
+    if flags & 1:
+        ref = ref.relu()
+    if flags & 2:                                        # mask of the stand-alone kernel on the same (seed, stream)
+        ones = torch.ones(R, N, device=DEV).bfloat16()
+        m = torch.empty_like(ones)
+        L.call("tg_act_dropout_fwd", L.ptr(ones), L.ptr(m), ones.numel(), 0, p, seed, rs, L.dt(ones), L.stream())
+        ref = ref * m.float()
+        frac = float((m == 0).float().mean())
+        assert 0.45 < frac < 0.55
+    if flags & 4:
+        ref = ref + y0.float()
+    err = (y.float() - ref).abs().max().item()
+    assert torch.isfinite(y.float()).all() and err < 0.03 * max(1.0, ref.abs().max().item()), err
