@@ -140,18 +140,22 @@ int tg_pna_scale_combine_bwd(const void* gout, const int32_t* rowptr, const floa
 /* seed-endpoint pooling of the fused layer, fused.py:261-268 (unique / index_add_ / bincount / mean) */
 int tg_seed_pool_fwd(const void* x, const void* xf, const int32_t* rowptr, const int32_t* perm, void* out, int32_t N,
                      int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);
+/* same update applied in place to x (only the <= 2B seed-endpoint rows are touched), as fused.py:268 does */
+int tg_seed_pool_inplace(void* x, const void* xf, const int32_t* tei, const int32_t* rowptr, const int32_t* perm,
+                         int32_t N, int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);
 int tg_seed_pool_bwd(const void* g, const int32_t* tei, const int32_t* rowptr, void* dx, void* dxf, int32_t N,
                      int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);
 
 /* ---- forward / input-gradient GEMM of the Linears on the path (torch.nn.Linear / TransformerEncoderLayer's
  *      in_proj, out_proj, linear1, linear2: fused.py:83-92; PNA and edge-update projections) with the elementwise
  *      tail fused:  Y[R,N] (bf16) = epilogue(X[R,K] W[N,K]^T);  epilogue = + bias (fp32 [N] or NULL) | flags&1 ReLU |
- *      flags&2 dropout(p_drop; element index r*N+n of stream (seed, rstream), as tg_act_dropout_*) | flags&4 Y += .
+ *      flags&2 dropout(p_drop; element index r*N+n of stream (seed, rstream), as tg_act_dropout_*) | flags&8 gate:
+ *      x 1/(1-p_drop) where gate[r,n] > 0 else 0 (backward of drop(relu(.)) from its saved output) | flags&4 Y += .
  *      MFMA 32x32x16 bf16, fp32 accumulation.  tg_gemm_nt_supported: N % 128 == 0 and K % 128 == 0. ------------- */
 int32_t tg_gemm_nt_supported(int64_t R, int32_t N, int32_t K);
-int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, void* Y, int64_t R, int32_t N, int32_t K,
-                    int64_t ldx, int64_t ldy, int32_t flags, float p_drop, uint64_t seed, uint32_t rstream,
-                    void* stream);
+int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* gate /* flags&8, else NULL */, void* Y,
+                    int64_t R, int32_t N, int32_t K, int64_t ldx, int64_t ldy, int32_t flags, float p_drop, uint64_t seed,
+                    uint32_t rstream, void* stream);
 
 /* ---- weight gradient of every Linear on the path (autograd of torch.nn.Linear in the reference):
  *      out[M,N] (fp32) = G[R,M]^T X[R,N], bf16 operands, split over row slabs, deterministic slab sum ------- */

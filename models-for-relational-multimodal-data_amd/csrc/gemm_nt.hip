@@ -14,7 +14,8 @@
 //   * K > 128 loops over 128-wide k chunks with the next chunk's global loads in flight under the MFMAs
 //     (no stores in between), W chunks come from L2.
 // Epilogue (flags): + bias[n] (fp32) | ReLU | dropout(p; counter RNG on the element index r*N+n, the same stream the
-// stand-alone act_dropout kernels use, so their backward applies unchanged) | += existing Y (gradient accumulation).
+// stand-alone act_dropout kernels use, so their backward applies unchanged) | gate: x inv_keep where gate[r,n] > 0 else
+// 0 (the backward of drop(relu(.)) from the saved forward OUTPUT: > 0 <=> active and kept) | += existing Y.
 #include "common.hpp"
 #include "../../include/tabgnn_hip.h"
 
@@ -35,12 +36,14 @@ __device__ __forceinline__ nt_v8bf nt_frag(const char* tile, int row, int ch) {
   return __builtin_bit_cast(nt_v8bf, v);
 }
 
-enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4 };
+enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4, NT_GATE = 8 };
 
 __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* __restrict__ X,
                                                            const unsigned short* __restrict__ W,
-                                                           const float* __restrict__ bias, unsigned short* __restrict__ Y,
-                                                           long long R, int N, int K, long long ldx, long long ldy,
+                                                           const float* __restrict__ bias,
+                                                           const unsigned short* __restrict__ gate,
+                                                           unsigned short* __restrict__ Y, long long R, int N, int K,
+                                                           long long ldx, long long ldy,
                                                            int flags, unsigned thresh, float inv_keep,
                                                            unsigned long long seed, unsigned rstream,
                                                            long long row_base /* RNG index of row 0 */) {
@@ -168,6 +171,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
     if (r < R) {
       uint4 o = *reinterpret_cast<const uint4*>(xs + nt_off(row, ch));
       unsigned short* dst = Y + r * ldy + n0 + ch * 8;
+      if (flags & NT_GATE) {    // backward of drop(relu(.)): pass (x inv_keep) where the saved forward output is > 0
+        const uint4 gt = *reinterpret_cast<const uint4*>(gate + r * ldy + n0 + ch * 8);
+        const unsigned gw[4] = {gt.x, gt.y, gt.z, gt.w};
+        unsigned nw[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float lo = __uint_as_float(gw[j] << 16) > 0.f ? __uint_as_float(nw[j] << 16) * inv_keep : 0.f;
+          float hi = __uint_as_float(gw[j] & 0xffff0000u) > 0.f ? __uint_as_float(nw[j] & 0xffff0000u) * inv_keep : 0.f;
+          nw[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        }
+        o = make_uint4(nw[0], nw[1], nw[2], nw[3]);
+      }
       if (flags & NT_ACCUM) {
         const uint4 old = *reinterpret_cast<const uint4*>(dst);
         const unsigned ow[4] = {old.x, old.y, old.z, old.w};
@@ -190,14 +205,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
 using namespace tg;
 
 // Y[R,N] = epilogue(X[R,K] W[N,K]^T);  X, W, Y bf16, bias fp32 [N] or NULL.  Requires N % 128 == 0, K % 128 == 0,
-// ldx/ldy multiples of 8, 16-byte aligned operands (tg_gemm_nt_supported tells).  flags: 1 ReLU, 2 dropout, 4 Y += .
+// ldx/ldy multiples of 8, 16-byte aligned operands (tg_gemm_nt_supported tells).  flags: 1 ReLU, 2 dropout, 4 Y += ,
+// 8 gate (gate: bf16 [R, ldy] like Y; p_drop gives the 1/(1-p) factor).
 extern "C" int32_t tg_gemm_nt_supported(int64_t R, int32_t N, int32_t K) {
   return R > 0 && N > 0 && K > 0 && N % NT_BN == 0 && K % NT_BK == 0;
 }
 
-extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, void* Y, int64_t R, int32_t N, int32_t K,
-                               int64_t ldx, int64_t ldy, int32_t flags, float p_drop, uint64_t seed, uint32_t rstream,
-                               void* stream) {
+extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* gate, void* Y, int64_t R,
+                               int32_t N, int32_t K, int64_t ldx, int64_t ldy, int32_t flags, float p_drop, uint64_t seed,
+                               uint32_t rstream, void* stream) {
   TG_CHECK(tg_gemm_nt_supported(R, N, K), "tg_gemm_nt_bf16: need N %% 128 == 0 and K %% 128 == 0 (R=%lld N=%d K=%d)",
            (long long)R, N, K);
   TG_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= K && ldy >= N, "tg_gemm_nt_bf16: bad row strides");
@@ -205,14 +221,18 @@ extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, 
                (reinterpret_cast<uintptr_t>(Y) & 15) == 0,
            "tg_gemm_nt_bf16: operands must be 16-byte aligned");
   TG_CHECK(!(flags & NT_DROPOUT) || ldy == N, "tg_gemm_nt_bf16: dropout needs a contiguous output (ldy == N)");
+  TG_CHECK(!(flags & NT_GATE) || (gate && (reinterpret_cast<uintptr_t>(gate) & 15) == 0),
+           "tg_gemm_nt_bf16: gate flag needs a 16-byte aligned gate tensor (same layout as Y)");
   unsigned thresh = (flags & NT_DROPOUT) && p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   if (!thresh) flags &= ~NT_DROPOUT;
+  if (!(flags & (NT_DROPOUT | NT_GATE)) || p_drop <= 0.f) inv_keep = 1.f;
   const long long row_tiles = (R + NT_BM - 1) / NT_BM;
   const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
   TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
   hipLaunchKernelGGL(k_gemm_nt_bf16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)X, (const unsigned short*)W, bias, (unsigned short*)Y, (long long)R, N, K,
+                     (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
+                     (unsigned short*)Y, (long long)R, N, K,
                      (long long)ldx, (long long)ldy, flags, thresh, inv_keep, (unsigned long long)seed, rstream, 0LL);
   TG_LAUNCH_CHECK();
   return 0;

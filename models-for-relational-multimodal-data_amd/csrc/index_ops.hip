@@ -238,6 +238,43 @@ __global__ void k_seed_pool_fwd(const T* __restrict__ x, const T* __restrict__ x
   }
 }
 
+// In-place form (the reference updates x_gnn in place too, fused.py:268): only the seed endpoints' rows are touched.
+// One lane group per CSR position q of the 2B endpoint slots; the group at the FIRST position of a node's segment
+// owns that node (same summation order as k_seed_pool_fwd, so the two agree bit for bit).
+template <typename T, int VEC>
+__global__ void k_seed_pool_inplace(T* __restrict__ x, const T* __restrict__ xf, const int* __restrict__ tei,
+                                    const int* __restrict__ rowptr, const int* __restrict__ perm, int F, int B, int C,
+                                    int D) {
+  int vpr = F / VEC;
+  long long total = (long long)2 * B * vpr;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    int q = (int)(i / vpr), c = (int)(i % vpr) * VEC;
+    int n = tei[perm[q]];
+    int s = rowptr[n], e = rowptr[n + 1];
+    if (q != s) continue;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int qq = s; qq < e; ++qq) {
+      int slot = perm[qq];
+      int b = slot < B ? slot : slot - B;
+      int off = slot < B ? C : C + F;
+      float t[VEC];
+      loadv<T, VEC>(xf + (long long)b * D + off + c, t);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += t[j];
+    }
+    float v[VEC];
+    loadv<T, VEC>(x + (long long)n * F + c, v);
+    float inv = 1.f / (float)(e - s);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = (v[j] + acc[j] * inv) * 0.5f;
+    storev<T, VEC>(x + (long long)n * F + c, v);
+  }
+}
+
 // dx[i] = g[i] * (seed ? .5 : 1)
 template <typename T, int VEC>
 __global__ void k_seed_pool_bwd_x(const T* __restrict__ g, const int* __restrict__ rowptr, T* __restrict__ dx, int N,
@@ -352,6 +389,21 @@ extern "C" int tg_seed_pool_fwd(const void* x, const void* xf, const int32_t* ro
     long long total = (long long)N * (F / VEC);
     hipLaunchKernelGGL((k_seed_pool_fwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0,
                        (hipStream_t)stream, (const T*)x, (const T*)xf, rowptr, perm, (T*)out, N, F, B, C, D);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_seed_pool_inplace(void* x, const void* xf, const int32_t* tei, const int32_t* rowptr,
+                                    const int32_t* perm, int32_t N, int32_t F, int32_t B, int32_t C, int32_t dt,
+                                    void* stream) {
+  TG_CHECK(F % 8 == 0 && C % 8 == 0, "tg_seed_pool_inplace: F and C must be multiples of 8 (F=%d C=%d)", F, C);
+  if (B == 0) return 0;
+  int D = C + 2 * F;
+  DISPATCH_T(dt, {
+    long long total = (long long)2 * B * (F / VEC);
+    hipLaunchKernelGGL((k_seed_pool_inplace<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0,
+                       (hipStream_t)stream, (T*)x, (const T*)xf, tei, rowptr, perm, F, B, C, D);
   })
   TG_LAUNCH_CHECK();
   return 0;

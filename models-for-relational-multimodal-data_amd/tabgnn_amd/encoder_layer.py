@@ -107,12 +107,16 @@ class _EncoderLayerFn(torch.autograd.Function):
         del d_x2
         dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
         nt = ctx.nt
-        d_h = ops.gemm_nt(d_y2, lw2.t()) if nt else d_y2 @ lw2
-        del d_y2
-        d_hpre = torch.empty_like(d_h)
-        L.call("tg_act_dropout_bwd", L.ptr(hpre), L.ptr(d_h), L.ptr(d_hpre), hpre.numel(), 1, p, seed, rs[2],
-               L.dt(hpre), L.stream())
-        del d_h
+        if nt:      # dX GEMM with the backward of drop(relu(.)) in its epilogue: d_h never exists
+            d_hpre = ops.gemm_nt(d_y2, lw2.t(), None, ops.NT_GATE, p, gate=h)
+            del d_y2
+        else:
+            d_h = d_y2 @ lw2
+            del d_y2
+            d_hpre = torch.empty_like(d_h)
+            L.call("tg_act_dropout_bwd", L.ptr(hpre), L.ptr(d_h), L.ptr(d_hpre), hpre.numel(), 1, p, seed, rs[2],
+                   L.dt(hpre), L.stream())
+            del d_h
         dw1, db1 = ops.weight_grad(d_hpre, x1, True, p_1, pb_1)
         if db1 is None and dw1 is not None:
             db1 = d_hpre.sum(0, dtype=torch.float32)

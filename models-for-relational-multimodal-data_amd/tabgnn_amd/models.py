@@ -106,7 +106,7 @@ class FTTransformerPNAFusedLayer(nn.Module):
             h = ops.linear(h, f[7].weight, f[7].bias)
             xf = ops.layer_norm(h, self.fuse_norm.weight, self.fuse_norm.bias, res=xf0, alpha=0.5, beta_c=0.5)
             x_tab = ops.cls_merge(x_tab, xf)                                        # fused.py:259-260
-            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels)                  # fused.py:261-268
+            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=True)    # fused.py:261-268
         return x_tab, x_gnn, edge_attr
 
 

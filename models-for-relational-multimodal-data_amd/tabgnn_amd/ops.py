@@ -147,7 +147,7 @@ class SeedIndex:
 # --------------------------------------------------------------------------- dense projection
 
 
-NT_RELU, NT_DROPOUT, NT_ACCUM = 1, 2, 4
+NT_RELU, NT_DROPOUT, NT_ACCUM, NT_GATE = 1, 2, 4, 8
 
 
 def nt_ok(x2, N, K):
@@ -158,8 +158,9 @@ def nt_ok(x2, N, K):
             and x2.data_ptr() % 16 == 0)
 
 
-def gemm_nt(x2, w, bias=None, flags=0, p=0.0, seed=0, rs=0, out=None):
-    """out[R,N] = epilogue(x2[R,K] w[N,K]^T)  (bf16; bias fp32 [N]; flags NT_RELU | NT_DROPOUT | NT_ACCUM)."""
+def gemm_nt(x2, w, bias=None, flags=0, p=0.0, seed=0, rs=0, out=None, gate=None):
+    """out[R,N] = epilogue(x2[R,K] w[N,K]^T)  (bf16; bias fp32 [N]; flags NT_RELU | NT_DROPOUT | NT_ACCUM | NT_GATE;
+    ``gate`` [R,N]: the saved output of a drop(relu(.)) whose backward the epilogue applies)."""
     R, K = x2.shape
     N = w.shape[0]
     w = w.contiguous()
@@ -167,7 +168,7 @@ def gemm_nt(x2, w, bias=None, flags=0, p=0.0, seed=0, rs=0, out=None):
         out = torch.empty(R, N, dtype=x2.dtype, device=x2.device)
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    L.call("tg_gemm_nt_bf16", x2.data_ptr(), L.ptr(w), L.ptr(bias), L.ptr(out), R, N, K, x2.stride(0), out.stride(0),
+    L.call("tg_gemm_nt_bf16", x2.data_ptr(), L.ptr(w), L.ptr(bias), L.ptr(gate), L.ptr(out), R, N, K, x2.stride(0), out.stride(0),
             int(flags), float(p), int(seed), int(rs), L.stream())
     return out
 
@@ -647,13 +648,19 @@ class _SeedPool(torch.autograd.Function):
     """x_gnn with every seed endpoint averaged with the mean of its fused embeddings (fused.py:261-268)."""
 
     @staticmethod
-    def forward(ctx, x, xf, seeds, C):
-        x, xf = x.contiguous(), xf.contiguous()
+    def forward(ctx, x, xf, seeds, C, inplace):
+        xf = xf.contiguous()
         N, F = x.shape
+        ctx.seeds, ctx.cfg = seeds, (N, F, C)
+        if inplace and x.is_contiguous():       # touch only the <= 2B seed rows of x (fused.py:268 is in place too)
+            ctx.mark_dirty(x)
+            L.call("tg_seed_pool_inplace", L.ptr(x), L.ptr(xf), L.ptr(seeds.tei), L.ptr(seeds.rowptr), L.ptr(seeds.perm),
+                   N, F, seeds.B, C, L.dt(x), L.stream())
+            return x
+        x = x.contiguous()
         out = torch.empty_like(x)
         L.call("tg_seed_pool_fwd", L.ptr(x), L.ptr(xf), L.ptr(seeds.rowptr), L.ptr(seeds.perm), L.ptr(out), N, F,
                seeds.B, C, L.dt(x), L.stream())
-        ctx.seeds, ctx.cfg = seeds, (N, F, C)
         return out
 
     @staticmethod
@@ -665,11 +672,12 @@ class _SeedPool(torch.autograd.Function):
         dxf = torch.empty(seeds.B, C + 2 * F, dtype=g.dtype, device=g.device)
         L.call("tg_seed_pool_bwd", L.ptr(g), L.ptr(seeds.tei), L.ptr(seeds.rowptr), L.ptr(dx), L.ptr(dxf), N, F,
                seeds.B, C, L.dt(g), L.stream())
-        return dx, dxf, None, None
+        return dx, dxf, None, None, None
 
 
-def seed_pool(x, xf, seeds, C):
-    return _SeedPool.apply(x, xf, seeds, C)
+def seed_pool(x, xf, seeds, C, inplace=False):
+    """``inplace``: update x itself (it must be an intermediate nobody saved for backward; autograd checks)."""
+    return _SeedPool.apply(x, xf, seeds, C, inplace)
 
 
 # --------------------------------------------------------------------------- loss

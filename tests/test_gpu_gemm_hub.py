@@ -100,7 +100,7 @@ def test_gemm_nt_fused_epilogue_matches_fp32_reference(R, N, K, flags):
     y0 = torch.randn(R, N, device=DEV).bfloat16()
     y = y0.clone() if flags & 4 else torch.full((R, N), float("nan"), device=DEV).bfloat16()
     p, seed, rs = 0.5, 1234567, 7
-    L.call("tg_gemm_nt_bf16", L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), R, N, K, K, N, flags, p, seed, rs, L.stream())
+    L.call("tg_gemm_nt_bf16", L.ptr(x), L.ptr(w), L.ptr(b), None, L.ptr(y), R, N, K, K, N, flags, p, seed, rs, L.stream())
     ref = x.float() @ w.float().t() + b
     if flags & 1:
         ref = ref.relu()
@@ -115,3 +115,22 @@ def test_gemm_nt_fused_epilogue_matches_fp32_reference(R, N, K, flags):
         ref = ref + y0.float()
     err = (y.float() - ref).abs().max().item()
     assert torch.isfinite(y.float()).all() and err < 0.03 * max(1.0, ref.abs().max().item()), err
+
+
+def test_gemm_nt_gate_epilogue_is_the_backward_of_relu_dropout():
+    """flags & 8: out = (G W^T) * 1/(1-p) where the saved forward output h > 0, else 0 == tg_act_dropout_bwd of the
+    un-fused product (h > 0 <=> ReLU active AND kept by the dropout)."""
+    from tabgnn_amd import _lib as L, ops
+    torch.manual_seed(5)
+    R, N, K, p, seed, rs = 3000, 128, 128, 0.5, 99, 3
+    pre = torch.randn(R, N, device=DEV).bfloat16()
+    h = torch.empty_like(pre)
+    L.call("tg_act_dropout_fwd", L.ptr(pre), L.ptr(h), pre.numel(), 1, p, seed, rs, L.dt(pre), L.stream())
+    g = (torch.randn(R, K, device=DEV) * 0.5).bfloat16()
+    w = (torch.randn(N, K, device=DEV) * 0.1).bfloat16()
+    got = ops.gemm_nt(g, w, None, ops.NT_GATE, p, gate=h)
+    d_h = (g.float() @ w.float().t()).bfloat16()
+    want = torch.empty_like(d_h)
+    L.call("tg_act_dropout_bwd", L.ptr(pre), L.ptr(d_h), L.ptr(want), pre.numel(), 1, p, seed, rs, L.dt(pre), L.stream())
+    assert torch.equal(got == 0, want == 0)
+    assert (got.float() - want.float()).abs().max().item() < 0.05

@@ -294,3 +294,27 @@ def test_weighted_ce_and_adam_match_torch(T):
         ref_lin(xin).pow(2).sum().backward()
         opt.step(); ropt.step()
     np.testing.assert_allclose(lin.weight.detach().cpu().numpy(), ref_lin.weight.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_seed_pool_inplace_equals_out_of_place(T, dtype):
+    """fused.py:261-268 updates x_gnn in place; the in-place kernel touches only the seed rows and must agree bit for
+    bit (forward and gradients) with the copying kernel; duplicate seed endpoints share one mean."""
+    torch.manual_seed(0)
+    N, F, C, B = 500, 32, 16, 40
+    tei = torch.randint(0, N, (2, B))
+    tei[0, :6] = 7; tei[1, 3:9] = 7                                  # a node that is many seeds' endpoint
+    seeds = T.ops.SeedIndex(tei.to(DEV), N)
+    x0 = torch.randn(N, F).to(DEV).to(dtype)
+    xf0 = torch.randn(B, C + 2 * F).to(DEV).to(dtype)
+    go = torch.randn(N, F).to(DEV).to(dtype)
+    outs = []
+    for inplace in (False, True):
+        xl, xfl = x0.clone().requires_grad_(True), xf0.clone().requires_grad_(True)
+        y = T.ops.seed_pool(xl * 1.0, xfl, seeds, C, inplace=inplace)
+        y.backward(go)
+        outs.append((y.detach(), xl.grad, xfl.grad))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    touched = torch.zeros(N, dtype=torch.bool); touched[tei.flatten()] = True
+    assert torch.equal(outs[1][0][~touched.to(DEV)], x0[~touched.to(DEV)])          # other rows untouched

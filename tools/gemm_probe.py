@@ -30,8 +30,8 @@ for name, R, K, Nn in shapes:
     dx = torch.empty(R, K, device=dev, dtype=torch.bfloat16)
     mine_f = mine_b = float("nan")
     if Nn % 128 == 0 and K % 128 == 0:
-        mine_f = timeit(lambda: L.call("tg_gemm_nt_bf16", L.ptr(x), L.ptr(w), L.ptr(bf), L.ptr(y), R, Nn, K, K, Nn, 0, 0.0, 0, 0, L.stream()))
-        mine_b = timeit(lambda: L.call("tg_gemm_nt_bf16", L.ptr(g), L.ptr(wt), None, L.ptr(dx), R, K, Nn, Nn, K, 0, 0.0, 0, 0, L.stream()))
+        mine_f = timeit(lambda: L.call("tg_gemm_nt_bf16", L.ptr(x), L.ptr(w), L.ptr(bf), None, L.ptr(y), R, Nn, K, K, Nn, 0, 0.0, 0, 0, L.stream()))
+        mine_b = timeit(lambda: L.call("tg_gemm_nt_bf16", L.ptr(g), L.ptr(wt), None, None, L.ptr(dx), R, K, Nn, Nn, K, 0, 0.0, 0, 0, L.stream()))
     by = (R * K + R * Nn) * 2
     tot_f += tf; tot_b += tb; ideal += by / 5.3e12
     print(f"{name:22s} R={R:8d} K={K:4d} N={Nn:4d}: fwd {tf*1e6:7.1f} us {by/tf/1e12:5.2f} TB/s {2*R*K*Nn/tf/1e12:6.1f} TFLOP/s | dX {tb*1e6:7.1f} us {by/tb/1e12:5.2f} TB/s || mine fwd {mine_f*1e6:7.1f} us {by/mine_f/1e12:5.2f} TB/s dX {mine_b*1e6:7.1f} us {by/mine_b/1e12:5.2f} TB/s")
