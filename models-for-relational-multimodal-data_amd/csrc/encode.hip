@@ -117,27 +117,38 @@ __global__ void __launch_bounds__(256) k_encode_fwd(EncDesc d, EncPtrs p, T* __r
 template <typename T>
 __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const T* __restrict__ g, long long R,
                                                      int ncols, int C, int acc_floats, float* __restrict__ partials,
-                                                     float* __restrict__ big_table_grad) {
-  extern __shared__ float acc[];   // [acc_floats]
-  for (int i = threadIdx.x; i < acc_floats; i += 256) acc[i] = 0.f;
+                                                     float* __restrict__ big_table_grad, int groups) {
+  extern __shared__ __align__(16) float acc_all[];   // [groups][acc_floats]
+  for (int i = threadIdx.x; i < acc_floats * groups; i += 256) acc_all[i] = 0.f;
   __syncthreads();
   const long long rowstride = (long long)ncols * C;
-  for (long long r0 = (long long)blockIdx.x * ENC_RCH; r0 < R; r0 += (long long)gridDim.x * ENC_RCH) {
+  // each (column, 4-channel group) is owned by one thread: 8-byte (bf16) / 16-byte (fp32) loads — one channel per
+  // lane (2-byte loads) ran at 0.76 TB/s, request-bound.  With few columns the block is split into `groups` row
+  // groups (each with its own LDS accumulators, summed in group order at the end) so that all 256 threads work.
+  constexpr int V = 4;
+  const int nitems = d.ncol * (C / V);
+  const int grp = groups > 1 ? threadIdx.x / nitems : 0;
+  const int first = groups > 1 ? threadIdx.x % nitems : threadIdx.x;
+  const int step = groups > 1 ? nitems : 256;                  // groups > 1  =>  one item per thread
+  float* acc = acc_all + (grp < groups ? grp : 0) * acc_floats;
+  for (long long r0 = ((long long)blockIdx.x * groups + grp) * ENC_RCH; grp < groups && r0 < R;
+       r0 += (long long)gridDim.x * groups * ENC_RCH) {
     int nrows = (int)((R - r0) < ENC_RCH ? (R - r0) : ENC_RCH);
-    // each (column, channel) pair is owned by one thread of the block
-    for (int pr = threadIdx.x; pr < d.ncol * C; pr += 256) {
-      int ch = pr % C, ci = pr / C;
+    for (int pr = first; pr < nitems; pr += step) {
+      int ch = (pr % (C / V)) * V, ci = pr / (C / V);
       const EncCol& c = d.col[ci];
       if (c.kind == ENC_TS) continue;
       const T* gp = g + (r0 * ncols + c.out_col) * C + ch;
-      float gv[ENC_RCH];
-#pragma unroll
+      float gv[ENC_RCH][V];
       // loads are UNCONDITIONAL (row index clamped into the chunk) so that all 16 fly together: a per-element
       // "load or zero" on a runtime bound makes hipcc branch and wait around every load (guide §5, item 4c)
+#pragma unroll
       for (int rr = 0; rr < ENC_RCH; ++rr) {
         int rc = rr < nrows ? rr : nrows - 1;
-        float t = to_f<T>(gp[rc * rowstride]);
-        gv[rr] = rr < nrows ? t : 0.f;
+        float t[V];
+        loadv<T, V>(gp + rc * rowstride, t);
+#pragma unroll
+        for (int j = 0; j < V; ++j) gv[rr][j] = rr < nrows ? t[j] : 0.f;
       }
       if (c.kind == ENC_NUM || c.kind == ENC_REL) {
         // all 16 raw values are fetched before any arithmetic (no branch between the loads: they fly together)
@@ -148,16 +159,24 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
 #pragma unroll
         for (int rr = 0; rr < ENC_RCH; ++rr) zv[rr] = src[(rr < nrows ? rr : nrows - 1) * sstride];   // gv is 0 past nrows
         const float mu = isnum ? p.num_mean[c.src_col] : 0.f, sd = isnum ? p.num_std[c.src_col] : 1.f;
-        float aw = 0.f, ab = 0.f;
+        float aw[V], ab[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { aw[j] = 0.f; ab[j] = 0.f; }
 #pragma unroll
         for (int rr = 0; rr < ENC_RCH; ++rr) {
           float z = (zv[rr] - mu) / sd;
           bool ok = !isnan(z);
-          aw += ok ? gv[rr] * z : 0.f;
-          ab += ok ? gv[rr] : 0.f;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            aw[j] += ok ? gv[rr][j] * z : 0.f;
+            ab[j] += ok ? gv[rr][j] : 0.f;
+          }
         }
-        acc[c.acc_off + ch] += aw;
-        acc[c.acc_off + C + ch] += ab;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          acc[c.acc_off + ch + j] += aw[j];
+          acc[c.acc_off + C + ch + j] += ab[j];
+        }
       } else {
         const long long* src = p.cat + r0 * p.nc + c.src_col;
         int rowi[ENC_RCH];
@@ -167,19 +186,32 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
           rowi[rr] = (int)(idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx));
         }
         if (c.acc_off >= 0) {
-          // predicated read-modify-write of the thread-owned LDS column; row 0 (padding_idx) only ever gets += 0
+          // predicated read-modify-write of the thread-owned LDS columns; row 0 (padding_idx) only ever gets += 0
 #pragma unroll
-          for (int rr = 0; rr < ENC_RCH; ++rr) acc[c.acc_off + rowi[rr] * C + ch] += rowi[rr] != 0 ? gv[rr] : 0.f;
+          for (int rr = 0; rr < ENC_RCH; ++rr) {
+            float4* a4 = reinterpret_cast<float4*>(acc + c.acc_off + rowi[rr] * C + ch);
+            float4 a = *a4;
+            const bool on = rowi[rr] != 0;
+            a.x += on ? gv[rr][0] : 0.f; a.y += on ? gv[rr][1] : 0.f; a.z += on ? gv[rr][2] : 0.f; a.w += on ? gv[rr][3] : 0.f;
+            *a4 = a;
+          }
         } else {
 #pragma unroll
           for (int rr = 0; rr < ENC_RCH; ++rr)
-            if (rowi[rr] != 0) atomicAdd(big_table_grad + ((long long)c.tab_off + rowi[rr]) * C + ch, gv[rr]);
+            if (rowi[rr] != 0)
+#pragma unroll
+              for (int j = 0; j < V; ++j)
+                atomicAdd(big_table_grad + ((long long)c.tab_off + rowi[rr]) * C + ch + j, gv[rr][j]);
         }
       }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < acc_floats; i += 256) partials[(long long)blockIdx.x * acc_floats + i] = acc[i];
+  for (int i = threadIdx.x; i < acc_floats; i += 256) {
+    float t = acc_all[i];
+    for (int gq = 1; gq < groups; ++gq) t += acc_all[gq * acc_floats + i];
+    partials[(long long)blockIdx.x * acc_floats + i] = t;
+  }
 }
 
 // ------------------------------------------------------------------ timestamp columns
@@ -367,17 +399,21 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
     return 0;
   }
   if (d->nts < d->ncol) {
-    size_t shm = (size_t)acc_floats * sizeof(float);
-    TG_CHECK(shm <= 150 * 1024, "tg_encode_bwd: column group needs %zu B of LDS (> 150 KiB); split the launch", shm);
-    int grid = grid_cap(ceil_div(R, ENC_RCH), ENC_BWD_BLOCKS);
+    TG_CHECK((size_t)acc_floats * sizeof(float) <= 150 * 1024,
+             "tg_encode_bwd: column group needs %zu B of LDS (> 150 KiB); split the launch", (size_t)acc_floats * 4);
+    const int nitems = d->ncol * (C / 4);
+    int groups = nitems <= 128 ? 256 / nitems : 1;                 // all 256 threads busy when the columns are few
+    while (groups > 1 && (size_t)groups * acc_floats * sizeof(float) > 48 * 1024) --groups;
+    size_t shm = (size_t)groups * acc_floats * sizeof(float);
+    int grid = grid_cap(ceil_div(R, (long long)ENC_RCH * groups), ENC_BWD_BLOCKS);
     if (dt == F32) {
       (void)hipFuncSetAttribute((const void*)k_encode_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       hipLaunchKernelGGL((k_encode_bwd<float>), dim3(grid), dim3(256), shm, st, *d, *p, (const float*)g, (long long)R,
-                         ncols, C, acc_floats, partials, big_table_grad);
+                         ncols, C, acc_floats, partials, big_table_grad, groups);
     } else {
       (void)hipFuncSetAttribute((const void*)k_encode_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       hipLaunchKernelGGL((k_encode_bwd<bf16_t>), dim3(grid), dim3(256), shm, st, *d, *p, (const bf16_t*)g,
-                         (long long)R, ncols, C, acc_floats, partials, big_table_grad);
+                         (long long)R, ncols, C, acc_floats, partials, big_table_grad, groups);
     }
     hipLaunchKernelGGL(k_enc_reduce, dim3(ceil_div(acc_floats, 64)), dim3(256), 0, st, partials, grid, acc_floats,
                        dflat, (const int*)nullptr, 0);
