@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-e2e", action="store_true", help="skip the sampling-inclusive loop reported beside `value`")
+    ap.add_argument("--e2e-steps", type=int, default=8)
     return ap.parse_args()
 
 
@@ -65,6 +67,80 @@ def host_cores():
         except Exception:
             pass
     return min(n, 16)
+
+
+def copy_rate_gbs(dev):
+    """Device-to-device copy rate of this box (read + write bytes / time), the second roofline denominator of
+    SURVEY 8d next to the 8 TB/s vendor peak."""
+    n = 1 << 29
+    a = torch.empty(n, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record(); torch.cuda.synchronize()
+    return 2 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
+    """Sampling-inclusive loop on rank 0 (SURVEY 8d "end-to-end time including sampling"; 8f ranks 1-2): native k-hop
+    sampler on the host (prefetching one batch ahead) -> id upload -> row gather from the HBM-resident raw table ->
+    the same train step.  HI-Small-shaped graph: 515 080 nodes, 5 078 345 edges.  Reported beside `value`, never in it."""
+    import queue, threading
+    import numpy as np
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    from tabgnn_amd.frame import stype
+    from tabgnn_amd.sampler import ColumnStore, NeighborSampler
+    rs = np.random.RandomState(0)
+    N, E = 515_080, 5_078_345
+    ei = np.stack([rs.permutation(N)[S._zipf_choice(rs, N, E, 1.0)], rs.permutation(N)[S._zipf_choice(rs, N, E, 0.5)]])
+    num, cat, ts = S.edge_table(E, 0)
+    labels = torch.from_numpy((rs.rand(E) < 0.001).astype(np.int64))
+    store = ColumnStore({stype.numerical: torch.from_numpy(num), stype.categorical: torch.from_numpy(cat),
+                         stype.timestamp: torch.from_numpy(ts)}, S.EDGE_COLS,
+                        {stype.relation: torch.ones(N, 1)}, S.NODE_COLS, labels).to(dev)
+    n_workers = 2                               # one sampler handle per host thread (the C call releases the GIL)
+    samplers = [NeighborSampler(ei, N, (100, 100), num_threads=1) for _ in range(n_workers)]
+    warm = 2
+    total = steps + warm
+    seeds = [rs.choice(E, batch_size, replace=False) for _ in range(total)]
+    t_sample = [0.0] * total
+    slots = [queue.Queue(maxsize=1) for _ in range(total)]
+    ahead = threading.Semaphore(2 * n_workers)                      # bounded prefetch depth
+
+    def work(w):
+        for i in range(w, total, n_workers):
+            ahead.acquire()
+            t0 = time.perf_counter()
+            out = samplers[w].sample(seeds[i], i)
+            t_sample[i] = time.perf_counter() - t0
+            slots[i].put(out)
+
+    for w in range(n_workers):
+        threading.Thread(target=work, args=(w,), daemon=True).start()
+    edges = 0
+    for i in range(total):
+        eid, lei, nodes = slots[i].get()
+        ahead.release()
+        if i == warm:
+            torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0
+        eid_d, nodes_d = eid.to(dev, non_blocking=True), nodes.to(dev, non_blocking=True)
+        edge_tf = T.frame.TensorFrame({k: v.index_select(0, eid_d) for k, v in store.edge_feats.items()}, store.edge_cols)
+        node_tf = T.frame.TensorFrame({k: v.index_select(0, nodes_d) for k, v in store.node_feats.items()}, store.node_cols)
+        y = store.labels.index_select(0, eid_d[:batch_size])
+        T.train_step(model, flat, opt, (node_tf, lei.to(dev, non_blocking=True), edge_tf, y), loss_w)
+        edges += eid.numel()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(value=edges / dt, unit="edges/s", ms_per_step=1e3 * dt / steps, steps=steps,
+                edges_per_step=edges / steps, sampler_ms_per_batch=1e3 * float(np.mean(t_sample[warm:])),
+                sampler=f"libtabgnn_sampler.so k-hop [100,100], {n_workers} host threads (one handle each), prefetch <= "
+                        f"{2 * n_workers} batches",
+                graph="synthetic HI-Small-shaped: 515080 nodes, 5078345 edges, raw columns resident in HBM")
 
 
 def cpu_baseline(model_sd, nhead, bs, steps, lr, loss_w):
@@ -176,6 +252,7 @@ def main():
             traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
     except Exception:
         traffic = None
+    copy_gbs = copy_rate_gbs(dev)
     out = {
         "metric": "edges/sec per training step, fused AML supervised (TABGNNFused fwd+CE+bwd+Adam)",
         "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,6 +266,7 @@ def main():
                    "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}"},
         "roofline": {"kernel": "k_pna_aggregate_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
                      "algorithmic_bytes_per_launch": agg_bytes, "avg_launch_ms": agg_ms,
                      "launches_timed": timer.count("tg_pna_aggregate_fwd"),
                      "bwd_avg_launch_ms": timer.mean_ms("tg_pna_aggregate_bwd")},
@@ -196,6 +274,8 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(model.state_dict(), args.nhead, args.cpu_batch_size, args.cpu_steps,
                                            cfg["lr"], cfg["loss_weights"])
+    if not args.no_e2e and world == 1 and args.dtype == "bf16":
+        out["end_to_end"] = end_to_end(model, flat, opt, loss_w, args.batch_size, args.e2e_steps, dev)
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
