@@ -38,6 +38,11 @@ __device__ __forceinline__ nt_v8bf nt_frag(const char* tile, int row, int ch) {
 
 enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4, NT_GATE = 8 };
 
+// WIDE (K == 128, N > 128: the QKV projection, edge_emb's input gradient): ONE workgroup per row tile walks the
+// N/128 column tiles with the X image staged once; each W tile is prefetched into registers under the previous
+// tile's MFMAs and the output tile is restaged through the (dead) W image.  The narrow form gives every column tile
+// its own workgroup (XCD-aware order) and loops over k chunks instead.
+template <bool WIDE>
 __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* __restrict__ X,
                                                            const unsigned short* __restrict__ W,
                                                            const float* __restrict__ bias,
@@ -45,67 +50,61 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
                                                            unsigned short* __restrict__ Y, long long R, int N, int K,
                                                            long long ldx, long long ldy,
                                                            int flags, unsigned thresh, float inv_keep,
-                                                           unsigned long long seed, unsigned rstream,
-                                                           long long row_base /* RNG index of row 0 */) {
+                                                           unsigned long long seed, unsigned rstream) {
   __shared__ __attribute__((aligned(16))) char lds[2 * NT_TILE_BYTES];   // [X image | W image] = 64 KiB
   char* xs = lds;
   char* ws = lds + NT_TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2.  The
-  // N/128 column tiles of one row tile get consecutive slots of the SAME XCD, so they run together there and the
-  // row tile's X rows are read from HBM once and from that L2 afterwards.
   const int ncol = N / NT_BN;
-  const long long slot = blockIdx.x >> 3;
-  const long long row_tile = (slot / ncol) * 8 + (blockIdx.x & 7);
+  long long row_tile;
+  int n0;
+  if constexpr (WIDE) {
+    row_tile = blockIdx.x;
+    n0 = 0;
+  } else {
+    // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2.  The
+    // N/128 column tiles of one row tile get consecutive slots of the SAME XCD, so they run together there and the
+    // row tile's X rows are read from HBM once and from that L2 afterwards.
+    const long long slot = blockIdx.x >> 3;
+    row_tile = (slot / ncol) * 8 + (blockIdx.x & 7);
+    n0 = (int)(slot % ncol) * NT_BN;
+  }
   if (row_tile * NT_BM >= R) return;
-  const int n0 = (int)(slot % ncol) * NT_BN;
   const long long r0 = row_tile * NT_BM;
   const int wn = wave >> 1, wr = wave & 1;           // wave tile: 64 n x 64 r
 
   nt_f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+#define NT_ZERO_ACC()                                                                                 \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)         \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  NT_ZERO_ACC()
 
   // staging map: piece = tid + 256*p (p = 0..7) -> tile row = piece >> 4 (0..127), 16-byte chunk = piece & 15.
   // Named registers, not arrays: an array written in one unrolled loop and read in another lands in scratch.
   uint4 rx0, rx1, rx2, rx3, rx4, rx5, rx6, rx7, rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7;
   const long long rlast = R - 1;
   const int st_row = tid >> 4, st_ch = tid & 15;              // piece p: row st_row + 16*p, chunk st_ch
-#define NT_LOAD1(P, RX, RW, K0)                                                                       \
+#define NT_LOADX1(P, RX, K0)                                                                          \
   {                                                                                                   \
     const int row = st_row + 16 * (P);                                                                \
     const long long r = r0 + row < rlast ? r0 + row : rlast;   /* clamped: rows past R are never stored */ \
     RX = *reinterpret_cast<const uint4*>(X + r * ldx + (K0) + st_ch * 8);                             \
-    RW = *reinterpret_cast<const uint4*>(W + (long long)(n0 + row) * K + (K0) + st_ch * 8);           \
   }
-#define NT_LOAD(K0)                                                                                   \
-  NT_LOAD1(0, rx0, rw0, K0) NT_LOAD1(1, rx1, rw1, K0) NT_LOAD1(2, rx2, rw2, K0) NT_LOAD1(3, rx3, rw3, K0) \
-  NT_LOAD1(4, rx4, rw4, K0) NT_LOAD1(5, rx5, rw5, K0) NT_LOAD1(6, rx6, rw6, K0) NT_LOAD1(7, rx7, rw7, K0)
-#define NT_STORE1(P, RX, RW)                                                                          \
-  {                                                                                                   \
-    const int off = nt_off(st_row + 16 * (P), st_ch);                                                 \
-    *reinterpret_cast<uint4*>(xs + off) = RX;                                                         \
-    *reinterpret_cast<uint4*>(ws + off) = RW;                                                         \
-  }
-#define NT_STORE()                                                                                    \
-  NT_STORE1(0, rx0, rw0) NT_STORE1(1, rx1, rw1) NT_STORE1(2, rx2, rw2) NT_STORE1(3, rx3, rw3)         \
-  NT_STORE1(4, rx4, rw4) NT_STORE1(5, rx5, rw5) NT_STORE1(6, rx6, rw6) NT_STORE1(7, rx7, rw7)
-
-  // this lane's 32 bias values (features wn*64 + a*32 + 8g + 4*(lane>>5) + j), fetched under the first row loads
-  float bv[2][4][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) t = *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5));
-      bv[a][g][0] = t.x; bv[a][g][1] = t.y; bv[a][g][2] = t.z; bv[a][g][3] = t.w;
-    }
-
+#define NT_LOADW1(P, RW, N0, K0)                                                                      \
+  RW = *reinterpret_cast<const uint4*>(W + (long long)((N0) + st_row + 16 * (P)) * K + (K0) + st_ch * 8);
+#define NT_LOADX(K0)                                                                                  \
+  NT_LOADX1(0, rx0, K0) NT_LOADX1(1, rx1, K0) NT_LOADX1(2, rx2, K0) NT_LOADX1(3, rx3, K0)             \
+  NT_LOADX1(4, rx4, K0) NT_LOADX1(5, rx5, K0) NT_LOADX1(6, rx6, K0) NT_LOADX1(7, rx7, K0)
+#define NT_LOADW(N0, K0)                                                                              \
+  NT_LOADW1(0, rw0, N0, K0) NT_LOADW1(1, rw1, N0, K0) NT_LOADW1(2, rw2, N0, K0) NT_LOADW1(3, rw3, N0, K0) \
+  NT_LOADW1(4, rw4, N0, K0) NT_LOADW1(5, rw5, N0, K0) NT_LOADW1(6, rw6, N0, K0) NT_LOADW1(7, rw7, N0, K0)
+#define NT_ST1(BUF, P, RV) *reinterpret_cast<uint4*>((BUF) + nt_off(st_row + 16 * (P), st_ch)) = RV;
+#define NT_STOREX()                                                                                   \
+  NT_ST1(xs, 0, rx0) NT_ST1(xs, 1, rx1) NT_ST1(xs, 2, rx2) NT_ST1(xs, 3, rx3)                         \
+  NT_ST1(xs, 4, rx4) NT_ST1(xs, 5, rx5) NT_ST1(xs, 6, rx6) NT_ST1(xs, 7, rx7)
+#define NT_STOREW()                                                                                   \
+  NT_ST1(ws, 0, rw0) NT_ST1(ws, 1, rw1) NT_ST1(ws, 2, rw2) NT_ST1(ws, 3, rw3)                         \
+  NT_ST1(ws, 4, rw4) NT_ST1(ws, 5, rw5) NT_ST1(ws, 6, rw6) NT_ST1(ws, 7, rw7)
 #define NT_MFMA_CHUNK()                                                                               \
   _Pragma("unroll") for (int ks = 0; ks < NT_BK / 16; ++ks) {                                         \
     const int ch = ks * 2 + (lane >> 5), rr = lane & 31;                                              \
@@ -117,86 +116,120 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);                  \
   }
 
-  // The last k chunk is peeled off the loop so that EVERY load in the loop body is unconditional and in bounds:
-  // with `if (more) load(next)` hipcc hoisted 14 of the 16 next-chunk loads out of the guard (speculative reads
-  // 256 bytes past each row; a fault when the operand ends on its mapping's last page).
-  NT_LOAD(0)
-  int k0 = 0;
-  for (; k0 + NT_BK < K; k0 += NT_BK) {
-    NT_STORE()                                        // waits for the chunk's loads; registers free again
-    __syncthreads();
-    NT_LOAD(k0 + NT_BK)                               // next k chunk's loads fly under this chunk's MFMAs
-    NT_MFMA_CHUNK()
-    __syncthreads();                                  // both images consumed
+  // this lane's 32 bias values (features wn*64 + a*32 + 8g + 4*(lane>>5) + j of column tile N0)
+  float bv[2][4][4];
+#define NT_LOAD_BIAS(N0)                                                                              \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int g = 0; g < 4; ++g) {       \
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+    if (bias) t = *reinterpret_cast<const float4*>(bias + (N0) + wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5)); \
+    bv[a][g][0] = t.x; bv[a][g][1] = t.y; bv[a][g][2] = t.z; bv[a][g][3] = t.w;                       \
   }
-  NT_STORE()
-  __syncthreads();
-  NT_MFMA_CHUNK()
-  __syncthreads();
 
   // epilogue in registers.  C/D map of a 32x32 tile: column (-> row r) = lane & 31,
-  // row (-> feature n) = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5): 4 consecutive n per register group
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int rl = wr * 64 + b * 32 + (lane & 31);          // row within the tile
-      const long long r = r0 + rl;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5);   // feature within the tile (multiple of 4)
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float u = acc[a][b][4 * g + j];
-          u += bv[a][g][j];
-          if (flags & NT_RELU) u = fmaxf(u, 0.f);
-          if (flags & NT_DROPOUT)
-            u *= drop_scale(seed, rstream, (unsigned long long)((row_base + r) * (long long)N + n0 + nl + j), thresh,
-                            inv_keep);
-          v[j] = u;
-        }
-        uint2 pk;
-        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(xs + nt_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;   // the X image is dead: output tile
-      }
-    }
-  __syncthreads();
+  // row (-> feature n) = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5): 4 consecutive n per register group.
+  // OB = the dead LDS image that restages the output tile for whole-row stores.
+#define NT_EPILOGUE(OB, N0)                                                                           \
+  _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) {       \
+    const int rl = wr * 64 + b * 32 + (lane & 31);                                                    \
+    const long long r = r0 + rl;                                                                      \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
+      const int nl = wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5);                                      \
+      float v[4];                                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
+        float u = acc[a][b][4 * g + j] + bv[a][g][j];                                                 \
+        if (flags & NT_RELU) u = fmaxf(u, 0.f);                                                       \
+        if (flags & NT_DROPOUT)                                                                       \
+          u *= drop_scale(seed, rstream, (unsigned long long)(r * (long long)N + (N0) + nl + j), thresh, inv_keep); \
+        v[j] = u;                                                                                     \
+      }                                                                                               \
+      uint2 pk;                                                                                       \
+      pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);                                     \
+      pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);                                     \
+      *reinterpret_cast<uint2*>((OB) + nt_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;                      \
+    }                                                                                                 \
+  }
   // whole-row stores: piece -> (row, 16-byte chunk)
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int piece = tid + 256 * p, row = piece >> 4, ch = piece & 15;
-    const long long r = r0 + row;
-    if (r < R) {
-      uint4 o = *reinterpret_cast<const uint4*>(xs + nt_off(row, ch));
-      unsigned short* dst = Y + r * ldy + n0 + ch * 8;
-      if (flags & NT_GATE) {    // backward of drop(relu(.)): pass (x inv_keep) where the saved forward output is > 0
-        const uint4 gt = *reinterpret_cast<const uint4*>(gate + r * ldy + n0 + ch * 8);
-        const unsigned gw[4] = {gt.x, gt.y, gt.z, gt.w};
-        unsigned nw[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float lo = __uint_as_float(gw[j] << 16) > 0.f ? __uint_as_float(nw[j] << 16) * inv_keep : 0.f;
-          float hi = __uint_as_float(gw[j] & 0xffff0000u) > 0.f ? __uint_as_float(nw[j] & 0xffff0000u) * inv_keep : 0.f;
-          nw[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-        }
-        o = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-      }
-      if (flags & NT_ACCUM) {
-        const uint4 old = *reinterpret_cast<const uint4*>(dst);
-        const unsigned ow[4] = {old.x, old.y, old.z, old.w};
-        unsigned nw[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float lo = __uint_as_float(ow[j] << 16) + __uint_as_float(nw[j] << 16);
-          float hi = __uint_as_float(ow[j] & 0xffff0000u) + __uint_as_float(nw[j] & 0xffff0000u);
-          nw[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-        }
-        o = make_uint4(nw[0], nw[1], nw[2], nw[3]);
-      }
-      *reinterpret_cast<uint4*>(dst) = o;
+#define NT_WRITE_OUT(OB, N0)                                                                          \
+  _Pragma("unroll") for (int p = 0; p < 8; ++p) {                                                     \
+    const int piece = tid + 256 * p, row = piece >> 4, ch = piece & 15;                               \
+    const long long r = r0 + row;                                                                     \
+    if (r < R) {                                                                                      \
+      uint4 o = *reinterpret_cast<const uint4*>((OB) + nt_off(row, ch));                              \
+      unsigned short* dst = Y + r * ldy + (N0) + ch * 8;                                              \
+      if (flags & NT_GATE) { /* backward of drop(relu(.)): x inv_keep where the saved output is > 0 */ \
+        const uint4 gt = *reinterpret_cast<const uint4*>(gate + r * ldy + (N0) + ch * 8);             \
+        const unsigned gw[4] = {gt.x, gt.y, gt.z, gt.w};                                              \
+        unsigned nw[4] = {o.x, o.y, o.z, o.w};                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+          float lo = __uint_as_float(gw[j] << 16) > 0.f ? __uint_as_float(nw[j] << 16) * inv_keep : 0.f; \
+          float hi = __uint_as_float(gw[j] & 0xffff0000u) > 0.f ? __uint_as_float(nw[j] & 0xffff0000u) * inv_keep : 0.f; \
+          nw[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);                                    \
+        }                                                                                             \
+        o = make_uint4(nw[0], nw[1], nw[2], nw[3]);                                                   \
+      }                                                                                               \
+      if (flags & NT_ACCUM) {                                                                         \
+        const uint4 old = *reinterpret_cast<const uint4*>(dst);                                       \
+        const unsigned ow[4] = {old.x, old.y, old.z, old.w};                                          \
+        unsigned nw[4] = {o.x, o.y, o.z, o.w};                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+          float lo = __uint_as_float(ow[j] << 16) + __uint_as_float(nw[j] << 16);                     \
+          float hi = __uint_as_float(ow[j] & 0xffff0000u) + __uint_as_float(nw[j] & 0xffff0000u);     \
+          nw[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);                                    \
+        }                                                                                             \
+        o = make_uint4(nw[0], nw[1], nw[2], nw[3]);                                                   \
+      }                                                                                               \
+      *reinterpret_cast<uint4*>(dst) = o;                                                             \
+    }                                                                                                 \
+  }
+
+  if constexpr (WIDE) {
+    NT_LOADX(0)
+    NT_LOADW(0, 0)
+    NT_STOREX()
+    NT_STOREW()
+    __syncthreads();
+    for (int ct = 0; ct < ncol; ++ct) {
+      const int nc0 = ct * NT_BN;
+      // next W tile (the last one once more on the final pass: unconditional, always in bounds) and this tile's
+      // bias fly under the MFMAs
+      const int nnext = (ct + 1 < ncol ? ct + 1 : ct) * NT_BN;
+      NT_LOADW(nnext, 0)
+      NT_LOAD_BIAS(nc0)
+      NT_ZERO_ACC()
+      NT_MFMA_CHUNK()
+      __syncthreads();                                // W image consumed -> it restages the output tile
+      NT_EPILOGUE(ws, nc0)
+      __syncthreads();
+      NT_WRITE_OUT(ws, nc0)
+      __syncthreads();
+      NT_STOREW()
+      __syncthreads();
     }
+  } else {
+    NT_LOAD_BIAS(n0)
+    // The last k chunk is peeled off the loop so that EVERY load in the loop body is unconditional and in bounds:
+    // with `if (more) load(next)` hipcc hoisted 14 of the 16 next-chunk loads out of the guard (speculative reads
+    // 256 bytes past each row; a fault when the operand ends on its mapping's last page).
+    NT_LOADX(0)
+    NT_LOADW(n0, 0)
+    int k0 = 0;
+    for (; k0 + NT_BK < K; k0 += NT_BK) {
+      NT_STOREX()                                     // waits for the chunk's loads; registers free again
+      NT_STOREW()
+      __syncthreads();
+      NT_LOADX(k0 + NT_BK)                            // next k chunk's loads fly under this chunk's MFMAs
+      NT_LOADW(n0, k0 + NT_BK)
+      NT_MFMA_CHUNK()
+      __syncthreads();                                // both images consumed
+    }
+    NT_STOREX()
+    NT_STOREW()
+    __syncthreads();
+    NT_MFMA_CHUNK()
+    __syncthreads();
+    NT_EPILOGUE(xs, n0)                               // the X image is dead: output tile
+    __syncthreads();
+    NT_WRITE_OUT(xs, n0)
   }
 }
 
@@ -228,12 +261,20 @@ extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, 
   if (!thresh) flags &= ~NT_DROPOUT;
   if (!(flags & (NT_DROPOUT | NT_GATE)) || p_drop <= 0.f) inv_keep = 1.f;
   const long long row_tiles = (R + NT_BM - 1) / NT_BM;
-  const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
-  TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
-  hipLaunchKernelGGL(k_gemm_nt_bf16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
-                     (unsigned short*)Y, (long long)R, N, K,
-                     (long long)ldx, (long long)ldy, flags, thresh, inv_keep, (unsigned long long)seed, rstream, 0LL);
+  if (K == NT_BK && N > NT_BN) {       // wide outputs of a 128-deep product: one workgroup per row tile
+    TG_CHECK(row_tiles <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
+    hipLaunchKernelGGL((k_gemm_nt_bf16<true>), dim3((unsigned)row_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
+                       (unsigned short*)Y, (long long)R, N, K, (long long)ldx, (long long)ldy, flags, thresh, inv_keep,
+                       (unsigned long long)seed, rstream);
+  } else {
+    const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
+    TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
+    hipLaunchKernelGGL((k_gemm_nt_bf16<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
+                       (unsigned short*)Y, (long long)R, N, K, (long long)ldx, (long long)ldy, flags, thresh, inv_keep,
+                       (unsigned long long)seed, rstream);
+  }
   TG_LAUNCH_CHECK();
   return 0;
 }

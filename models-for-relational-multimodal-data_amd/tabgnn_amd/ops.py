@@ -152,9 +152,9 @@ NT_RELU, NT_DROPOUT, NT_ACCUM, NT_GATE = 1, 2, 4, 8
 
 def nt_ok(x2, N, K):
     """Shapes the hand-written MFMA GEMM (tg_gemm_nt_bf16) takes: bf16 rows, N and K multiples of 128; measured at or
-    above the library GEMM for N == 128 (any K) and for the QKV shape (K == 128, N == 384)."""
+    above the library GEMM for N == 128 (any K) and for K == 128 (any N: the QKV projection, edge_emb's dX)."""
     return (x2.dtype == torch.bfloat16 and x2.is_cuda and N % 128 == 0 and K % 128 == 0 and x2.shape[0] > 0
-            and (N == 128 or (K == 128 and N <= 384)) and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
+            and (N == 128 or K == 128) and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
             and x2.data_ptr() % 16 == 0)
 
 

@@ -88,7 +88,7 @@ def test_weight_grad_accumulates_into_existing_grad_buffer():
 
 @pytest.mark.parametrize("R,N,K,flags", [(128, 128, 128, 0), (1000, 128, 128, 1), (4133, 384, 128, 0), (2500, 128, 384, 4),
                                          (777, 128, 768, 1), (3000, 384, 512, 0), (5000, 128, 128, 3),
-                                         (49152, 128, 128, 0)])   # 12 MiB operands end on their mapping's last page
+                                         (3001, 768, 128, 3), (2000, 384, 128, 4), (49152, 128, 128, 0)])   # 12 MiB operands end on their mapping's last page
 def test_gemm_nt_fused_epilogue_matches_fp32_reference(R, N, K, flags):
     """tg_gemm_nt_bf16: Y = epilogue(X W^T): bias, ReLU, dropout (same counter stream as tg_act_dropout_fwd, so the
     fused output equals act_dropout applied to the un-fused product), accumulation into an existing Y; ragged R."""
