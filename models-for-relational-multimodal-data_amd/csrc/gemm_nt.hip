@@ -135,11 +135,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
     _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
       const int nl = wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5);                                      \
       float v[4];                                                                                     \
+      const unsigned long long e0 = (unsigned long long)(r * (long long)N + (N0) + nl);   /* multiple of 4 */ \
+      const unsigned key = rng_key(seed, rstream, (unsigned)(e0 >> 32));                              \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
         float u = acc[a][b][4 * g + j] + bv[a][g][j];                                                 \
         if (flags & NT_RELU) u = fmaxf(u, 0.f);                                                       \
-        if (flags & NT_DROPOUT)                                                                       \
-          u *= drop_scale(seed, rstream, (unsigned long long)(r * (long long)N + (N0) + nl + j), thresh, inv_keep); \
+        if (flags & NT_DROPOUT) u *= drop_scale_key(key, (unsigned)e0 + j, thresh, inv_keep);         \
         v[j] = u;                                                                                     \
       }                                                                                               \
       uint2 pk;                                                                                       \

@@ -51,9 +51,10 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_fwd(const T* __restrict__ a, co
           float t[VEC];
           loadv<T, VEC>(b + row * C + c, t);
           const unsigned long long e0 = (unsigned long long)(row * C + c);
+          const unsigned key = rng_key(seed, rstream, (unsigned)(e0 >> 32));   // c % VEC == 0: no carry within the vector
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {   // branch-free: the mask is a select, so nothing splits the loads
-            float m = drop_scale(seed, rstream, e0 + j, thresh, inv_keep);
+            float m = drop_scale_key(key, (unsigned)e0 + j, thresh, inv_keep);
             x[k][j] += (t[j] + bsr[k][j]) * (thresh ? m : 1.f);
           }
         }
@@ -145,9 +146,10 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
           float t[VEC];
           loadv<T, VEC>(b + row * C + c, t);
           const unsigned long long e0 = (unsigned long long)(row * C + c);
+          const unsigned key = rng_key(seed, rstream, (unsigned)(e0 >> 32));
 #pragma unroll
           for (int j = 0; j < VEC; ++j) {   // branch-free (select), see k_ln_fwd
-            float m = drop_scale(seed, rstream, e0 + j, thresh, inv_keep);
+            float m = drop_scale_key(key, (unsigned)e0 + j, thresh, inv_keep);
             m = thresh ? m : 1.f;
             msk[k][j] = m;
             x[j] += (t[j] + bsr[k][j]) * m;
@@ -463,12 +465,13 @@ __global__ void k_act_dropout_fwd(const T* __restrict__ x, T* __restrict__ y, lo
     else
 #pragma unroll
       for (int j = 0; j < VEC; ++j) v[j] = i + j < n ? to_f<T>(x[i + j]) : 0.f;
+    const unsigned key = rng_key(seed, rstream, (unsigned)((unsigned long long)i >> 32));   // i % VEC == 0
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float u = v[j];
       if (act == 1) u = fmaxf(u, 0.f);
       else if (act == 2) u = u > 0.f ? u : 0.01f * u;
-      if (thresh) u *= drop_scale(seed, rstream, (unsigned long long)(i + j), thresh, inv_keep);
+      if (thresh) u *= drop_scale_key(key, (unsigned)i + j, thresh, inv_keep);
       v[j] = u;
     }
     if (full) storev<T, VEC>(y + i, v);
@@ -491,12 +494,13 @@ __global__ void k_act_dropout_bwd(const T* __restrict__ x, const T* __restrict__
     else
 #pragma unroll
       for (int j = 0; j < VEC; ++j) { v[j] = i + j < n ? to_f<T>(x[i + j]) : 0.f; g[j] = i + j < n ? to_f<T>(dy[i + j]) : 0.f; }
+    const unsigned key = rng_key(seed, rstream, (unsigned)((unsigned long long)i >> 32));   // i % VEC == 0
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float d = g[j];
       if (act == 1) d = v[j] > 0.f ? d : 0.f;
       else if (act == 2) d = v[j] > 0.f ? d : 0.01f * d;
-      if (thresh) d *= drop_scale(seed, rstream, (unsigned long long)(i + j), thresh, inv_keep);
+      if (thresh) d *= drop_scale_key(key, (unsigned)i + j, thresh, inv_keep);
       g[j] = d;
     }
     if (full) storev<T, VEC>(dx + i, g);
