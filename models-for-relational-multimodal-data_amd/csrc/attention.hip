@@ -46,6 +46,10 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const T* __restrict__ qkv, T* 
   for (; gid < total; gid += stride) {
     int sq = (int)(gid % S);
     long long rh = gid / S;
+    // the S*S mask indices of one (row, head) share the dropout key unless they straddle a 2^32 boundary
+    const unsigned long long blk0 = (unsigned long long)rh * S * S;
+    const bool one_key = (blk0 >> 32) == ((blk0 + (unsigned long long)(S * S - 1)) >> 32);
+    const unsigned key = rng_key(seed, rstream, (unsigned)(blk0 >> 32));
     int h = (int)(rh % H);
     long long r = rh / H;
     const T* base = qkv + r * S * 3 * C + h * D;
@@ -66,7 +70,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const T* __restrict__ qkv, T* 
       float p = __expf(s - mn);
       l = l * corr + p;
       float pm = p;
-      if (thresh) pm *= drop_scale(seed, rstream, (unsigned long long)((rh * S + sq) * S + k), thresh, inv_keep);
+      if (thresh) pm *= one_key ? drop_scale_key(key, (unsigned)(blk0 + (unsigned long long)(sq * S + k)), thresh, inv_keep)
+                                : drop_scale(seed, rstream, blk0 + (unsigned long long)(sq * S + k), thresh, inv_keep);
 #pragma unroll
       for (int i = 0; i < D; ++i) acc[i] = acc[i] * corr + pm * vv[i];
       m = mn;
@@ -93,6 +98,10 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const T* __restrict__ qkv, con
   for (; gid < total; gid += stride) {
     int me = (int)(gid % S);
     long long rh = gid / S;
+    // the S*S mask indices of one (row, head) share the dropout key unless they straddle a 2^32 boundary
+    const unsigned long long blk0 = (unsigned long long)rh * S * S;
+    const bool one_key = (blk0 >> 32) == ((blk0 + (unsigned long long)(S * S - 1)) >> 32);
+    const unsigned key = rng_key(seed, rstream, (unsigned)(blk0 >> 32));
     int h = (int)(rh % H);
     long long r = rh / H;
     const T* base = qkv + r * S * 3 * C + h * D;
@@ -123,7 +132,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const T* __restrict__ qkv, con
 #pragma unroll
         for (int i = 0; i < D; ++i) { s += qm[i] * kj[i]; dp += gm[i] * vj[i]; }
         float p = __expf(s * scale - lse_me);
-        float mk = thresh ? drop_scale(seed, rstream, (unsigned long long)((rh * S + me) * S + j), thresh, inv_keep) : 1.f;
+        float mk = !thresh ? 1.f
+                   : one_key ? drop_scale_key(key, (unsigned)(blk0 + (unsigned long long)(me * S + j)), thresh, inv_keep)
+                             : drop_scale(seed, rstream, blk0 + (unsigned long long)(me * S + j), thresh, inv_keep);
         float ds = p * (dp * mk - delta_me) * scale;
 #pragma unroll
         for (int i = 0; i < D; ++i) dq[i] += ds * kj[i];
@@ -151,7 +162,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const T* __restrict__ qkv, con
 #pragma unroll
         for (int i = 0; i < D; ++i) { s += qj[i] * km[i]; dp += gj[i] * vm[i]; }
         float p = __expf(s * scale - lbase[j]);
-        float mk = thresh ? drop_scale(seed, rstream, (unsigned long long)((rh * S + j) * S + me), thresh, inv_keep) : 1.f;
+        float mk = !thresh ? 1.f
+                   : one_key ? drop_scale_key(key, (unsigned)(blk0 + (unsigned long long)(j * S + me)), thresh, inv_keep)
+                             : drop_scale(seed, rstream, blk0 + (unsigned long long)(j * S + me), thresh, inv_keep);
         float ds = p * (dp * mk - delta_j) * scale;
         float pm = p * mk;
 #pragma unroll
