@@ -176,6 +176,93 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const T* __restrict__ qkv, con
   }
 }
 
+// Lane-split backward for head dims >= 16: the D channels of a (row, head, token) are spread over LPD = D/8 adjacent
+// lanes (8 channels = one 16-byte load each), dot products finish with xor-shuffles inside that lane group.  The
+// thread-per-token kernel above keeps 5 x D values live (250 VGPRs at D = 32 -> 2 waves per SIMD, latency-bound:
+// 1.84 ms at R = 430 k); here a lane holds 5 x 8.  Same arithmetic order per channel, the dot products only differ by
+// the (pairwise) order of the final cross-lane adds.  D = 32 at R = 430 k: 1.84 -> 1.58 ms with 8 channels per lane;
+// 4 channels per lane (more lanes, more replicated exp / mask / shuffle work) measured 2.2 ms.
+template <typename T, int D, int DL>
+__global__ void __launch_bounds__(256) k_attn_bwd_split(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                         const T* __restrict__ dout, const float* __restrict__ lse,
+                                                         T* __restrict__ dqkv, long long R, int S, int H, float scale,
+                                                         unsigned thresh, float inv_keep, unsigned long long seed,
+                                                         unsigned rstream) {
+  constexpr int LPD = D / DL;
+  static_assert(D % DL == 0 && (LPD & (LPD - 1)) == 0 && LPD <= 16, "head dim must be DL * power of two");
+  const int C = H * D;
+  const long long total = R * H * S * LPD;
+  long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;      // multiple of LPD: lane groups iterate together
+#define TG_RED(v) for (int m_ = LPD >> 1; m_ > 0; m_ >>= 1) v += __shfl_xor(v, m_, 64);
+  for (; gid < total; gid += stride) {
+    const int dq = (int)(gid % LPD) * DL;
+    const long long tok = gid / LPD;
+    const int me = (int)(tok % S);
+    const long long rh = tok / S;
+    const int h = (int)(rh % H);
+    const long long r = rh / H;
+    const unsigned long long blk0 = (unsigned long long)rh * S * S;
+    const bool one_key = (blk0 >> 32) == ((blk0 + (unsigned long long)(S * S - 1)) >> 32);
+    const unsigned key = rng_key(seed, rstream, (unsigned)(blk0 >> 32));
+    const T* base = qkv + r * S * 3 * C + h * D + dq;
+    const T* obase = o + r * S * C + h * D + dq;
+    const T* gbase = dout + r * S * C + h * D + dq;
+    const float* lbase = lse + rh * S;
+    T* dbase = dqkv + r * S * 3 * C + h * D + dq + (long long)me * 3 * C;
+    float qm[DL], km[DL], vm[DL], gm[DL];
+    loadv<T, DL>(base + (long long)me * 3 * C, qm);
+    loadv<T, DL>(base + (long long)me * 3 * C + C, km);
+    loadv<T, DL>(base + (long long)me * 3 * C + 2 * C, vm);
+    loadv<T, DL>(gbase + (long long)me * C, gm);
+    float delta_me = 0.f;
+    {
+      float om[DL];
+      loadv<T, DL>(obase + (long long)me * C, om);
+#pragma unroll
+      for (int i = 0; i < DL; ++i) delta_me += gm[i] * om[i];
+    }
+    TG_RED(delta_me)
+    const float lse_me = lbase[me];
+    float dqv[DL], dk[DL], dv[DL];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) { dqv[i] = 0.f; dk[i] = 0.f; dv[i] = 0.f; }
+    for (int j = 0; j < S; ++j) {
+      float qj[DL], kj[DL], vj[DL], gj[DL], oj[DL];
+      loadv<T, DL>(base + (long long)j * 3 * C, qj);
+      loadv<T, DL>(base + (long long)j * 3 * C + C, kj);
+      loadv<T, DL>(base + (long long)j * 3 * C + 2 * C, vj);
+      loadv<T, DL>(gbase + (long long)j * C, gj);
+      loadv<T, DL>(obase + (long long)j * C, oj);
+      // me as QUERY against key j; me as KEY against query j
+      float sA = 0.f, dpA = 0.f, sB = 0.f, dpB = 0.f, delta_j = 0.f;
+#pragma unroll
+      for (int i = 0; i < DL; ++i) {
+        sA += qm[i] * kj[i]; dpA += gm[i] * vj[i];
+        sB += qj[i] * km[i]; dpB += gj[i] * vm[i]; delta_j += gj[i] * oj[i];
+      }
+      TG_RED(sA) TG_RED(dpA) TG_RED(sB) TG_RED(dpB) TG_RED(delta_j)
+      const float pA = __expf(sA * scale - lse_me);
+      const float pB = __expf(sB * scale - lbase[j]);
+      float mkA = 1.f, mkB = 1.f;
+      if (thresh) {
+        const unsigned long long iA = blk0 + (unsigned long long)(me * S + j), iB = blk0 + (unsigned long long)(j * S + me);
+        mkA = one_key ? drop_scale_key(key, (unsigned)iA, thresh, inv_keep) : drop_scale(seed, rstream, iA, thresh, inv_keep);
+        mkB = one_key ? drop_scale_key(key, (unsigned)iB, thresh, inv_keep) : drop_scale(seed, rstream, iB, thresh, inv_keep);
+      }
+      const float dsA = pA * (dpA * mkA - delta_me) * scale;
+      const float dsB = pB * (dpB * mkB - delta_j) * scale;
+      const float pmB = pB * mkB;
+#pragma unroll
+      for (int i = 0; i < DL; ++i) { dqv[i] += dsA * kj[i]; dk[i] += dsB * qj[i]; dv[i] += pmB * gj[i]; }
+    }
+    storev<T, DL>(dbase, dqv);
+    storev<T, DL>(dbase + C, dk);
+    storev<T, DL>(dbase + 2 * C, dv);
+  }
+#undef TG_RED
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -200,9 +287,16 @@ template <typename T, int D> static void launch_fwd(const AttnArgs& a) {
                      a.H, a.scale, a.thresh, a.inv_keep, a.seed, a.rstream);
 }
 template <typename T, int D> static void launch_bwd(const AttnArgs& a) {
-  hipLaunchKernelGGL((k_attn_bwd<T, D>), dim3(a.grid), dim3(256), 0, a.st, (const T*)a.qkv, (const T*)a.o,
-                     (const T*)a.dout, (const float*)a.lse, (T*)a.dqkv, a.R, a.S, a.H, a.scale, a.thresh, a.inv_keep,
-                     a.seed, a.rstream);
+  if constexpr (D >= 16 && sizeof(T) == 2) {          // bf16, 16-byte lane slices: lane-split kernel
+    int grid = grid_cap(ceil_div(a.R * a.H * a.S * (D / 8), 256), 256 * 32);
+    hipLaunchKernelGGL((k_attn_bwd_split<T, D, 8>), dim3(grid), dim3(256), 0, a.st, (const T*)a.qkv, (const T*)a.o,
+                       (const T*)a.dout, (const float*)a.lse, (T*)a.dqkv, a.R, a.S, a.H, a.scale, a.thresh, a.inv_keep,
+                       a.seed, a.rstream);
+  } else {
+    hipLaunchKernelGGL((k_attn_bwd<T, D>), dim3(a.grid), dim3(256), 0, a.st, (const T*)a.qkv, (const T*)a.o,
+                       (const T*)a.dout, (const float*)a.lse, (T*)a.dqkv, a.R, a.S, a.H, a.scale, a.thresh, a.inv_keep,
+                       a.seed, a.rstream);
+  }
 }
 template <typename T> static int dispatch(const AttnArgs& a, int D, bool fwd) {
   switch (D) {
