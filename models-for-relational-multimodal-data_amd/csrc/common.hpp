@@ -134,6 +134,23 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned st
 __device__ __forceinline__ float drop_scale_key(unsigned key, unsigned lo, unsigned thresh, float inv_keep) {
   return mix32(lo ^ key) >= thresh ? inv_keep : 0.f;
 }
+// Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used on the path: on virtual-memory-managed
+// allocations (hipMemCreate/hipMemMap: the debug fence allocator of tools/guard_alloc.cpp, torch's expandable segments)
+// it was observed to run out of order with the kernels of the same stream.
+template <int UNUSED>
+__global__ void k_zero_words(unsigned* __restrict__ p, long long n) {
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = 0u;
+}
+inline void zero_async(void* p, size_t bytes, hipStream_t st) {      // bytes % 4 == 0
+  const long long n = (long long)(bytes / 4);
+  if (n == 0) return;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((k_zero_words<0>), dim3((unsigned)blocks), dim3(256), 0, st, (unsigned*)p, n);
+}
+
 inline unsigned drop_threshold(float p) {
   double t = (double)p * 4294967296.0;
   if (t < 0) t = 0;

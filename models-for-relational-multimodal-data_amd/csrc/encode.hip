@@ -395,7 +395,7 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
   if (check_desc(d, C, "tg_encode_bwd")) return 1;
   hipStream_t st = (hipStream_t)stream;
   if (R == 0) {
-    (void)hipMemsetAsync(dflat, 0, (size_t)acc_floats * sizeof(float), st);
+    zero_async(dflat, (size_t)acc_floats * sizeof(float), st);
     return 0;
   }
   if (d->nts < d->ncol) {

@@ -345,10 +345,7 @@ extern "C" int tg_csr_build(const int32_t* key, int64_t M, int32_t N, int32_t* r
   int* cursor = work;              // [N+1]
   int* tmp = work + n1;            // [M]
   int* totals = work + n1 + M;     // [nchunks]
-  if (hipMemsetAsync(rowptr, 0, n1 * sizeof(int), st) != hipSuccess) {
-    set_error("tg_csr_build: memset failed");
-    return 2;
-  }
+  zero_async(rowptr, (size_t)n1 * sizeof(int), st);
   if (M > 0) {
     hipLaunchKernelGGL(k_hist, dim3(grid_cap(ceil_div(M, 256))), dim3(256), 0, st, key, (long long)M, rowptr);
   }
@@ -358,10 +355,7 @@ extern "C" int tg_csr_build(const int32_t* key, int64_t M, int32_t N, int32_t* r
   if (M > 0) {
     hipLaunchKernelGGL(k_fill, dim3(grid_cap(ceil_div(M, 256))), dim3(256), 0, st, key, (long long)M, cursor, tmp);
     int* hub = totals + nchunks + 8;   // [2 + M / RANK_HUB]
-    if (hipMemsetAsync(hub, 0, sizeof(int), st) != hipSuccess) {
-      set_error("tg_csr_build: memset failed");
-      return 2;
-    }
+    zero_async(hub, sizeof(int), st);
     hipLaunchKernelGGL(k_rank, dim3(grid_cap(ceil_div(M, 256), 256 * 16)), dim3(256), 0, st, key, rowptr, tmp, perm,
                        (long long)M, hub);
     hipLaunchKernelGGL(k_rank_hub, dim3(128), dim3(1024), 0, st, rowptr, tmp, perm, (long long)M, hub);

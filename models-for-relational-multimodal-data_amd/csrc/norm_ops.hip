@@ -612,7 +612,7 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
   TG_CHECK(C % 8 == 0 && C <= 2048, "tg_ln_bwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    (void)hipMemsetAsync(dparams, 0, 3 * C * sizeof(float), st);
+    zero_async(dparams, 3 * (size_t)C * sizeof(float), st);
     return 0;
   }
   unsigned thresh = (b && p_drop > 0.f) ? drop_threshold(p_drop) : 0u;

@@ -540,10 +540,7 @@ extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, con
   TG_CHECK(F % 8 == 0 && offA % 8 == 0 && offB % 8 == 0 && gstride % 8 == 0, "tg_segment_sum2: misaligned F=%d", F);
   TG_CHECK(rpA && pmA && hub_work, "tg_segment_sum2: CSR A and hub workspace required");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(hub_work, 0, sizeof(int), st) != hipSuccess) {
-    set_error("tg_segment_sum2: memset failed");
-    return 2;
-  }
+  zero_async(hub_work, sizeof(int), st);
   DISPATCH_T(dt, {
     TG_CHECK(1024 % (F / VEC) == 0, "tg_segment_sum2: F/VEC must divide 1024 (F=%d)", F);
     long long total = (long long)N * (F / VEC);
