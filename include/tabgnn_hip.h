@@ -97,12 +97,17 @@ int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* ga
 int tg_bn_partials_floats(int64_t N, int32_t F);
 int tg_bn_act_res_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float* mean, float* rstd, void* out, float* partials, int64_t N, int32_t F,
-                      int32_t training, float momentum, float eps, int32_t relu, float alpha, float beta_c, int32_t dt,
-                      void* stream);
+                      int32_t training, float momentum, float eps, int32_t relu, float alpha, float beta_c,
+                      int64_t n_stat, int32_t phase, int32_t dt, void* stream);
+/* phase 0: everything (n_stat ignored).  Synchronised BatchNorm across data-parallel ranks (optional):
+ * phase 1 = local statistics only -> (sum x, sum x^2) at partials + 512*2*F, which the caller all-reduces in place;
+ * phase 2 = finalize with n_stat = rows of ALL ranks (running statistics updated from the global batch) + apply.
+ * Backward: phase 1 = local (sum dz, sum dz*xhat) -> dparams, caller all-reduces a COPY (the parameter gradients stay
+ * local sums, the data-parallel all-reduce averages them as usual); phase 2 = dx from the global sums and n_stat. */
 int tg_bn_act_res_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* mean,
                       const float* rstd, void* dx, void* dres, float* dparams /*[2F]: dbeta,dgamma*/, float* partials,
-                      int64_t N, int32_t F, int32_t training, int32_t relu, float alpha, float beta_c, int32_t dt,
-                      void* stream);
+                      int64_t N, int32_t F, int32_t training, int32_t relu, float alpha, float beta_c, int64_t n_stat,
+                      int32_t phase, int32_t dt, void* stream);
 
 /* ---- activation + dropout after a Linear (encoder FFN; fuse MLP fused.py:224-231; heads decoder.py:14-15)
  *      act: 0 none, 1 relu, 2 leaky_relu(0.01) ------------------------------------------------------------ */

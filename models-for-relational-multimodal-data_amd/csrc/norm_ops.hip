@@ -374,13 +374,13 @@ template <typename T, int VEC>
 __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ dout, const float* __restrict__ mean,
                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ sums /*[2][F]*/,
-                               T* __restrict__ dx, T* __restrict__ dres, long long N, int F, int relu, int training,
-                               float alpha, float beta_c) {
+                               T* __restrict__ dx, T* __restrict__ dres, long long N, long long n_stat, int F, int relu,
+                               int training, float alpha, float beta_c) {
   const int vpr = F / VEC;
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
   long long total = N * vpr;
-  float invN = 1.f / (float)N;
+  float invN = 1.f / (float)n_stat;
   // per-channel parameters in registers (a thread keeps its channel vector across the loop: 256 % vpr == 0)
   const int c = (int)(i % vpr) * VEC;
   float mu[VEC], rs[VEC], gm[VEC], bt[VEC], m1[VEC], m2[VEC];
@@ -641,20 +641,29 @@ extern "C" int tg_bn_partials_floats(int64_t N, int32_t F) { return 513 * 2 * F;
 extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float* mean, float* rstd, void* out,
                                  float* partials, int64_t N, int32_t F, int32_t training, float momentum, float eps,
-                                 int32_t relu, float alpha, float beta_c, int32_t dt, void* stream) {
+                                 int32_t relu, float alpha, float beta_c, int64_t n_stat, int32_t phase, int32_t dt,
+                                 void* stream) {
   TG_CHECK(F % 8 == 0 && F <= 1024 && N > 0, "tg_bn_act_res_fwd: bad F=%d N=%lld", F, (long long)N);
+  TG_CHECK(phase >= 0 && phase <= 2 && (phase == 0 || training), "tg_bn_act_res_fwd: bad phase %d", phase);
   hipStream_t st = (hipStream_t)stream;
+  if (n_stat <= 0 || phase == 0) n_stat = N;
   DISPATCH_T(dt, {
     TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_fwd: F/VEC must divide 256 (F=%d)", F);
+    float* sums = partials + (size_t)512 * 2 * F;      // (sum x, sum x^2): the vector a synchronised BN all-reduces
     if (training) {
-      int groups = 256 / (F / VEC);
-      int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
-      size_t shm = (size_t)groups * 2 * F * sizeof(float);
-      hipLaunchKernelGGL((k_col_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)nullptr,
-                         (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, partials, (long long)N, F, 0);
-      float* sums = partials + (size_t)512 * 2 * F;
-      hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, sums);
-      hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, st, sums, 1, (long long)N, F, eps,
+      if (phase != 2) {
+        int groups = 256 / (F / VEC);
+        int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
+        size_t shm = (size_t)groups * 2 * F * sizeof(float);
+        hipLaunchKernelGGL((k_col_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, partials, (long long)N, F, 0);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, sums);
+      }
+      if (phase == 1) {
+        TG_LAUNCH_CHECK();
+        return 0;
+      }
+      hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, st, sums, 1, (long long)n_stat, F, eps,
                          momentum, mean, rstd, running_mean, running_var);
     } else {
       hipLaunchKernelGGL(k_bn_eval_stats, dim3(ceil_div(F, 256)), dim3(256), 0, st, running_mean, running_var, F, eps,
@@ -672,21 +681,27 @@ extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* ga
 extern "C" int tg_bn_act_res_bwd(const void* x, const void* dout, const float* gamma, const float* beta,
                                  const float* mean, const float* rstd, void* dx, void* dres, float* dparams,
                                  float* partials, int64_t N, int32_t F, int32_t training, int32_t relu, float alpha,
-                                 float beta_c, int32_t dt, void* stream) {
+                                 float beta_c, int64_t n_stat, int32_t phase, int32_t dt, void* stream) {
   TG_CHECK(F % 8 == 0 && F <= 1024 && N > 0, "tg_bn_act_res_bwd: bad F=%d N=%lld", F, (long long)N);
+  TG_CHECK(phase >= 0 && phase <= 2, "tg_bn_act_res_bwd: bad phase %d", phase);
   hipStream_t st = (hipStream_t)stream;
+  if (n_stat <= 0 || phase == 0) n_stat = N;
   DISPATCH_T(dt, {
     TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_bwd: F/VEC must divide 256 (F=%d)", F);
-    int groups = 256 / (F / VEC);
-    int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
-    size_t shm = (size_t)groups * 2 * F * sizeof(float);
-    hipLaunchKernelGGL((k_bn_bwd_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)dout, mean,
-                       rstd, gamma, beta, partials, (long long)N, F, relu, beta_c);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, dparams);
-    long long total = (long long)N * (F / VEC);
-    hipLaunchKernelGGL((k_bn_bwd_apply<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, st, (const T*)x,
-                       (const T*)dout, mean, rstd, gamma, beta, dparams, (T*)dx, (T*)dres, (long long)N, F, relu,
-                       training, alpha, beta_c);
+    if (phase != 2) {
+      int groups = 256 / (F / VEC);
+      int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
+      size_t shm = (size_t)groups * 2 * F * sizeof(float);
+      hipLaunchKernelGGL((k_bn_bwd_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)dout, mean,
+                         rstd, gamma, beta, partials, (long long)N, F, relu, beta_c);
+      hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, dparams);
+    }
+    if (phase != 1) {    // the statistics terms divide by the number of rows behind dparams (all ranks when synchronised)
+      long long total = (long long)N * (F / VEC);
+      hipLaunchKernelGGL((k_bn_bwd_apply<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, st, (const T*)x,
+                         (const T*)dout, mean, rstd, gamma, beta, dparams, (T*)dx, (T*)dres, (long long)N,
+                         (long long)n_stat, F, relu, training, alpha, beta_c);
+    }
   })
   TG_LAUNCH_CHECK();
   return 0;

@@ -37,9 +37,9 @@ SIGNATURES = {
                   _i32, _i32, _vp],
     "tg_bn_partials_floats": [_i64, _i32],
     "tg_bn_act_res_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _i32, _f32,
-                          _f32, _i32, _vp],
-    "tg_bn_act_res_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _i32,
-                          _vp],
+                          _f32, _i64, _i32, _i32, _vp],
+    "tg_bn_act_res_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _i64,
+                          _i32, _i32, _vp],
     "tg_act_dropout_fwd": [_vp, _vp, _i64, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_act_dropout_bwd": [_vp, _vp, _vp, _i64, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_axpby": [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp],

@@ -86,6 +86,7 @@ class BatchNorm(nn.Module):
     def __init__(self, in_channels, eps=1e-5, momentum=0.1):
         super().__init__()
         self.module = nn.BatchNorm1d(in_channels, eps, momentum)
+        self.sync_group = None      # set by train.DataParallel(sync_batchnorm=True): batch statistics over all ranks
 
     def reset_parameters(self):
         self.module.reset_parameters()
@@ -94,7 +95,8 @@ class BatchNorm(nn.Module):
         m = self.module
         training = self.training and x.shape[0] > 1
         out = ops.batch_norm_act_res(x, m.weight, m.bias, m.running_mean, m.running_var, training, res=res,
-                                     momentum=m.momentum, eps=m.eps, relu=relu, alpha=alpha, beta_c=beta_c)
+                                     momentum=m.momentum, eps=m.eps, relu=relu, alpha=alpha, beta_c=beta_c,
+                                     group=self.sync_group if training else None)
         if training:
             m.num_batches_tracked += 1
         return out

@@ -351,42 +351,64 @@ def layer_norm(a, gamma, beta, b=None, bias_b=None, res=None, eps=1e-5, alpha=0.
 
 
 class _BatchNormActRes(torch.autograd.Function):
-    """out = alpha*res + beta_c*relu(BN(x)); updates running statistics in training mode."""
+    """out = alpha*res + beta_c*relu(BN(x)); updates running statistics in training mode.  ``group`` (a
+    torch.distributed process group, training only) synchronises the batch statistics across its ranks: the
+    [2F]+1 vector (sum x, sum x^2, rows) is all-reduced between the statistics and the apply kernels, and the
+    backward does the same with (sum dz, sum dz*xhat)  (optional SyncBatchNorm)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, alpha, beta_c):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, alpha, beta_c, group):
         x = x.contiguous()
         N, F = x.shape
         res = res.contiguous() if res is not None else None
         out = torch.empty_like(x)
         mean = torch.empty(F, dtype=torch.float32, device=x.device)
         rstd = torch.empty(F, dtype=torch.float32, device=x.device)
-        partials = _workspace(L.load().tg_bn_partials_floats(N, F), x.device)
-        L.call("tg_bn_act_res_fwd", L.ptr(x), L.ptr(res), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean),
-               L.ptr(running_var), L.ptr(mean), L.ptr(rstd), L.ptr(out), L.ptr(partials), N, F, int(training), momentum,
-               eps, int(relu), alpha, beta_c, L.dt(x), L.stream())
+        partials = _workspace(L.load().tg_bn_partials_floats(N, F) + 8, x.device)
+        args = (L.ptr(x), L.ptr(res), L.ptr(gamma), L.ptr(beta), L.ptr(running_mean), L.ptr(running_var), L.ptr(mean),
+                L.ptr(rstd), L.ptr(out), L.ptr(partials), N, F, int(training), momentum, eps, int(relu), alpha, beta_c)
+        sync = bool(training) and group is not None
+        n_stat = N
+        if sync:
+            import torch.distributed as dist
+            L.call("tg_bn_act_res_fwd", *args, 0, 1, L.dt(x), L.stream())
+            vec = partials[512 * 2 * F:512 * 2 * F + 2 * F + 1]      # (sum x, sum x^2) + one slot for the row count
+            vec[2 * F] = float(N)
+            dist.all_reduce(vec, group=group)
+            n_stat = int(round(float(vec[2 * F])))
+            L.call("tg_bn_act_res_fwd", *args, n_stat, 2, L.dt(x), L.stream())
+        else:
+            L.call("tg_bn_act_res_fwd", *args, 0, 0, L.dt(x), L.stream())
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
-        ctx.cfg = (N, F, int(training), int(relu), alpha, beta_c, res is not None)
+        ctx.cfg = (N, F, int(training), int(relu), alpha, beta_c, res is not None, group if sync else None, n_stat)
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
-        N, F, training, relu, alpha, beta_c, has_res = ctx.cfg
+        N, F, training, relu, alpha, beta_c, has_res, group, n_stat = ctx.cfg
         g = g.contiguous()
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
         dparams = torch.empty(2, F, dtype=torch.float32, device=x.device)
         partials = _workspace(L.load().tg_bn_partials_floats(N, F), x.device)
-        L.call("tg_bn_act_res_bwd", L.ptr(x), L.ptr(g), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dx),
-               L.ptr(dres), L.ptr(dparams), L.ptr(partials), N, F, training, relu, alpha, beta_c, L.dt(x), L.stream())
-        return dx, dres, dparams[1], dparams[0], None, None, None, None, None, None, None, None
+        head = (L.ptr(x), L.ptr(g), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dres))
+        tail = (L.ptr(partials), N, F, training, relu, alpha, beta_c)
+        if group is not None:
+            import torch.distributed as dist
+            L.call("tg_bn_act_res_bwd", *head, L.ptr(dparams), *tail, 0, 1, L.dt(x), L.stream())
+            glob = dparams.clone()                 # parameter gradients stay LOCAL sums (the DP all-reduce averages them)
+            dist.all_reduce(glob, group=group)
+            L.call("tg_bn_act_res_bwd", *head, L.ptr(glob), *tail, n_stat, 2, L.dt(x), L.stream())
+        else:
+            L.call("tg_bn_act_res_bwd", *head, L.ptr(dparams), *tail, 0, 0, L.dt(x), L.stream())
+        return dx, dres, dparams[1], dparams[0], None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act_res(x, gamma, beta, running_mean, running_var, training, res=None, momentum=0.1, eps=1e-5,
-                       relu=True, alpha=0.0, beta_c=1.0):
+                       relu=True, alpha=0.0, beta_c=1.0, group=None):
     return _BatchNormActRes.apply(x, res, gamma, beta, running_mean, running_var, bool(training), float(momentum),
-                                  float(eps), bool(relu), float(alpha), float(beta_c))
+                                  float(eps), bool(relu), float(alpha), float(beta_c), group)
 
 
 # --------------------------------------------------------------------------- activation + dropout, axpby

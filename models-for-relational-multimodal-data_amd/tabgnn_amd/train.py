@@ -80,7 +80,10 @@ class FusedAdam:
 class DataParallel:
     """Gradient-averaging data parallelism over independently sampled mini-batches."""
 
-    def __init__(self, module, flat: FlatParams, bucket_mb=32, sync_buffers=True):
+    def __init__(self, module, flat: FlatParams, bucket_mb=32, sync_buffers=True, sync_batchnorm=False):
+        """``sync_batchnorm``: BatchNorm statistics over the batches of ALL ranks (optional; default is the
+        DDP convention of per-rank statistics): every ``layers.BatchNorm`` all-reduces its [2F+1] statistics vector
+        in the forward and its [2F] gradient-statistics vector in the backward."""
         self.module, self.flat = module, flat
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket = int(bucket_mb * (1 << 20) // 4)
@@ -95,6 +98,11 @@ class DataParallel:
                 for b in module.buffers():
                     dist.broadcast(b, src=0)
             flat.refresh_shadow()
+        if sync_batchnorm and dist.is_initialized() and dist.get_world_size() > 1:
+            from .layers import BatchNorm
+            for m in module.modules():
+                if isinstance(m, BatchNorm):
+                    m.sync_group = dist.group.WORLD
 
     def all_reduce_grads(self):
         """Sum over ranks, bucketed (async, in flight together); the 1/world factor is folded into the optimiser."""
