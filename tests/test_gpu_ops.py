@@ -318,3 +318,32 @@ def test_seed_pool_inplace_equals_out_of_place(T, dtype):
         assert torch.equal(a, b)
     touched = torch.zeros(N, dtype=torch.bool); touched[tei.flatten()] = True
     assert torch.equal(outs[1][0][~touched.to(DEV)], x0[~touched.to(DEV)])          # other rows untouched
+
+
+@pytest.mark.parametrize("C,H,dtype,p", [(128, 4, torch.bfloat16, 0.3), (128, 4, torch.float32, 0.3), (32, 8, torch.float32, 0.0)])
+def test_encoder_layer_composite_equals_op_by_op_composition(T, C, H, dtype, p):
+    """The one-node encoder layer (hand-scheduled backward; in bf16 at C = 128: MFMA NT GEMMs with fused ReLU+dropout
+    and gate epilogues, in-kernel weight-gradient accumulation) against the op-by-op composition of the single
+    operators — same dropout streams (same site order), so forward, input gradient and parameter gradients agree."""
+    torch.manual_seed(1)
+    R, S = 700, 6
+    layer = T.ColumnTransformerLayer(C, H, dropout=p).to(DEV).train()
+    x0 = torch.randn(R, S, C, device=DEV).to(dtype)
+    go = torch.randn(R, S, C, device=DEV).to(dtype)
+    res = []
+    for fused in (True, False):
+        for q in layer.parameters():
+            q.grad = None
+        if dtype == torch.bfloat16:
+            for q in layer.parameters():
+                q._lp = q.detach().to(dtype)
+        T.ops.DropoutRNG.new_step(77)
+        x = x0.clone().requires_grad_(True)
+        y = layer(x) if fused else layer.forward_unfused(x)
+        y.backward(go)
+        res.append((y.detach().float(), x.grad.float(), {k: q.grad.float().clone() for k, q in layer.named_parameters()}))
+    tol = 0.06 if dtype == torch.bfloat16 else 2e-4
+    (y1, g1, p1), (y2, g2, p2) = res
+    assert (y1 - y2).abs().max().item() < tol and (g1 - g2).abs().max().item() < tol * max(1.0, g2.abs().max().item())
+    for k in p1:
+        assert (p1[k] - p2[k]).abs().max().item() < tol * max(1.0, p2[k].abs().max().item()), k
