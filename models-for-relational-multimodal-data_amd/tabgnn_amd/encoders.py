@@ -90,21 +90,32 @@ class _Encode(torch.autograd.Function):
         R = next(iter(feats.values())).shape[0]
         dev = next(iter(feats.values())).device
         Cc = enc.out_channels
-        out = torch.empty(R, plan["ncols"], Cc, dtype=out_dtype, device=dev)
+        # The rows are written into columns 1.. of a [R, ncols+1, C] buffer and returned as that view: the backbones
+        # prepend a CLS token to every encoded row (fused.py:158-163, tabgnn.py:120-125), which then is a write into
+        # the free column 0 instead of a copy of the whole tensor (models.prepend_cls); same contract
+        # ``[R, ncols, C]`` for every other consumer (a strided view).
+        S = plan["ncols"] + 1
+        buf = torch.empty(R, S, Cc, dtype=out_dtype, device=dev)
+        out = buf[:, 1:, :]
         ptrs = enc._ptrs(feats, params)
         for desc in plan["descs"]:
-            L.call("tg_encode_fwd", C.addressof(desc), C.addressof(ptrs), L.ptr(out), R, plan["ncols"], Cc,
-                   L.dt(out), L.stream())
+            L.call("tg_encode_fwd", C.addressof(desc), C.addressof(ptrs), out.data_ptr(), R, S, Cc, L.dt(out), L.stream())
         ctx.enc, ctx.feats, ctx.params, ctx.R = enc, feats, params, R
+        out._cls_base = buf
         return out
 
     @staticmethod
     def backward(ctx, g):
         enc, feats, params, R = ctx.enc, ctx.feats, ctx.params, ctx.R
         plan = enc._plan
-        g = g.contiguous()
-        dev = g.device
         Cc = enc.out_channels
+        # the gradient of a CLS-prepended tensor arrives as the [:, 1:, :] view of a [R, ncols+1, C] tensor: read in place
+        row_cols = plan["ncols"]
+        if g.dim() == 3 and g.stride() == ((row_cols + 1) * Cc, Cc, 1) and g.data_ptr() % 16 == 0:
+            row_cols += 1
+        else:
+            g = g.contiguous()
+        dev = g.device
         ptrs = enc._ptrs(feats, params)
         num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b = params
         grads = [None if p is None else torch.zeros_like(p) for p in params]
@@ -112,7 +123,7 @@ class _Encode(torch.autograd.Function):
         for desc, acc_floats, segs in zip(plan["descs"], plan["acc_floats"], plan["segments"]):
             dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
             partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
-            L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), L.ptr(g), R, plan["ncols"], Cc, acc_floats,
+            L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), g.data_ptr(), R, row_cols, Cc, acc_floats,
                    L.ptr(dflat), L.ptr(partials), L.ptr(grads[2]), L.dt(g), L.stream())
             for kind, src_col, off, rows, tab_off in segs:
                 if kind == 0:

@@ -32,11 +32,20 @@ def _xavier_matrices(module):
 
 
 class _PrependCLS(torch.autograd.Function):
-    """[cls | row] per table row (fused.py:158-159,162-163) without a broadcast temp: one gather-concat launch."""
+    """[cls | row] per table row (fused.py:158-159,162-163).  Rows that come from the stype encoder sit in columns 1..
+    of a [R, ncols+1, C] buffer (``encoders._Encode``): the CLS vector is then written into column 0 and the buffer
+    itself is the result — no copy; otherwise one gather-concat launch builds the tensor."""
 
     @staticmethod
     def forward(ctx, cls, rows):
         R, ncols, C = rows.shape
+        ctx.C = C
+        base = getattr(rows, "_cls_base", None)
+        if (base is not None and base.shape == (R, ncols + 1, C) and base.is_contiguous() and base.dtype == rows.dtype
+                and rows.data_ptr() == base.data_ptr() + C * rows.element_size()):
+            base[:, 0, :] = cls.detach().to(rows.dtype)
+            rows._cls_base = None                      # the slot is taken: a second prepend of the same rows must copy
+            return base
         rows = rows.contiguous()
         c = cls.detach().to(rows.dtype).contiguous().view(1, C)
         flat = rows.view(R, ncols * C)
@@ -44,14 +53,12 @@ class _PrependCLS(torch.autograd.Function):
         from . import _lib as L
         L.call("tg_gather_concat3", c.data_ptr(), None, 0, C, 0, flat.data_ptr(), None, ncols * C, ncols * C, 0,
                flat.data_ptr(), None, ncols * C, 0, L.ptr(out), R, L.dt(out), L.stream())
-        ctx.C = C
         return out.view(R, ncols + 1, C)
 
     @staticmethod
     def backward(ctx, g):
-        C = ctx.C
         dcls = g[:, 0, :].sum(0, dtype=torch.float32)
-        return dcls, g[:, 1:, :].contiguous()
+        return dcls, g[:, 1:, :]           # a view: the encoder's backward reads it in place (no copy of [R,ncols,C])
 
 
 def prepend_cls(cls, rows):
