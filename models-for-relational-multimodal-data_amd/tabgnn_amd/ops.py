@@ -516,7 +516,7 @@ class _EdgeGather(torch.autograd.Function):
             de = _gather3([(tail, sv["inv"], ctx.We, 0), (tail, None, 0, 0), (tail, None, 0, 0)], g.shape[0], g.dtype,
                           g.device)
         else:
-            de = g[:, 2 * F:].contiguous()
+            de = g[:, 2 * F:]               # a view: autograd's accumulation reads it strided, no [E,F] copy
         return dx, de, None, None
 
 
