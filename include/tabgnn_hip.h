@@ -162,6 +162,13 @@ int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void*
                     int64_t R, int32_t N, int32_t K, int64_t ldx, int64_t ldy, int32_t flags, float p_drop, uint64_t seed,
                     uint32_t rstream, void* stream);
 
+/* GEMM + bias + dropout + residual + LayerNorm in one pass (out_proj -> norm1, linear2 -> norm2 of
+ * nn.TransformerEncoderLayer, fused.py:83-92), d_model = 128:  Z = res + drop(X W^T + bias)  (kept for the backward:
+ * tg_ln_bwd(a = Z, b = NULL, db != NULL) is its "z mode"),  OUT = LayerNorm(Z) * gamma + beta,  stats = (mean, rstd). */
+int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bias, const void* res, const float* gamma,
+                       const float* beta, void* Z, void* OUT, float* stats, int64_t R, int32_t K, int64_t ldx, float eps,
+                       float p_drop, uint64_t seed, uint32_t rstream, void* stream);
+
 /* ---- weight gradient of every Linear on the path (autograd of torch.nn.Linear in the reference):
  *      out[M,N] (fp32) = G[R,M]^T X[R,N], bf16 operands, split over row slabs, deterministic slab sum ------- */
 int64_t tg_gemm_tn_workspace_floats(int64_t R, int32_t M, int32_t N);

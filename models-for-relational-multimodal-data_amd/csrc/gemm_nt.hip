@@ -234,6 +234,133 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
   }
 }
 
+// GEMM + bias + dropout + residual + LayerNorm in one pass (out_proj -> norm1 and linear2 -> norm2 of the column
+// transformer, fused.py:83-92):   z = res + drop(X W^T + bias),   out = LN(z) * gamma + beta.
+// N = 128 = d_model, so one workgroup's 128 x 128 tile holds whole rows: the accumulators (+bias, x mask) are restaged
+// as fp32 through the two dead LDS images (64 KiB, 16-byte chunks XOR-swizzled by row), then 16 lanes per row add the
+// residual, reduce mean / variance with xor-shuffles and write z (kept for the backward, which no longer needs the
+// GEMM output or the residual), out and the (mean, rstd) pair.  One pass less than GEMM -> y, LN(x, y) -> out in the
+// forward, one read less in the LayerNorm backward.
+__global__ void __launch_bounds__(256, 2) k_gemm_nt_ln_bf16(const unsigned short* __restrict__ X,
+                                                              const unsigned short* __restrict__ W,
+                                                              const float* __restrict__ bias,
+                                                              const unsigned short* __restrict__ res,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              unsigned short* __restrict__ Z, unsigned short* __restrict__ OUT,
+                                                              float* __restrict__ stats, long long R, int K,
+                                                              long long ldx, float eps, unsigned thresh, float inv_keep,
+                                                              unsigned long long seed, unsigned rstream) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * NT_TILE_BYTES];
+  char* xs = lds;
+  char* ws = lds + NT_TILE_BYTES;
+  const int N = NT_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long row_tile = blockIdx.x;
+  if (row_tile * NT_BM >= R) return;
+  const int n0 = 0;
+  const long long r0 = row_tile * NT_BM;
+  const int wn = wave >> 1, wr = wave & 1;
+  nt_f32x16 acc[2][2];
+  NT_ZERO_ACC()
+  uint4 rx0, rx1, rx2, rx3, rx4, rx5, rx6, rx7, rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7;
+  const long long rlast = R - 1;
+  const int st_row = tid >> 4, st_ch = tid & 15;
+  float bv[2][4][4];
+  NT_LOAD_BIAS(n0)
+  NT_LOADX(0)
+  NT_LOADW(n0, 0)
+  int k0 = 0;
+  for (; k0 + NT_BK < K; k0 += NT_BK) {
+    NT_STOREX()
+    NT_STOREW()
+    __syncthreads();
+    NT_LOADX(k0 + NT_BK)
+    NT_LOADW(n0, k0 + NT_BK)
+    NT_MFMA_CHUNK()
+    __syncthreads();
+  }
+  NT_STOREX()
+  NT_STOREW()
+  __syncthreads();
+  NT_MFMA_CHUNK()
+  __syncthreads();
+  // fp32 restage: row rl, 16-byte chunk c (4 floats) at 512*rl + 16*(c ^ (rl & 31))
+  float* ob = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int rl = wr * 64 + b * 32 + (lane & 31);
+      const long long r = r0 + rl;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5);
+        const unsigned long long e0 = (unsigned long long)(r * (long long)N + nl);
+        const unsigned key = rng_key(seed, rstream, (unsigned)(e0 >> 32));
+        float4 v;
+        float* pv = &v.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = acc[a][b][4 * g + j] + bv[a][g][j];
+          if (thresh) u *= drop_scale_key(key, (unsigned)e0 + j, thresh, inv_keep);
+          pv[j] = u;
+        }
+        *reinterpret_cast<float4*>(ob + 128 * rl + 4 * ((nl >> 2) ^ (rl & 31))) = v;
+      }
+    }
+  __syncthreads();
+  // 16 lanes per row, 8 channels per lane (channels 8*ch .. 8*ch+7)
+  float gm[8], bt[8];
+  {
+    const int ch = tid & 15;
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + ch * 8), b1 = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
+    gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+    bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int piece = tid + 256 * p, row = piece >> 4, ch = piece & 15;
+    const long long r = r0 + row;
+    const long long rc = r < R ? r : R - 1;                       // clamped: every lane takes part in the shuffles
+    const float4 u0 = *reinterpret_cast<const float4*>(ob + 128 * row + 4 * ((2 * ch) ^ (row & 31)));
+    const float4 u1 = *reinterpret_cast<const float4*>(ob + 128 * row + 4 * ((2 * ch + 1) ^ (row & 31)));
+    const uint4 rv = *reinterpret_cast<const uint4*>(res + rc * N + ch * 8);
+    const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+    float z[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      z[2 * j] += __uint_as_float(rw[j] << 16);
+      z[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u);
+      s += z[2 * j] + z[2 * j + 1];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mu = s * (1.f / 128.f);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const float rstd = rsqrtf(v * (1.f / 128.f) + eps);
+    if (r < R) {
+      unsigned zw[4], ow[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y0 = (z[2 * j] - mu) * rstd * gm[2 * j] + bt[2 * j];
+        const float y1 = (z[2 * j + 1] - mu) * rstd * gm[2 * j + 1] + bt[2 * j + 1];
+        zw[j] = (unsigned)f2bf(z[2 * j]) | ((unsigned)f2bf(z[2 * j + 1]) << 16);
+        ow[j] = (unsigned)f2bf(y0) | ((unsigned)f2bf(y1) << 16);
+      }
+      *reinterpret_cast<uint4*>(Z + r * N + ch * 8) = make_uint4(zw[0], zw[1], zw[2], zw[3]);
+      *reinterpret_cast<uint4*>(OUT + r * N + ch * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      if (ch == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
+    }
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -276,6 +403,30 @@ extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, 
                        (unsigned short*)Y, (long long)R, N, K, (long long)ldx, (long long)ldy, flags, thresh, inv_keep,
                        (unsigned long long)seed, rstream);
   }
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// z = res + drop(X W^T + bias) (bf16, kept for the backward), out = LayerNorm(z) * gamma + beta, stats = (mean, rstd)
+// per row.  N = d_model = 128; K % 128 == 0; res, Z, OUT contiguous [R,128].
+extern "C" int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bias, const void* res, const float* gamma,
+                                  const float* beta, void* Z, void* OUT, float* stats, int64_t R, int32_t K, int64_t ldx,
+                                  float eps, float p_drop, uint64_t seed, uint32_t rstream, void* stream) {
+  TG_CHECK(R > 0 && K > 0 && K % NT_BK == 0 && ldx % 8 == 0 && ldx >= K, "tg_gemm_nt_ln_bf16: bad shape R=%lld K=%d",
+           (long long)R, K);
+  TG_CHECK(X && W && res && gamma && beta && Z && OUT && stats, "tg_gemm_nt_ln_bf16: null operand");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(res) |
+             reinterpret_cast<uintptr_t>(Z) | reinterpret_cast<uintptr_t>(OUT) | reinterpret_cast<uintptr_t>(gamma) |
+             reinterpret_cast<uintptr_t>(beta)) & 15) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0),
+           "tg_gemm_nt_ln_bf16: operands must be 16-byte aligned");
+  unsigned thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  const long long row_tiles = (R + NT_BM - 1) / NT_BM;
+  TG_CHECK(row_tiles <= 2147483647LL, "tg_gemm_nt_ln_bf16: too many tiles");
+  hipLaunchKernelGGL(k_gemm_nt_ln_bf16, dim3((unsigned)row_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)res, gamma, beta,
+                     (unsigned short*)Z, (unsigned short*)OUT, stats, (long long)R, K, (long long)ldx, eps, thresh,
+                     inv_keep, (unsigned long long)seed, rstream);
   TG_LAUNCH_CHECK();
   return 0;
 }

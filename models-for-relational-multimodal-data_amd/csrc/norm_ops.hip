@@ -142,9 +142,13 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
         int c = vi * VEC;
         float x[VEC], g[VEC];
         loadv<T, VEC>(a + row * C + c, x);
-        if (b) {
+        // b == NULL with db given ("z mode"): a already IS the pre-norm sum z = a0 + drop(b + bias) written by the
+        // fused GEMM+LayerNorm forward; only the mask is needed, for db = da * mask
+        if (b || db) {
           float t[VEC];
-          loadv<T, VEC>(b + row * C + c, t);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) t[j] = 0.f;
+          if (b) loadv<T, VEC>(b + row * C + c, t);
           const unsigned long long e0 = (unsigned long long)(row * C + c);
           const unsigned key = rng_key(seed, rstream, (unsigned)(e0 >> 32));
 #pragma unroll
@@ -152,7 +156,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
             float m = drop_scale_key(key, (unsigned)e0 + j, thresh, inv_keep);
             m = thresh ? m : 1.f;
             msk[k][j] = m;
-            x[j] += (t[j] + bsr[k][j]) * m;
+            if (b) x[j] += (t[j] + bsr[k][j]) * m;
           }
         }
         loadv<T, VEC>(dout + row * C + c, g);
@@ -193,7 +197,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
         } else {
           storev<T, VEC>(da + row * C + c, d);
         }
-        if (b) {
+        if (b || db) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) { d[j] *= msk[k][j]; dbs[k][j] += d[j]; }
           storev<T, VEC>(db + row * C + c, d);
@@ -615,7 +619,7 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
     zero_async(dparams, 3 * (size_t)C * sizeof(float), st);
     return 0;
   }
-  unsigned thresh = (b && p_drop > 0.f) ? drop_threshold(p_drop) : 0u;
+  unsigned thresh = ((b || db) && p_drop > 0.f) ? drop_threshold(p_drop) : 0u;
   float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   int grid = 1;
   DISPATCH_T(dt, {

@@ -58,6 +58,7 @@ SIGNATURES = {
     "tg_gemm_tn_workspace_floats": [_i64, _i32, _i32],
     "tg_gemm_nt_supported": [_i64, _i32, _i32],
     "tg_gemm_nt_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _f32, _u64, _u32, _vp],
+    "tg_gemm_nt_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _u64, _u32, _vp],
     "tg_gemm_tn_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
     "tg_weighted_ce_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "tg_weighted_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],

@@ -61,8 +61,11 @@ class _EncoderLayerFn(torch.autograd.Function):
         o = torch.empty(T, C, dtype=dt, device=x.device)
         lse = torch.empty(R, nhead, S, dtype=torch.float32, device=x.device)
         L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, nhead, p, seed, rs[0], L.dt(x), L.stream())
-        y = ops.gemm_nt(o, lw_o) if nt else o @ lw_o.t()
-        x1, st1 = _ln_fwd(x2d, y, b_o, g1, be1, None, 0.0, 1.0, p, seed, rs[1])
+        if nt:      # out_proj + bias + dropout + residual + LayerNorm in one kernel; y := z1 (the pre-norm sum) is kept
+            y, x1, st1 = ops.gemm_nt_ln(o, lw_o, b_o.detach(), x2d, g1.detach(), be1.detach(), p, seed, rs[1])
+        else:
+            y = o @ lw_o.t()
+            x1, st1 = _ln_fwd(x2d, y, b_o, g1, be1, None, 0.0, 1.0, p, seed, rs[1])
         if nt:      # h = drop(relu(x1 W1^T + b1)) in one pass; the backward gates on h > 0 (kept AND active)
             h = ops.gemm_nt(x1, lw1, b1.detach(), ops.NT_RELU | ops.NT_DROPOUT, p, seed, rs[2])
             hpre = h
@@ -70,8 +73,11 @@ class _EncoderLayerFn(torch.autograd.Function):
             hpre = torch.addmm(lb1, x1, lw1.t())
             h = torch.empty_like(hpre)
             L.call("tg_act_dropout_fwd", L.ptr(hpre), L.ptr(h), hpre.numel(), 1, p, seed, rs[2], L.dt(x), L.stream())
-        y2 = ops.gemm_nt(h, lw2) if nt else h @ lw2.t()
-        x2, st2 = _ln_fwd(x1, y2, b2, g2, be2, None, 0.0, 1.0, p, seed, rs[3])
+        if nt:
+            y2, x2, st2 = ops.gemm_nt_ln(h, lw2, b2.detach(), x1, g2.detach(), be2.detach(), p, seed, rs[3])
+        else:
+            y2 = h @ lw2.t()
+            x2, st2 = _ln_fwd(x1, y2, b2, g2, be2, None, 0.0, 1.0, p, seed, rs[3])
         if tail:
             out, st3 = _ln_fwd(x2, None, None, gt, bt, x2d if alpha != 0.0 else None, alpha, beta_c, 0.0, 0, 0)
         else:
@@ -103,7 +109,10 @@ class _EncoderLayerFn(torch.autograd.Function):
             d_x2 = g
         # x2 = LN2(x1 + drop(y2 + b2))
         d_x1 = torch.empty_like(x1)
-        d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
+        if ctx.nt:  # y2 holds z2 = x1 + drop(h W2^T + b2): the LayerNorm backward's "z mode"
+            d_y2, dp2 = _ln_bwd(y2, None, None, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
+        else:
+            d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
         del d_x2
         dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
         nt = ctx.nt
@@ -126,11 +135,13 @@ class _EncoderLayerFn(torch.autograd.Function):
             d_x1.addmm_(d_hpre, lw1)
         del d_hpre
         # x1 = LN1(x + drop(y + b_o))
+        acc_dx = d_x is not None
         if d_x is None:
             d_x = torch.empty_like(x1)
-            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], False)
+        if ctx.nt:
+            d_y, dp1 = _ln_bwd(y, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx)
         else:
-            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], True)
+            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx)
         del d_x1
         dwo, _ = ops.weight_grad(d_y, o, False, p_o)
         d_o = ops.gemm_nt(d_y, lw_o.t()) if nt else d_y @ lw_o

