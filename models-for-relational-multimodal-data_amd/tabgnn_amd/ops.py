@@ -248,7 +248,7 @@ def weight_grad(g2, x2, want_bias=False, wparam=None, bparam=None):
     bg = _grad_target(bparam) if want_bias else None
     if wg is not None and wg.shape != (M, N):
         wg = None
-    if (g2.dtype == torch.bfloat16 and R >= 4096 and M % 8 == 0 and N % 8 == 0 and g2.stride(1) == 1
+    if (g2.dtype == torch.bfloat16 and R >= 64 and M % 8 == 0 and N % 8 == 0 and g2.stride(1) == 1
             and x2.stride(1) == 1 and g2.stride(0) % 8 == 0 and x2.stride(0) % 8 == 0
             and g2.data_ptr() % 16 == 0 and x2.data_ptr() % 16 == 0):
         acc = wg is not None and (not want_bias or bg is not None)
