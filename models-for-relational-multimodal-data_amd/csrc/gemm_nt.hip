@@ -283,6 +283,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_ln_bf16(const unsigned short
   NT_STOREX()
   NT_STOREW()
   __syncthreads();
+  // the residual rows of the epilogue are fetched now (the staging registers are free again): their latency hides
+  // under the last chunk's MFMAs instead of sitting in front of every row's reduction
+  {
+    const unsigned short* rb = res + st_ch * 8;
+#define NT_RES1(P, RX) { const long long r = r0 + st_row + 16 * (P); RX = *reinterpret_cast<const uint4*>(rb + (r < rlast ? r : rlast) * N); }
+    NT_RES1(0, rx0) NT_RES1(1, rx1) NT_RES1(2, rx2) NT_RES1(3, rx3) NT_RES1(4, rx4) NT_RES1(5, rx5) NT_RES1(6, rx6) NT_RES1(7, rx7)
+#undef NT_RES1
+  }
   NT_MFMA_CHUNK()
   __syncthreads();
   // fp32 restage: row rl, 16-byte chunk c (4 floats) at 512*rl + 16*(c ^ (rl & 31))
@@ -319,46 +327,47 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_ln_bf16(const unsigned short
     gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
     bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
   }
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int piece = tid + 256 * p, row = piece >> 4, ch = piece & 15;
-    const long long r = r0 + row;
-    const long long rc = r < R ? r : R - 1;                       // clamped: every lane takes part in the shuffles
-    const float4 u0 = *reinterpret_cast<const float4*>(ob + 128 * row + 4 * ((2 * ch) ^ (row & 31)));
-    const float4 u1 = *reinterpret_cast<const float4*>(ob + 128 * row + 4 * ((2 * ch + 1) ^ (row & 31)));
-    const uint4 rv = *reinterpret_cast<const uint4*>(res + rc * N + ch * 8);
-    const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
-    float z[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      z[2 * j] += __uint_as_float(rw[j] << 16);
-      z[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u);
-      s += z[2 * j] + z[2 * j + 1];
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mu = s * (1.f / 128.f);
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    const float rstd = rsqrtf(v * (1.f / 128.f) + eps);
-    if (r < R) {
-      unsigned zw[4], ow[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float y0 = (z[2 * j] - mu) * rstd * gm[2 * j] + bt[2 * j];
-        const float y1 = (z[2 * j + 1] - mu) * rstd * gm[2 * j + 1] + bt[2 * j + 1];
-        zw[j] = (unsigned)f2bf(z[2 * j]) | ((unsigned)f2bf(z[2 * j + 1]) << 16);
-        ow[j] = (unsigned)f2bf(y0) | ((unsigned)f2bf(y1) << 16);
-      }
-      *reinterpret_cast<uint4*>(Z + r * N + ch * 8) = make_uint4(zw[0], zw[1], zw[2], zw[3]);
-      *reinterpret_cast<uint4*>(OUT + r * N + ch * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-      if (ch == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }
-    }
+#define NT_LN_ROW(P, RV)                                                                              \
+  {                                                                                                   \
+    const int row = st_row + 16 * (P), ch = st_ch;                                                    \
+    const long long r = r0 + row;                                                                     \
+    const float4 u0 = *reinterpret_cast<const float4*>(ob + 128 * row + 4 * ((2 * ch) ^ (row & 31))); \
+    const float4 u1 = *reinterpret_cast<const float4*>(ob + 128 * row + 4 * ((2 * ch + 1) ^ (row & 31))); \
+    const unsigned rw[4] = {RV.x, RV.y, RV.z, RV.w};                                                  \
+    float z[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};                                    \
+    float s = 0.f;                                                                                    \
+    _Pragma("unroll")          \
+    for (int j = 0; j < 4; ++j) {                                                                     \
+      z[2 * j] += __uint_as_float(rw[j] << 16);                                                       \
+      z[2 * j + 1] += __uint_as_float(rw[j] & 0xffff0000u);                                           \
+      s += z[2 * j] + z[2 * j + 1];                                                                   \
+    }                                                                                                 \
+    _Pragma("unroll")          \
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);                                        \
+    const float mu = s * (1.f / 128.f);                                                               \
+    float v = 0.f;                                                                                    \
+    _Pragma("unroll")          \
+    for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }                            \
+    _Pragma("unroll")          \
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);                                        \
+    const float rstd = rsqrtf(v * (1.f / 128.f) + eps);                                               \
+    if (r < R) {                                                                                      \
+      unsigned zw[4], ow[4];                                                                          \
+    _Pragma("unroll")          \
+      for (int j = 0; j < 4; ++j) {                                                                   \
+        const float y0 = (z[2 * j] - mu) * rstd * gm[2 * j] + bt[2 * j];                              \
+        const float y1 = (z[2 * j + 1] - mu) * rstd * gm[2 * j + 1] + bt[2 * j + 1];                  \
+        zw[j] = (unsigned)f2bf(z[2 * j]) | ((unsigned)f2bf(z[2 * j + 1]) << 16);                      \
+        ow[j] = (unsigned)f2bf(y0) | ((unsigned)f2bf(y1) << 16);                                      \
+      }                                                                                               \
+      *reinterpret_cast<uint4*>(Z + r * N + ch * 8) = make_uint4(zw[0], zw[1], zw[2], zw[3]);         \
+      *reinterpret_cast<uint4*>(OUT + r * N + ch * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);       \
+      if (ch == 0) { stats[2 * r] = mu; stats[2 * r + 1] = rstd; }                                    \
+    }                                                                                                 \
   }
+  NT_LN_ROW(0, rx0) NT_LN_ROW(1, rx1) NT_LN_ROW(2, rx2) NT_LN_ROW(3, rx3)
+  NT_LN_ROW(4, rx4) NT_LN_ROW(5, rx5) NT_LN_ROW(6, rx6) NT_LN_ROW(7, rx7)
+#undef NT_LN_ROW
 }
 
 }  // namespace tg
