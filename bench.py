@@ -173,12 +173,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank control flow on ONE card (gpurun boxes have one GPU, RCCL refuses two ranks on one
+    # device): TABGNN_DIST_BACKEND=gloo TABGNN_ONE_DEVICE=1 python -m torch.distributed.run --nproc-per-node 2 bench.py
+    backend = os.environ.get("TABGNN_DIST_BACKEND", "nccl")
+    if os.environ.get("TABGNN_ONE_DEVICE") == "1":
+        local_rank = 0
     use_dist = world > 1 or os.environ.get("TABGNN_FORCE_ALLREDUCE") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")

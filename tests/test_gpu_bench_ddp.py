@@ -1,0 +1,32 @@
+"""GPU: rehearsal of bench.py's multi-rank control flow on the one card of a gpurun box — two ranks launched by
+torch.distributed.run exactly as the driver does, gloo instead of RCCL (RCCL refuses two ranks on one device), both on
+cuda:0: rank-0 broadcast, per-step gradient all-reduce of the flat buffer, barrier-bracketed timing, max/sum
+reductions of the results, ONE JSON line from rank 0."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_one_json_line():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, TABGNN_DIST_BACKEND="gloo", TABGNN_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch-size", "512"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                              # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["parallelism"] == "dp2" and d["value"] > 0
+    # whole-job aggregate: both ranks' edges over the max-over-ranks time
+    assert abs(d["value"] - 2 * d["config"]["edges_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
+    assert "cpu_baseline" not in d and "end_to_end" not in d            # rank 0 at N = 1 only

@@ -14,9 +14,10 @@ b = S.make_batch(bs, seed=1, device=dev)
 for _ in range(5):
     T.train_step(model, flat, opt, b, lw)
 torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)      # backward on this thread, so cProfile sees it
 pr = cProfile.Profile(); pr.enable()
 for _ in range(20):
     T.train_step(model, flat, opt, b, lw)
 torch.cuda.synchronize()
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(40)
