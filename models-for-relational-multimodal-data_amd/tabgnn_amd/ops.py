@@ -1,7 +1,7 @@
 """Autograd operators of the hot path: thin torch.autograd.Function shells around the C-ABI kernels.
 
 Every operator runs on the current HIP stream through ``_lib.call`` and raises if the library or a GPU
-is missing — there is no eager/CPU fallback.  Plain dense projections use torch's GEMM (hipBLASLt);
+is missing — there is no eager/CPU fallback.  Dense projections of the 128-wide shapes run on the hand-written MFMA GEMMs (gemm_nt / gemm_tn), the rest on torch's GEMM (hipBLASLt);
 everything else (gather, attention core, norms, aggregation, pooling, loss, optimiser) is a HIP kernel.
 """
 from __future__ import annotations
