@@ -257,7 +257,22 @@ __global__ void k_seed_pool_inplace(T* __restrict__ x, const T* __restrict__ xf,
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-    for (int qq = s; qq < e; ++qq) {
+    int qq = s;
+    for (; qq + 3 < e; qq += 4) {     // a hub endpoint is shared by hundreds of seed edges: four rows in flight
+      float t[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int slot = perm[qq + u];
+        int b = slot < B ? slot : slot - B;
+        int off = slot < B ? C : C + F;
+        loadv<T, VEC>(xf + (long long)b * D + off + c, t[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += t[u][j];
+    }
+    for (; qq < e; ++qq) {
       int slot = perm[qq];
       int b = slot < B ? slot : slot - B;
       int off = slot < B ? C : C + F;
