@@ -175,3 +175,26 @@ def test_full_size_properties_of_the_aggregation_path():
     (d2,) = torch.autograd.grad(out, x, g2, retain_graph=True)
     (d12,) = torch.autograd.grad(out, x, g1 + g2)
     assert torch.equal(d1 + d2, d12)                                              # linearity, exact on integers
+
+
+def test_bf16_eval_forward_is_deterministic_and_leaves_inputs_untouched():
+    """Inference (`main.py:104-155`: eval mode under no_grad) in bf16: two calls agree bit for bit, nothing in the
+    batch is modified (the in-place seed pooling works on an internal tensor), logits are finite."""
+    import copy
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    cfg = S.make_config(128, 2, 4, 256, compute_dtype=torch.bfloat16)
+    torch.manual_seed(0)
+    model = T.TABGNNFusedS(cfg).to(DEV)
+    batch = S.make_batch(256, seed=3, device=DEV)
+    keep = copy.deepcopy([batch[0].feat_dict, batch[1], batch[2].feat_dict])
+    model.train()
+    T.ops.DropoutRNG.new_step(1)
+    model(batch[0], batch[1], batch[2]).float().sum().backward()          # one training pass first (BN statistics)
+    model.eval()
+    with torch.no_grad():
+        a = model(batch[0], batch[1], batch[2])
+        b = model(batch[0], batch[1], batch[2])
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b) and a.shape == (256, 2)
+    assert all(torch.equal(v, keep[0][k]) for k, v in batch[0].feat_dict.items())
+    assert torch.equal(batch[1], keep[1]) and all(torch.equal(v, keep[2][k]) for k, v in batch[2].feat_dict.items())
