@@ -100,9 +100,8 @@ class FTTransformerPNAFusedLayer(nn.Module):
         conv = self.gnn_conv(x_gnn, g, edge_attr)
         x_gnn = self.gnn_norm(conv, res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
         # (e + MLP([x[src], x[dst], e])) / 2   (fused.py:253-254)
-        up0, up2 = self.gnn_edge_update[0], self.gnn_edge_update[2]
-        m = ops.act_dropout(ops.linear(ops.edge_gather(x_gnn, edge_attr, g, "src"), up0.weight, up0.bias), "relu", 0.0)
-        edge_attr = ops.axpby(edge_attr, ops.linear(m, up2.weight, up2.bias), 0.5, 0.5)
+        upd = ops.mlp_relu(ops.edge_gather(x_gnn, edge_attr, g, "src"), self.gnn_edge_update[0], self.gnn_edge_update[2])
+        edge_attr = ops.axpby(edge_attr, upd, 0.5, 0.5)
         if not lp:
             seeds = ops.SeedIndex(target_edge_index, N)
             f = self.fuse
@@ -215,9 +214,8 @@ class PNALayer(nn.Module):
     def forward(self, x_gnn, edge_index, edge_attr):                                        # tabgnn.py:187-191
         g = ops.SubgraphIndex.build(edge_index, x_gnn.shape[0])
         x_gnn = self.gnn_norm(self.gnn_conv(x_gnn, g, edge_attr), res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
-        up0, up2 = self.gnn_edge_update[0], self.gnn_edge_update[2]
-        m = ops.act_dropout(ops.linear(ops.edge_gather(x_gnn, edge_attr, g, "src"), up0.weight, up0.bias), "relu", 0.0)
-        return x_gnn, ops.axpby(edge_attr, ops.linear(m, up2.weight, up2.bias), 1.0, 0.5)  # e + MLP/2 (sic)
+        upd = ops.mlp_relu(ops.edge_gather(x_gnn, edge_attr, g, "src"), self.gnn_edge_update[0], self.gnn_edge_update[2])
+        return x_gnn, ops.axpby(edge_attr, upd, 1.0, 0.5)  # e + MLP/2 (sic)
 
 
 class TABGNN(nn.Module):
@@ -296,9 +294,8 @@ class FTTransformerPNAInterleavedLayer(nn.Module):
         edge_attr = self.tab_conv(edge_attr, self.tab_norm, 1.0, 0.5)          # e + LN(enc(e)) / 2   (sic, :217)
         cls = edge_attr[:, 0, :].contiguous()
         x_gnn = self.gnn_norm(self.gnn_conv(x_gnn, g, cls), res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
-        up0, up2 = self.gnn_edge_update[0], self.gnn_edge_update[2]
-        m = ops.act_dropout(ops.linear(ops.edge_gather(x_gnn, cls, g, "src"), up0.weight, up0.bias), "relu", 0.0)
-        cls = ops.axpby(cls, ops.linear(m, up2.weight, up2.bias), 0.5, 0.5)
+        upd = ops.mlp_relu(ops.edge_gather(x_gnn, cls, g, "src"), self.gnn_edge_update[0], self.gnn_edge_update[2])
+        cls = ops.axpby(cls, upd, 0.5, 0.5)
         return x_gnn, torch.cat([cls.unsqueeze(1), edge_attr[:, 1:, :]], dim=1)
 
 
@@ -386,7 +383,5 @@ class PNAS(nn.Module):
         for i in range(self.num_gnn_layers):
             x = self.batch_norms[i](self.convs[i](x, g, e), res=x, relu=True, alpha=0.5, beta_c=0.5)
             if self.edge_updates:
-                up0, up2 = self.emlps[i][0], self.emlps[i][2]
-                m = ops.act_dropout(ops.linear(ops.edge_gather(x, e, g, "src"), up0.weight, up0.bias), "relu", 0.0)
-                e = ops.axpby(e, ops.linear(m, up2.weight, up2.bias), 1.0, 0.5)
+                e = ops.axpby(e, ops.mlp_relu(ops.edge_gather(x, e, g, "src"), self.emlps[i][0], self.emlps[i][2]), 1.0, 0.5)
         return x, e

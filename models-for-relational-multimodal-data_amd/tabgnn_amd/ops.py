@@ -284,6 +284,52 @@ def linear(x, weight, bias=None):
     return _Linear.apply(x, weight, bias, shadow(weight, dtype), shadow(bias, dtype))
 
 
+class _MLPRelu(torch.autograd.Function):
+    """Linear -> ReLU -> Linear (the edge-update MLP ``gnn_edge_update``, fused.py:216-220 / tabgnn.py:174-178) as one
+    node on the MFMA GEMMs: ReLU in the first GEMM's epilogue (the pre-activation never exists), its backward as the
+    gate epilogue of the second layer's input-gradient GEMM, weight gradients accumulated in place."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2, lw0, lw2):
+        x2 = x.reshape(-1, x.shape[-1])
+        m = gemm_nt(x2, lw0, b0.detach(), NT_RELU)
+        y = gemm_nt(m, lw2, b2.detach())
+        ctx.save_for_backward(x2, m, lw0, lw2)
+        ctx.params = (w0, b0, w2, b2)
+        ctx.xshape = x.shape
+        return y.reshape(*x.shape[:-1], lw2.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, m, lw0, lw2 = ctx.saved_tensors
+        w0, b0, w2, b2 = ctx.params
+        isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
+        dw2, db2 = weight_grad(g2, m, True, isp(w2), isp(b2))
+        if db2 is None and dw2 is not None:
+            db2 = g2.sum(0, dtype=torch.float32)
+        d_pre = gemm_nt(g2, lw2.t(), None, NT_GATE, 0.0, gate=m)        # (g W2) where relu was active
+        dw0, db0 = weight_grad(d_pre, x2, True, isp(w0), isp(b0))
+        if db0 is None and dw0 is not None:
+            db0 = d_pre.sum(0, dtype=torch.float32)
+        dx = gemm_nt(d_pre, lw0.t()).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        return dx, dw0, db0, dw2, db2, None, None
+
+
+def mlp_relu(x, lin0, lin2):
+    """``lin2(relu(lin0(x)))`` for two ``nn.Linear`` modules; one fused node when the MFMA kernels take the shapes
+    (bf16, widths multiples of 128 with a 128-wide hidden layer), the op-by-op composition otherwise."""
+    x2 = x.reshape(-1, x.shape[-1])
+    H, K = lin0.weight.shape
+    N = lin2.weight.shape[0]
+    if (lin0.bias is not None and lin2.bias is not None and H == 128 and N == 128 and nt_ok(x2, H, K)
+            and x2.is_contiguous()):
+        dt = x.dtype
+        return _MLPRelu.apply(x, lin0.weight, lin0.bias, lin2.weight, lin2.bias, shadow(lin0.weight, dt),
+                              shadow(lin2.weight, dt))
+    return linear(act_dropout(linear(x, lin0.weight, lin0.bias), "relu", 0.0), lin2.weight, lin2.bias)
+
+
 # --------------------------------------------------------------------------- attention core
 
 
