@@ -385,3 +385,43 @@ class PNAS(nn.Module):
             if self.edge_updates:
                 e = ops.axpby(e, ops.mlp_relu(ops.edge_gather(x, e, g, "src"), self.emlps[i][0], self.emlps[i][2]), 1.0, 0.5)
         return x, e
+
+
+class CPNA(nn.Module):
+    """``CPNA`` (``src/nn/gnn/pna.py:150-219``), ``--model cpna``: one stack of L PNA layers per edge-table column, all
+    reading and updating the same node state; column c's embedding is updated by its own edge MLPs.  Parameter names
+    ``node_emb, col_convs.{c}.{i}, col_emlps.{c}.{i}, col_batch_norms.{c}.{i}``.  Returns a new ``[E, ncols, F]``
+    tensor where the reference writes the columns back into its argument."""
+
+    def __init__(self, num_features, num_gnn_layers, n_classes=2, n_hidden=128, edge_updates=True, edge_dim=None,
+                 dropout=0.0, final_dropout=0.5, deg=None, reverse_mp=False):
+        super().__init__()
+        self.n_hidden, self.num_gnn_layers, self.edge_updates = n_hidden, num_gnn_layers, edge_updates
+        self.final_dropout, self.reverse_mp = final_dropout, reverse_mp
+        self.num_cols = edge_dim // n_hidden
+        kw = dict(in_channels=n_hidden, out_channels=n_hidden, aggregators=["mean", "min", "max", "std"], scalers=_SCAL,
+                  deg=deg, edge_dim=n_hidden, towers=1, pre_layers=1, post_layers=1, divide_input=False)
+        self.node_emb = nn.Linear(num_features, n_hidden)
+        self.col_convs, self.col_emlps, self.col_batch_norms = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for _ in range(self.num_cols):
+            convs, emlps, bns = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+            for _ in range(num_gnn_layers):
+                convs.append(PNAConvHetero(n_hidden=n_hidden, **kw) if reverse_mp else PNAConv(**kw))
+                if edge_updates:
+                    emlps.append(nn.Sequential(nn.Linear(3 * n_hidden, n_hidden), nn.ReLU(), nn.Linear(n_hidden, n_hidden)))
+                bns.append(BatchNorm(n_hidden))
+            self.col_convs.append(convs); self.col_emlps.append(emlps); self.col_batch_norms.append(bns)
+
+    def forward(self, x, edge_index, edge_attr):
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        x = ops.linear(x.reshape(x.shape[0], -1), self.node_emb.weight, self.node_emb.bias)
+        cols = []
+        for c in range(self.num_cols):
+            col = edge_attr[:, c, :].contiguous()
+            for i in range(self.num_gnn_layers):
+                x = self.col_batch_norms[c][i](self.col_convs[c][i](x, g, col), res=x, relu=True, alpha=0.5, beta_c=0.5)
+                if self.edge_updates:
+                    mlp = self.col_emlps[c][i]
+                    col = ops.axpby(col, ops.mlp_relu(ops.edge_gather(x, col, g, "src"), mlp[0], mlp[2]), 1.0, 0.5)
+            cols.append(col)
+        return x, torch.stack(cols, dim=1)

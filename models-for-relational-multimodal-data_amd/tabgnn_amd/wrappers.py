@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .heads import ClassifierHead, NodeClassificationHead
-from .models import PNAS, TABGNN, TABGNNFused, TABGNNInterleaved
+from .models import CPNA, PNAS, TABGNN, TABGNNFused, TABGNNInterleaved
 
 
 def degree_histogram(in_degrees):
@@ -96,6 +96,8 @@ class TABGNNS(nn.Module):
         x, _ = self.node_encoder(x)
         edge_attr, _ = self.edge_encoder(edge_attr)
         x, edge_attr = self.model(x, edge_index, edge_attr)
+        if getattr(self, "cpna", False):
+            edge_attr = edge_attr.reshape(edge_attr.shape[0], -1)                            # utils.py:142-144
         if self.config["task"] == "edge_classification":
             bs = self.batch_size
             return self.decoder(x, edge_index[:, :bs].contiguous(), edge_attr[:bs].contiguous())
@@ -104,8 +106,10 @@ class TABGNNS(nn.Module):
 
 
 class GNN(nn.Module):
-    """``utils.py:111-233`` for ``--model pna`` (``PNAS``): encoders -> backbone -> head on the first ``batch_size``
-    (seed) edges, or on the nodes.  The reference's other GNN variants (gin / cpna / cpnatab) are not built."""
+    """``utils.py:111-233`` for ``--model pna`` (``PNAS``) and ``--model cpna`` (``CPNA``: the head then sees all
+    ``num_edge_features`` column embeddings of a seed edge, ``e_hidden = ncols * n_hidden``, :120-122,142-144):
+    encoders -> backbone -> head on the first ``batch_size`` (seed) edges, or on the nodes.  Not built: gin, cpnatab
+    (whose reference forward returns nothing, pna.py:285-302)."""
 
     def __init__(self, config):
         super().__init__()
@@ -113,17 +117,25 @@ class GNN(nn.Module):
         self.batch_size = config["batch_size"]
         self.node_encoder = config["node_encoder"]
         self.edge_encoder = config["edge_encoder"]
-        if config.get("model", "pna") != "pna":
+        name = config.get("model", "pna")
+        if name not in ("pna", "cpna"):
             raise ValueError("Invalid model name!")
         if config.get("in_degrees") is None:
             raise ValueError("In degrees are not provided for PNA model!")
         n_dim = config["num_node_features"] * config["n_hidden"]
         e_dim = config["num_edge_features"] * config["n_hidden"]
-        self.model = PNAS(num_features=n_dim, n_hidden=config["n_hidden"], num_gnn_layers=config["n_gnn_layers"],
-                          edge_dim=e_dim, deg=degree_histogram(config["in_degrees"]),
-                          edge_updates=config.get("emlps", True), reverse_mp=config.get("reverse_mp", False))
+        cls = PNAS if name == "pna" else CPNA
+        self.model = cls(num_features=n_dim, n_hidden=config["n_hidden"], num_gnn_layers=config["n_gnn_layers"],
+                         edge_dim=e_dim, deg=degree_histogram(config["in_degrees"]),
+                         edge_updates=config.get("emlps", True), reverse_mp=config.get("reverse_mp", False))
+        self.cpna = name == "cpna"
         if config["task"] == "edge_classification":
-            self.decoder = ClassifierHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
+            e_hidden = config["num_edge_features"] * config["n_hidden"] if self.cpna else None
+            self.decoder = ClassifierHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"],
+                                          e_hidden=e_hidden)
+        elif self.cpna:     # utils.py:126-127 sizes the node head by the edge width; the node state itself is n_hidden
+            self.decoder = NodeClassificationHead(config["n_classes"], config["num_edge_features"] * config["n_hidden"],
+                                                  dropout=config["dropout"])
         else:
             self.decoder = NodeClassificationHead(config["n_classes"], config["n_hidden"], dropout=config["dropout"])
 
@@ -131,6 +143,8 @@ class GNN(nn.Module):
         x, _ = self.node_encoder(x)
         edge_attr, _ = self.edge_encoder(edge_attr)
         x, edge_attr = self.model(x, edge_index, edge_attr)
+        if getattr(self, "cpna", False):
+            edge_attr = edge_attr.reshape(edge_attr.shape[0], -1)                            # utils.py:142-144
         if self.config["task"] == "edge_classification":
             bs = self.batch_size
             return self.decoder(x, edge_index[:, :bs].contiguous(), edge_attr[:bs].contiguous())

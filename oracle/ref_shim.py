@@ -58,7 +58,7 @@ def load_reference():
     spec = importlib.util.spec_from_file_location("tabgnn_ref_loss", f"{REF}/src/utils/loss.py")   # pure torch file
     loss = importlib.util.module_from_spec(spec); spec.loader.exec_module(loss)
     inter = importlib.import_module("src.nn.models.inteleaved")
-    extra = {"TABGNNInterleaved": inter.TABGNNInterleaved, "PNAS": pna.PNAS, "LinkPredHead": dec.LinkPredHead, "MCMHead": ssl.MCMHead, "SelfSupervisedHead": ssl.SelfSupervisedHead,
+    extra = {"TABGNNInterleaved": inter.TABGNNInterleaved, "PNAS": pna.PNAS, "CPNA": pna.CPNA, "LinkPredHead": dec.LinkPredHead, "MCMHead": ssl.MCMHead, "SelfSupervisedHead": ssl.SelfSupervisedHead,
              "SSLoss": loss.SSLoss}
     return {**extra, "TABGNNFused": fused.TABGNNFused, "FTTransformerPNAFusedLayer": fused.FTTransformerPNAFusedLayer,
             "TABGNN": tabgnn.TABGNN, "PNAConvHetero": pna.PNAConvHetero,

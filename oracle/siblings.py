@@ -62,3 +62,24 @@ def pnas_forward(sd, x, edge_index, edge_attr, training=False, edge_updates=True
             e = e + _edge_mlp(x, edge_index, e, sd, f"emlps.{i}.") / 2
         i += 1
     return x, e
+
+
+def cpna_forward(sd, x, edge_index, edge_attr, training=False, edge_updates=True):
+    """``CPNA.forward`` (src/nn/gnn/pna.py:205-219): one stack of L PNA layers PER edge-table column, all sharing the
+    evolving node state x; column c's embeddings are updated by its own edge MLPs and written back.
+    edge_attr [E, ncols, F] -> (x [N,F], edge_attr [E, ncols, F])."""
+    x = x.reshape(x.shape[0], -1) @ sd["node_emb.weight"].t() + sd["node_emb.bias"]
+    cols = []
+    c = 0
+    while f"col_batch_norms.{c}.0.module.weight" in sd:
+        col = edge_attr[:, c, :]
+        i = 0
+        while f"col_batch_norms.{c}.{i}.module.weight" in sd:
+            conv = gnn_conv(x, edge_index, col, sd, f"col_convs.{c}.{i}.", PNAS_AGGREGATORS)
+            x = (x + torch.relu(batch_norm(conv, sd, f"col_batch_norms.{c}.{i}.module.", training))) / 2
+            if edge_updates:
+                col = col + _edge_mlp(x, edge_index, col, sd, f"col_emlps.{c}.{i}.") / 2
+            i += 1
+        cols.append(col)
+        c += 1
+    return x, torch.stack(cols, dim=1)

@@ -124,3 +124,55 @@ def test_gpu_pnas_matches_reference(name):
         ref = float(z[f"gradnorm.{k}"])
         got = 0.0 if p.grad is None else p.grad.double().norm().item()      # unused parameters (edge_emb) stay None
         assert abs(got - ref) < 2e-3 * max(1.0, ref), k
+
+
+def test_oracle_cpna_matches_reference():
+    from oracle.siblings import cpna_forward
+    cfg, z = load_case("cpna_f32_l2")
+    x, ei, ea = _inputs(cfg, z, cfg["F"])
+    sd = build_state(cfg["keys"], z, cfg["seed"])
+    with torch.no_grad():
+        xo, eo = cpna_forward({k: v.clone() for k, v in sd.items()}, x, ei, ea)
+    np.testing.assert_allclose(xo.numpy(), z["eval.x"], atol=2e-5)
+    np.testing.assert_allclose(eo.numpy(), z["eval.edge_attr"], atol=2e-5)
+    for k in sd:
+        if sd[k].is_floating_point() and "avg_deg" not in k and "running" not in k:
+            sd[k].requires_grad_(True)
+    ea_in = ea.clone().requires_grad_(True)
+    xo, eo = cpna_forward(sd, x, ei, ea_in, training=True)
+    loss = _scalar(cfg, xo, eo, cfg["N"], cfg["E"])
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-5
+    np.testing.assert_allclose(ea_in.grad.numpy(), z["grad.edge_attr"], atol=1e-6)
+    for k in sd:
+        if f"gradnorm.{k}" in z.files and sd[k].grad is not None:
+            assert abs(sd[k].grad.double().norm().item() - float(z[f"gradnorm.{k}"])) < 1e-4 * max(1.0, float(z[f"gradnorm.{k}"])), k
+
+
+@pytest.mark.gpu
+def test_gpu_cpna_matches_reference():
+    import tabgnn_amd as T
+    dev = "cuda:0"
+    cfg, z = load_case("cpna_f32_l2")
+    Fh, N, E = cfg["F"], cfg["N"], cfg["E"]
+    x, ei, ea = _inputs(cfg, z, Fh)
+    deg = torch.bincount(torch.bincount(ei[1], minlength=N))
+    m = T.CPNA(num_features=Fh, num_gnn_layers=cfg["L"], n_hidden=Fh, edge_updates=True, edge_dim=cfg["ncols"] * Fh, deg=deg)
+    m.load_state_dict(build_state(cfg["keys"], z, cfg["seed"]))
+    m.to(dev).eval()
+    with torch.no_grad():
+        xo, eo = m(x.to(dev), ei.to(dev), ea.to(dev))
+    np.testing.assert_allclose(xo.cpu().numpy(), z["eval.x"], atol=1e-4)
+    np.testing.assert_allclose(eo.cpu().numpy(), z["eval.edge_attr"], atol=1e-4)
+    m.load_state_dict(build_state(cfg["keys"], z, cfg["seed"]))
+    m.train()
+    ea_in = ea.to(dev).requires_grad_(True)
+    xo, eo = m(x.to(dev), ei.to(dev), ea_in)
+    loss = _scalar(cfg, xo, eo, N, E)
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-4
+    np.testing.assert_allclose(ea_in.grad.cpu().numpy(), z["grad.edge_attr"], atol=1e-5)
+    for k, p in m.named_parameters():
+        ref = float(z[f"gradnorm.{k}"])
+        got = 0.0 if p.grad is None else p.grad.double().norm().item()
+        assert abs(got - ref) < 2e-3 * max(1.0, ref), k
