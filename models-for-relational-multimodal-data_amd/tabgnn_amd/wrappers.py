@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import ops
 from .heads import ClassifierHead, NodeClassificationHead
 from .models import CPNA, PNAS, TABGNN, TABGNNFused, TABGNNInterleaved
 
@@ -44,9 +45,10 @@ class TABGNNFusedS(nn.Module):
         x, _ = self.node_encoder(x)
         edge_attr, _ = self.edge_encoder(edge_attr)
         target_edge_attr, _ = self.edge_encoder(target_edge_attr)
-        x, edge_attr, target_edge_attr = self.model(x, edge_index, edge_attr, target_edge_index, target_edge_attr)
+        seeds = ops.SeedIndex(target_edge_index, x.shape[0])          # one CSR of the seed endpoints for backbone AND head
+        x, edge_attr, target_edge_attr = self.model(x, edge_index, edge_attr, seeds, target_edge_attr)
         if self.config["task"] == "edge_classification":
-            return self.decoder(x, target_edge_index, target_edge_attr)
+            return self.decoder(x, seeds, target_edge_attr)
         return self.decoder(x)
 
     def get_model(self, config):
