@@ -90,6 +90,8 @@ int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* ga
               const void* dout, void* da, void* db, void* dres, float* dparams /*[3C]: dgamma,dbeta,dbias_b*/,
               float* partials, int64_t M, int32_t C, float alpha, float beta_c, float p_drop, uint64_t seed,
               uint32_t rstream, int32_t accum_da /*1: da += (another branch's gradient is already there)*/,
+              float* acc_gamma, float* acc_beta, float* acc_bias /* any non-NULL: the parameter gradients are ADDED to
+              these [C] buffers (the parameters' .grad) instead of being written to dparams; a NULL one is skipped */,
               int32_t dt, void* stream);
 
 /* ---- BatchNorm1d (+ReLU) with residual combine: out = alpha*res + beta_c*relu(BN(x))

@@ -160,11 +160,18 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
 
 // out[i] = sum_s partial[s][i]: 256 threads = 16 float4 columns x 16 slab strips, four loads in flight per
 // thread, strips combined through LDS in strip order (deterministic)
-__global__ void __launch_bounds__(256) k_sum_slabs(const float* __restrict__ partial, int nslab, long long mn,
-                                                    float* __restrict__ out, int accumulate) {
+// Two jobs in one launch (the weight slabs and the bias column sums of the same GEMM): blocks [0, nb1) reduce job 1,
+// the rest job 2.
+__global__ void __launch_bounds__(256) k_sum_slabs(const float* __restrict__ partial1, int nslab, long long mn1,
+                                                    float* __restrict__ out1, int nb1, const float* __restrict__ partial2,
+                                                    long long mn2, float* __restrict__ out2, int accumulate) {
   __shared__ float4 red[16][16];
   const int col = threadIdx.x & 15, strip = threadIdx.x >> 4;
-  const long long i = ((long long)blockIdx.x * 16 + col) * 4;
+  const bool second = (int)blockIdx.x >= nb1;
+  const float* __restrict__ partial = second ? partial2 : partial1;
+  float* __restrict__ out = second ? out2 : out1;
+  const long long mn = second ? mn2 : mn1;
+  const long long i = ((long long)(second ? blockIdx.x - nb1 : blockIdx.x) * 16 + col) * 4;
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < mn) {
     const int per = (nslab + 15) / 16, s0 = strip * per, s1 = s0 + per < nslab ? s0 + per : nslab;
@@ -252,11 +259,9 @@ extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* 
                      (const unsigned short*)X, workspace, colsum ? workspace + (long long)nslab * M * N : nullptr,
                      (long long)R, M, N, (long long)ldg, (long long)ldx, rps);
   long long mn = (long long)M * N;
-  hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(mn, 4), 16)), dim3(256), 0, st, workspace, nslab, mn, out, accumulate);
-  if (colsum) {
-    float* cs = workspace + (long long)nslab * mn;
-    hipLaunchKernelGGL(k_sum_slabs, dim3(ceil_div(ceil_div(M, 4), 16)), dim3(256), 0, st, cs, nslab, (long long)M, colsum, accumulate);
-  }
+  const int nb1 = ceil_div(ceil_div(mn, 4), 16), nb2 = colsum ? ceil_div(ceil_div(M, 4), 16) : 0;
+  hipLaunchKernelGGL(k_sum_slabs, dim3(nb1 + nb2), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
+                     workspace + (long long)nslab * mn, (long long)M, colsum, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }

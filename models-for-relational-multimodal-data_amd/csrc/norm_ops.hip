@@ -260,6 +260,42 @@ __global__ void __launch_bounds__(1024) k_reduce_partials(const float* __restric
   }
 }
 
+// LayerNorm parameter gradients straight into the parameters' gradient buffers: the [3][C] reduction of
+// k_reduce_partials with one destination per C-wide segment (dgamma, dbeta, dbias; a NULL destination is skipped) and
+// "+=" semantics, so autograd never runs an AccumulateGrad add for them.
+__global__ void __launch_bounds__(1024) k_reduce_partials_acc3(const float* __restrict__ partials, int nblk, int C,
+                                                                float* __restrict__ o0, float* __restrict__ o1,
+                                                                float* __restrict__ o2) {
+  __shared__ float red[RP_STRIPS][64];
+  const int width = 3 * C;
+  const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float t = 0.f;
+  if (col < width) {
+    const int per = (nblk + RP_STRIPS - 1) / RP_STRIPS, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float acc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+    int b = b0;
+    for (; b + 7 < b1; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += partials[(long long)(b + u) * width + col];
+    }
+    for (; b < b1; ++b) acc[0] += partials[(long long)b * width + col];
+    t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  }
+  red[strip][lane] = t;
+  __syncthreads();
+  if (strip == 0 && col < width) {
+    float r = 0.f;
+#pragma unroll
+    for (int u = 0; u < RP_STRIPS; ++u) r += red[u][lane];
+    const int seg = col / C, c = col - seg * C;
+    float* o = seg == 0 ? o0 : (seg == 1 ? o1 : o2);
+    if (o) o[c] += r;
+  }
+}
+
 // ------------------------------------------------------------------ BatchNorm (+ReLU, + residual average)
 // column statistics: each lane owns VEC channels, rows strided over lane groups and blocks
 template <typename T, int VEC>
@@ -612,11 +648,13 @@ extern "C" int tg_ln_fwd(const void* a, const void* b, const float* bias_b, cons
 extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* gamma, const float* stats,
                          const void* dout, void* da, void* db, void* dres, float* dparams, float* partials, int64_t M,
                          int32_t C, float alpha, float beta_c, float p_drop, uint64_t seed, uint32_t rstream,
-                         int32_t accum_da, int32_t dt, void* stream) {
+                         int32_t accum_da, float* acc_gamma, float* acc_beta, float* acc_bias, int32_t dt,
+                         void* stream) {
   TG_CHECK(C % 8 == 0 && C <= 2048, "tg_ln_bwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
   hipStream_t st = (hipStream_t)stream;
+  const bool acc_params = acc_gamma != nullptr || acc_beta != nullptr || acc_bias != nullptr;
   if (M == 0) {
-    zero_async(dparams, 3 * (size_t)C * sizeof(float), st);
+    if (!acc_params) zero_async(dparams, 3 * (size_t)C * sizeof(float), st);
     return 0;
   }
   unsigned thresh = ((b || db) && p_drop > 0.f) ? drop_threshold(p_drop) : 0u;
@@ -633,7 +671,11 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
               (const T*)dout, (T*)da, (T*)db, (T*)dres, partials, (long long)M, C, lpr, alpha, beta_c, thresh, inv_keep,
               (unsigned long long)seed, rstream, (int)accum_da);
   })
-  hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 64)), dim3(1024), 0, st, partials, grid, 3 * C, dparams);
+  if (acc_params)
+    hipLaunchKernelGGL(k_reduce_partials_acc3, dim3(ceil_div(3 * C, 64)), dim3(1024), 0, st, partials, grid, C, acc_gamma,
+                       acc_beta, acc_bias);
+  else
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 64)), dim3(1024), 0, st, partials, grid, 3 * C, dparams);
   TG_LAUNCH_CHECK();
   return 0;
 }

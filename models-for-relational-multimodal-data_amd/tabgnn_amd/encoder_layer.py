@@ -29,17 +29,19 @@ def _ln_fwd(a, b, bias_b, gamma, beta, res, alpha, beta_c, p, seed, rs, eps=1e-5
     return out, stats
 
 
-def _ln_bwd(a, b, bias_b, gamma, stats, g, da, want_db, dres, alpha, beta_c, p, seed, rs, accum):
-    """Returns (db, dparams[3,C]); writes (or accumulates into) ``da`` and writes ``dres`` when given."""
+def _ln_bwd(a, b, bias_b, gamma, stats, g, da, want_db, dres, alpha, beta_c, p, seed, rs, accum, targets=None):
+    """Returns (db, dparams[3,C]); writes (or accumulates into) ``da`` and writes ``dres`` when given.  ``targets`` =
+    (dgamma, dbeta, dbias) gradient-buffer pointers (ops.ln_grad_targets): the parameter gradients are then added
+    there by the kernel and ``dparams`` comes back as (None, None, None)."""
     C = a.shape[-1]
     M = a.numel() // C
     db = torch.empty_like(a) if want_db else None
-    dparams = torch.empty(3, C, dtype=torch.float32, device=a.device)
+    dparams = None if targets else torch.empty(3, C, dtype=torch.float32, device=a.device)
     partials = torch.empty(L.load().tg_ln_partials_floats(M, C), dtype=torch.float32, device=a.device)
     L.call("tg_ln_bwd", L.ptr(a), L.ptr(b), L.ptr(bias_b), L.ptr(gamma), L.ptr(stats), L.ptr(g), L.ptr(da), L.ptr(db),
-           L.ptr(dres), L.ptr(dparams), L.ptr(partials), M, C, alpha, beta_c, p, seed, rs, int(accum), L.dt(a),
-           L.stream())
-    return db, dparams
+           L.ptr(dres), L.ptr(dparams), L.ptr(partials), M, C, alpha, beta_c, p, seed, rs, int(accum),
+           *(targets or (None, None, None)), L.dt(a), L.stream())
+    return db, (dparams if dparams is not None else (None, None, None))
 
 
 class _EncoderLayerFn(torch.autograd.Function):
@@ -88,6 +90,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         ctx.nt = nt
         isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
         ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2))   # weight gradients accumulate in place
+        ctx.ln_params = ((g1, be1, b_o), (g2, be2, b2), (gt, bt, None))               # LayerNorm gradients too
         return out.view(R, S, C)
 
     @staticmethod
@@ -103,16 +106,18 @@ class _EncoderLayerFn(torch.autograd.Function):
         if tail:                                         # out = alpha*x + beta_c*LN_t(x2)
             d_x2 = torch.empty_like(x2)
             d_x = torch.empty_like(x2) if alpha != 0.0 else None
-            _, dp = _ln_bwd(x2, None, None, gt, st3, g, d_x2, False, d_x, alpha, beta_c, 0.0, 0, 0, False)
+            _, dp = _ln_bwd(x2, None, None, gt, st3, g, d_x2, False, d_x, alpha, beta_c, 0.0, 0, 0, False,
+                            ops.ln_grad_targets(*ctx.ln_params[2]))
             dgt, dbt = dp[0], dp[1]
         else:
             d_x2 = g
+        tg1, tg2 = ops.ln_grad_targets(*ctx.ln_params[0]), ops.ln_grad_targets(*ctx.ln_params[1])
         # x2 = LN2(x1 + drop(y2 + b2))
         d_x1 = torch.empty_like(x1)
         if ctx.nt:  # y2 holds z2 = x1 + drop(h W2^T + b2): the LayerNorm backward's "z mode"
-            d_y2, dp2 = _ln_bwd(y2, None, None, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
+            d_y2, dp2 = _ln_bwd(y2, None, None, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False, tg2)
         else:
-            d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False)
+            d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False, tg2)
         del d_x2
         dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
         nt = ctx.nt
@@ -139,9 +144,9 @@ class _EncoderLayerFn(torch.autograd.Function):
         if d_x is None:
             d_x = torch.empty_like(x1)
         if ctx.nt:
-            d_y, dp1 = _ln_bwd(y, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx)
+            d_y, dp1 = _ln_bwd(y, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
         else:
-            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx)
+            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
         del d_x1
         dwo, _ = ops.weight_grad(d_y, o, False, p_o)
         d_o = ops.gemm_nt(d_y, lw_o.t()) if nt else d_y @ lw_o

@@ -237,6 +237,19 @@ def _grad_target(p):
     return g
 
 
+def ln_grad_targets(gamma, beta, bias):
+    """(dgamma, dbeta, dbias) device pointers of the parameters' existing gradient buffers when ALL the LayerNorm's
+    parameters own one (FlatParams views) — the backward kernel then adds into them and returns no gradient tensors —
+    else None.  ``bias`` may be None (no bias on this path)."""
+    is_p = lambda t: isinstance(t, torch.nn.Parameter)
+    if not (is_p(gamma) and is_p(beta)) or (bias is not None and not is_p(bias)):
+        return None
+    tg = [_grad_target(gamma), _grad_target(beta), _grad_target(bias) if bias is not None else None]
+    if tg[0] is None or tg[1] is None or (bias is not None and tg[2] is None):
+        return None
+    return tuple(None if t is None else t.data_ptr() for t in tg)
+
+
 def weight_grad(g2, x2, want_bias=False, wparam=None, bparam=None):
     """(dW [M,N] fp32 = g2[R,M]^T x2[R,N], db [M] fp32 = column sums of g2 or None).  Tall-skinny bf16 problems go
     to the split-row MFMA kernel (tg_gemm_tn_bf16, bias gradient from the same LDS tiles); small or fp32 ones to
@@ -382,6 +395,7 @@ class _LayerNorm(torch.autograd.Function):
                L.ptr(stats), M, C, eps, alpha, beta_c, p_drop, ctx.seed, ctx.rs, L.dt(a), L.stream())
         ctx.save_for_backward(a, b, bias_b, gamma, stats)
         ctx.cfg = (M, C, alpha, beta_c, p_drop, res is not None)
+        ctx.params = (gamma, beta, bias_b)
         return out
 
     @staticmethod
@@ -392,11 +406,14 @@ class _LayerNorm(torch.autograd.Function):
         da = torch.empty_like(a)
         db = torch.empty_like(a) if b is not None else None
         dres = torch.empty_like(a) if has_res else None
-        dparams = torch.empty(3, C, dtype=torch.float32, device=a.device)
         partials = _workspace(L.load().tg_ln_partials_floats(M, C), a.device)
+        tg = ln_grad_targets(*ctx.params)
+        dparams = None if tg else torch.empty(3, C, dtype=torch.float32, device=a.device)
         L.call("tg_ln_bwd", L.ptr(a), L.ptr(b), L.ptr(bias_b), L.ptr(gamma), L.ptr(stats), L.ptr(g), L.ptr(da),
                L.ptr(db), L.ptr(dres), L.ptr(dparams), L.ptr(partials), M, C, alpha, beta_c, p_drop, ctx.seed, ctx.rs,
-               0, L.dt(a), L.stream())
+               0, *(tg or (None, None, None)), L.dt(a), L.stream())
+        if tg:
+            return da, db, None, None, None, dres, None, None, None, None
         dbias = dparams[2] if bias_b is not None else None
         return da, db, dbias, dparams[0], dparams[1], dres, None, None, None, None
 

@@ -332,8 +332,8 @@ def test_encoder_layer_composite_equals_op_by_op_composition(T, C, H, dtype, p):
     go = torch.randn(R, S, C, device=DEV).to(dtype)
     res = []
     for fused in (True, False):
-        for q in layer.parameters():
-            q.grad = None
+        for q in layer.parameters():      # existing gradient buffers on the fused run: the in-kernel "+=" paths are taken
+            q.grad = torch.zeros_like(q) if fused else None
         if dtype == torch.bfloat16:
             for q in layer.parameters():
                 q._lp = q.detach().to(dtype)
