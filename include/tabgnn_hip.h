@@ -71,6 +71,10 @@ int tg_encode_fwd(const void* desc, const void* ptrs, void* out /*[R,ncols,C]*/,
 int tg_encode_bwd(const void* desc, const void* ptrs, const void* g /*[R,ncols,C]*/, int64_t R, int32_t ncols,
                   int32_t C, int32_t acc_floats, float* dflat, float* partials, float* big_table_grad, int32_t dt,
                   void* stream);
+/* adds segments of a reduced gradient vector into parameter gradient buffers in one launch: table int64 [nseg][3] on
+ * the device = (destination float* as integer, offset into src, length).  Used by the encoder backward so that no
+ * per-parameter zero-fill / slice copy / autograd add runs. */
+int tg_scatter_add_segments(const float* src, const int64_t* table, int32_t nseg, int64_t max_len, void* stream);
 
 /* ---- column self-attention core (torch nn.MultiheadAttention inside nn.TransformerEncoderLayer;
  *      src/nn/models/fused.py:83-92,160,164,187-196,249; src/nn/models/tabgnn.py:199-208,219) ---------- */

@@ -335,6 +335,19 @@ __global__ void __launch_bounds__(256) k_enc_reduce(const float* __restrict__ pa
   if (strip == 0 && col < width) out[col] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// dst_k[0..len_k) += src[off_k .. off_k+len_k) for every segment k of a table (dst pointer, src offset, length):
+// the reduced encoder gradient vector is added into the encoder parameters' gradient buffers in ONE launch
+// (instead of a zero-fill, a slice copy and an autograd add per parameter column).
+__global__ void __launch_bounds__(256) k_scatter_add_segments(const float* __restrict__ src,
+                                                               const long long* __restrict__ table, int nseg) {
+  const int k = blockIdx.y;
+  if (k >= nseg) return;
+  float* __restrict__ dst = reinterpret_cast<float*>(table[3 * k]);
+  const long long off = table[3 * k + 1], len = table[3 * k + 2];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+    dst[i] += src[off + i];
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -437,6 +450,20 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
     hipLaunchKernelGGL(k_enc_reduce, dim3(ceil_div(width, 64)), dim3(256), 0, st, partials, grid, width,
                        dflat + c.acc_off, (const int*)nullptr, 0);
   }
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// table: int64 [nseg][3] on the device = (destination float* as integer, offset into src, length); segments must not
+// overlap in their destinations (each parameter column is one segment).
+extern "C" int tg_scatter_add_segments(const float* src, const int64_t* table, int32_t nseg, int64_t max_len,
+                                       void* stream) {
+  if (nseg <= 0) return 0;
+  TG_CHECK(src && table && max_len > 0, "tg_scatter_add_segments: null argument");
+  int bx = (int)((max_len + 255) / 256);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(k_scatter_add_segments, dim3(bx, nseg), dim3(256), 0, (hipStream_t)stream, src,
+                     (const long long*)table, nseg);
   TG_LAUNCH_CHECK();
   return 0;
 }

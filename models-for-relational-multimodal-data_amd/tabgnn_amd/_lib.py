@@ -29,6 +29,7 @@ SIGNATURES = {
     "tg_encode_bwd_blocks": [],
     "tg_encode_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "tg_encode_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
+    "tg_scatter_add_segments": [_vp, _vp, _i32, _i64, _vp],
     "tg_attn_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_ln_partials_floats": [_i64, _i32],

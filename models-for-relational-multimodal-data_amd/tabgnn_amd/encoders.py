@@ -118,8 +118,19 @@ class _Encode(torch.autograd.Function):
         dev = g.device
         ptrs = enc._ptrs(feats, params)
         num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b = params
-        grads = [None if p is None else torch.zeros_like(p) for p in params]
         nblk = L.load().tg_encode_bwd_blocks()
+        seg_tables = enc._grad_segment_tables(dev)
+        if seg_tables is not None:
+            # every encoder parameter already owns a gradient buffer: the reduced vector of each column group is
+            # added into them by one scatter-add launch (no zero-fill / slice copy / autograd add per column)
+            for desc, acc_floats, (table, nseg, max_len) in zip(plan["descs"], plan["acc_floats"], seg_tables):
+                dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
+                partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
+                L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), g.data_ptr(), R, row_cols, Cc, acc_floats,
+                       L.ptr(dflat), L.ptr(partials), None, L.dt(g), L.stream())
+                L.call("tg_scatter_add_segments", L.ptr(dflat), L.ptr(table), nseg, max_len, L.stream())
+            return (None,) * (3 + len(params))
+        grads = [None if p is None else torch.zeros_like(p) for p in params]
         for desc, acc_floats, segs in zip(plan["descs"], plan["acc_floats"], plan["segments"]):
             dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
             partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
@@ -211,6 +222,50 @@ class StypeWiseFeatureEncoder(nn.Module):
             d.nts = nts
             descs.append(d); accs.append(off); segments.append(segs)
         return dict(ncols=out_col, descs=descs, acc_floats=accs, segments=segments)
+
+    def _grad_segment_tables(self, dev):
+        """Per column group: (device int64 table [nseg,3] = (gradient-buffer address, offset in the group's reduced
+        vector, length), nseg, longest segment) — or None when some parameter has no gradient buffer yet, or a
+        categorical table is too large for the LDS accumulators (its gradient then goes through atomics)."""
+        ed, Cc = self.encoder_dict, self.out_channels
+
+        def grad_of(p):
+            g = p.grad
+            return g if (g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.device == dev) else None
+        src = {}
+        if "numerical" in ed:
+            src[0] = (grad_of(ed["numerical"].weight), grad_of(ed["numerical"].bias))
+        if "relation" in ed:
+            src[3] = (grad_of(ed["relation"].weight), grad_of(ed["relation"].bias))
+        if "timestamp" in ed:
+            src[2] = (grad_of(ed["timestamp"].weight), grad_of(ed["timestamp"].bias))
+        embs = [grad_of(e.weight) for e in ed["categorical"].embs] if "categorical" in ed else []
+        if any(g is None for pair in src.values() for g in pair) or any(g is None for g in embs):
+            return None
+        key = tuple(g.data_ptr() for pair in src.values() for g in pair) + tuple(g.data_ptr() for g in embs)
+        cache = self.__dict__.setdefault("_seg_cache", {})
+        if key in cache:
+            return cache[key]
+        tables = []
+        for segs in self._plan["segments"]:
+            rows_ = []
+            for kind, src_col, off, rows, tab_off in segs:
+                if kind in (0, 3):
+                    w, b = src[kind]
+                    rows_ += [(w[src_col].data_ptr(), off, Cc), (b[src_col].data_ptr(), off + Cc, Cc)]
+                elif kind == 2:
+                    w, b = src[2]
+                    rows_ += [(w[src_col].data_ptr(), off, 56 * Cc), (b[src_col].data_ptr(), off + 56 * Cc, Cc)]
+                elif off >= 0:
+                    rows_.append((embs[src_col].data_ptr(), off, rows * Cc))
+                else:
+                    cache[key] = None
+                    return None
+            table = torch.tensor(rows_, dtype=torch.int64, device=dev).reshape(-1, 3) if rows_ else \
+                torch.zeros(0, 3, dtype=torch.int64, device=dev)
+            tables.append((table, len(rows_), max([r[2] for r in rows_], default=1)))
+        cache[key] = tables
+        return tables
 
     def _cat_table(self):
         embs = self.encoder_dict["categorical"].embs
