@@ -191,6 +191,9 @@ int tg_weighted_ce_bwd(const void* logits, const int64_t* y, const float* w, con
 int tg_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                  float eps, int32_t t, float grad_scale, int32_t zero_grad, void* stream);
 int tg_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+/* one launch: transposed bf16 copies of all 2-D parameters (table int64 [n][3] = element offset, rows, cols inside
+ * src/dst) — the input-gradient GEMMs read W^T as their row-major weight */
+int tg_transpose_batched_bf16(const void* src, void* dst, const int64_t* table, int32_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,45 @@ extern "C" int tg_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* str
   return 0;
 }
 
+// Batched transpose of the 2-D parameters' bf16 shadows (one launch for the whole model, after the optimiser step):
+// dst[off .. off+rows*cols) viewed [cols, rows] = transpose of src[off ..) viewed [rows, cols].  The input-gradient
+// GEMMs (dX = G W) read W^T as their row-major weight, so no per-call transpose kernels run.
+namespace tg {
+__global__ void __launch_bounds__(256) k_transpose_batched(const unsigned short* __restrict__ src,
+                                                           unsigned short* __restrict__ dst,
+                                                           const long long* __restrict__ table) {
+  __shared__ unsigned short tile[32][33];
+  const long long off = table[3 * blockIdx.z];
+  const int rows = (int)table[3 * blockIdx.z + 1], cols = (int)table[3 * blockIdx.z + 2];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8 threads, 32 x 32 tiles
+  for (int r0 = blockIdx.y * 32; r0 < rows; r0 += gridDim.y * 32)
+    for (int c0 = blockIdx.x * 32; c0 < cols; c0 += gridDim.x * 32) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * k][tx] = src[off + (long long)r * cols + c];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (r < rows && c < cols) dst[off + (long long)c * rows + r] = tile[tx][ty + 8 * k];
+      }
+      __syncthreads();
+    }
+}
+}  // namespace tg
+
+// table: int64 [n][3] on the device = (element offset, rows, cols) of each matrix inside src / dst
+extern "C" int tg_transpose_batched_bf16(const void* src, void* dst, const int64_t* table, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  TG_CHECK(src && dst && table, "tg_transpose_batched_bf16: null argument");
+  hipLaunchKernelGGL(tg::k_transpose_batched, dim3(8, 8, n), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)src, (unsigned short*)dst, (const long long*)table);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---------------------------------------------------------------- library plumbing
 #include <stdarg.h>
 #include <stdio.h>

@@ -65,6 +65,7 @@ SIGNATURES = {
     "tg_weighted_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "tg_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],
     "tg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "tg_transpose_batched_bf16": [_vp, _vp, _vp, _i32, _vp],
 }
 _RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,
              "tg_gemm_tn_workspace_floats": _i64}

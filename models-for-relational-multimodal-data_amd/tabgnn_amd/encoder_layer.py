@@ -122,7 +122,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
         nt = ctx.nt
         if nt:      # dX GEMM with the backward of drop(relu(.)) in its epilogue: d_h never exists
-            d_hpre = ops.gemm_nt(d_y2, lw2.t(), None, ops.NT_GATE, p, gate=h)
+            d_hpre = ops.gemm_nt(d_y2, ops.wt(lw2, p_2), None, ops.NT_GATE, p, gate=h)
             del d_y2
         else:
             d_h = d_y2 @ lw2
@@ -135,7 +135,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         if db1 is None and dw1 is not None:
             db1 = d_hpre.sum(0, dtype=torch.float32)
         if nt:                                           # second consumer of x1: accumulated by the GEMM (beta = 1)
-            ops.gemm_nt(d_hpre, lw1.t(), None, ops.NT_ACCUM, out=d_x1)
+            ops.gemm_nt(d_hpre, ops.wt(lw1, p_1), None, ops.NT_ACCUM, out=d_x1)
         else:
             d_x1.addmm_(d_hpre, lw1)
         del d_hpre
@@ -149,7 +149,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
         del d_x1
         dwo, _ = ops.weight_grad(d_y, o, False, p_o)
-        d_o = ops.gemm_nt(d_y, lw_o.t()) if nt else d_y @ lw_o
+        d_o = ops.gemm_nt(d_y, ops.wt(lw_o, p_o)) if nt else d_y @ lw_o
         del d_y
         d_qkv = torch.empty_like(qkv)
         L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
@@ -159,7 +159,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         if dbin is None and dwin is not None:
             dbin = d_qkv.sum(0, dtype=torch.float32)
         if nt:                                           # third consumer of x
-            ops.gemm_nt(d_qkv, lw_in.t(), None, ops.NT_ACCUM, out=d_x)
+            ops.gemm_nt(d_qkv, ops.wt(lw_in, p_in), None, ops.NT_ACCUM, out=d_x)
         else:
             d_x.addmm_(d_qkv, lw_in)
         return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],

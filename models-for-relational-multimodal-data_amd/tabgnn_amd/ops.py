@@ -173,6 +173,16 @@ def gemm_nt(x2, w, bias=None, flags=0, p=0.0, seed=0, rs=0, out=None, gate=None)
     return out
 
 
+def wt(lp, param=None):
+    """W^T [in, out] as a row-major tensor for the input-gradient GEMM: the transposed shadow FlatParams keeps up to
+    date (one batched transpose per optimiser step) when the parameter has one, else a transposed view (gemm_nt then
+    makes it contiguous with a small kernel)."""
+    t = getattr(param, "_lp_t", None) if param is not None else None
+    if t is not None and t.dtype == lp.dtype and t.shape == (lp.shape[1], lp.shape[0]) and t.device == lp.device:
+        return t
+    return lp.t()
+
+
 def gemm_nt_ln(x2, w, bias, res, gamma, beta, p=0.0, seed=0, rs=0, eps=1e-5):
     """(z, out, stats): z = res + drop(x2 w^T + bias), out = LayerNorm(z) * gamma + beta  (bf16, d_model = 128)."""
     R, K = x2.shape
@@ -212,7 +222,7 @@ class _Linear(torch.autograd.Function):
         if not ctx.needs_input_grad[0]:
             dx = None
         elif g2.is_contiguous() and nt_ok(g2, w.shape[1], w.shape[0]) and w.dtype == g2.dtype:
-            dx = gemm_nt(g2, w.t()).reshape(ctx.xshape)          # dX = G W = G (W^T)^T: W^T [K,N] is the NT weight
+            dx = gemm_nt(g2, wt(w, ctx.params[0])).reshape(ctx.xshape)   # dX = G W = G (W^T)^T: W^T is the NT weight
         else:
             dx = (g2 @ w).reshape(ctx.xshape)
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
@@ -321,11 +331,11 @@ class _MLPRelu(torch.autograd.Function):
         dw2, db2 = weight_grad(g2, m, True, isp(w2), isp(b2))
         if db2 is None and dw2 is not None:
             db2 = g2.sum(0, dtype=torch.float32)
-        d_pre = gemm_nt(g2, lw2.t(), None, NT_GATE, 0.0, gate=m)        # (g W2) where relu was active
+        d_pre = gemm_nt(g2, wt(lw2, w2), None, NT_GATE, 0.0, gate=m)    # (g W2) where relu was active
         dw0, db0 = weight_grad(d_pre, x2, True, isp(w0), isp(b0))
         if db0 is None and dw0 is not None:
             db0 = d_pre.sum(0, dtype=torch.float32)
-        dx = gemm_nt(d_pre, lw0.t()).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dx = gemm_nt(d_pre, wt(lw0, w0)).reshape(ctx.xshape) if ctx.needs_input_grad[0] else None
         return dx, dw0, db0, dw2, db2, None, None
 
 

@@ -34,6 +34,9 @@ class FlatParams:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.shadow = torch.zeros(n, dtype=shadow_dtype, device=dev) if shadow_dtype not in (None, torch.float32) else None
+        # transposed bf16 shadows of the 2-D parameters (``p._lp_t`` [in, out]): the dX GEMMs' row-major weight
+        self.shadow_t = torch.zeros_like(self.shadow) if self.shadow is not None and dev.type == "cuda" else None
+        t_rows = []
         for p, off in zip(uniq, self.offsets):
             view = self.flat[off:off + p.numel()].view_as(p)
             view.copy_(p.data)
@@ -41,6 +44,10 @@ class FlatParams:
             p.grad = self.grad[off:off + p.numel()].view_as(p)
             if self.shadow is not None:
                 p._lp = self.shadow[off:off + p.numel()].view_as(p)
+                if self.shadow_t is not None and p.dim() == 2:
+                    p._lp_t = self.shadow_t[off:off + p.numel()].view(p.shape[1], p.shape[0])
+                    t_rows.append((off, p.shape[0], p.shape[1]))
+        self.t_table = torch.tensor(t_rows, dtype=torch.int64, device=dev).reshape(-1, 3) if t_rows else None
         self.refresh_shadow()
 
     @property
@@ -54,6 +61,12 @@ class FlatParams:
             L.call("tg_cast_f32_to_bf16", L.ptr(self.flat), L.ptr(self.shadow), self.flat.numel(), L.stream())
         else:
             self.shadow.copy_(self.flat)
+        self.refresh_transposed()
+
+    def refresh_transposed(self):
+        if getattr(self, "t_table", None) is not None:
+            L.call("tg_transpose_batched_bf16", L.ptr(self.shadow), L.ptr(self.shadow_t), L.ptr(self.t_table),
+                   self.t_table.shape[0], L.stream())
 
     def zero_grad(self):
         self.grad.zero_()
@@ -75,6 +88,7 @@ class FusedAdam:
         L.call("tg_adam_step", L.ptr(f.flat), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(f.shadow),
                f.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t, grad_scale, int(zero_grad),
                L.stream())
+        f.refresh_transposed()
 
 
 class DataParallel:

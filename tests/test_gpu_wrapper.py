@@ -198,3 +198,29 @@ def test_bf16_eval_forward_is_deterministic_and_leaves_inputs_untouched():
     assert torch.isfinite(a.float()).all() and torch.equal(a, b) and a.shape == (256, 2)
     assert all(torch.equal(v, keep[0][k]) for k, v in batch[0].feat_dict.items())
     assert torch.equal(batch[1], keep[1]) and all(torch.equal(v, keep[2][k]) for k, v in batch[2].feat_dict.items())
+
+
+def test_transposed_shadows_track_the_optimiser():
+    """FlatParams keeps W^T bf16 copies for the input-gradient GEMMs: after every FusedAdam step they must equal the
+    transposes of the (just refreshed) bf16 shadows, for every 2-D parameter."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    cfg = S.make_config(128, 1, 4, 128, compute_dtype=torch.bfloat16)
+    torch.manual_seed(0)
+    model = T.TABGNNFusedS(cfg).to(DEV).train()
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    opt = T.FusedAdam(flat, lr=1e-2)
+    lw = torch.tensor(cfg["loss_weights"], device=DEV)
+    batch = S.make_batch(128, seed=1, device=DEV)
+
+    def check():
+        n = 0
+        for p in model.parameters():
+            assert torch.equal(p._lp.float(), p.detach().to(torch.bfloat16).float())
+            if p.dim() == 2:
+                assert torch.equal(p._lp_t, p._lp.t()); n += 1
+        assert n > 20
+    check()
+    for _ in range(2):
+        T.train_step(model, flat, opt, batch, lw)
+        check()
