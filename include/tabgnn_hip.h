@@ -139,10 +139,16 @@ int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t*
                     int32_t F, int32_t* hub_work, int32_t dt, void* stream);
 /* mean|max|min|std of messages h[E,F] per destination -> agg[N,4F]  (PNAConv.aggregate, "the SpMM") */
 /* perm == NULL: h rows are already in CSR (destination-sorted) order (E = number of rows of h) */
+/* hub_work: tg_segment_hub_ints(E) ints with hub_work[0] == 0 on entry, or NULL.  With it, destinations of more than
+ * 512 rows (reverse message passing: the heavy-tailed sources become destinations) are only LISTED there by these two
+ * launches and reduced, a whole workgroup each, by tg_pna_aggregate_hubs (forward: dh == NULL, fills agg rows;
+ * backward: fills dh rows). */
 int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const int32_t* perm, void* agg, int32_t N, int32_t F,
-                         int64_t E, int32_t dt, void* stream);
+                         int64_t E, int32_t* hub_work, int32_t dt, void* stream);
 int tg_pna_aggregate_bwd(const void* h, const void* agg, const void* dagg, const int32_t* rowptr, const int32_t* perm,
-                         void* dh, int32_t N, int32_t F, int32_t dt, void* stream);
+                         void* dh, int32_t N, int32_t F, int32_t* hub_work, int32_t dt, void* stream);
+int tg_pna_aggregate_hubs(const void* h, const void* agg, const void* dagg, const int32_t* rowptr, const int32_t* perm,
+                          void* dh, int32_t F, const int32_t* hub_work, int32_t dt, void* stream);
 /* degree scalers applied after the post GEMM: out = xw + G0 + amp*G1 + att*G2 (DegreeScalerAggregation) */
 int tg_pna_scale_combine_fwd(const void* xw, const void* G /*[N,3F]*/, const int32_t* rowptr, const float* avg_log,
                              void* out, int32_t N, int32_t F, int32_t dt, void* stream);

@@ -186,13 +186,17 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
 // One group of F/VEC lanes per destination node (16 lanes for bf16 F=128 -> 4 nodes per wave),
 // 16-byte loads of whole message rows in CSR order, single pass for sum, sum of squares, max, min.
 constexpr float STD_EPS = 1e-5f;
+// Destinations with more rows than this (reverse message passing turns the heavy-tailed SOURCES into destinations: one
+// with 12.7 k in-edges at B = 8192) are reduced by a whole workgroup instead of one lane group: 2.0 -> ~0.2 ms forward,
+// 8.4 -> ~0.4 ms backward on the flipped bench graph.
+constexpr int AGG_HUB = 512;
 
 // SORTED: the messages are already in CSR (destination-sorted) order — row q of h IS position q of the CSR, so the
 // perm indirection disappears and consecutive destinations read consecutive rows (a pure stream).
 template <typename T, int VEC, bool SORTED>
 __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__ h, const int* __restrict__ rowptr,
                                                             const int* __restrict__ perm, T* __restrict__ agg, int N,
-                                                            int F) {
+                                                            int F, int* __restrict__ hub) {
   const int lpn = F / VEC;
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
@@ -207,6 +211,10 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
       long long ng = gid + stride;
       int nn = (int)((ng < total ? ng : gid) / lpn);
       ps = rowptr[nn]; pe = rowptr[nn + 1];
+    }
+    if (hub && e - s > AGG_HUB) {          // deferred to k_pna_aggregate_fwd_hub (one workgroup per hub destination)
+      if (c == 0) hub[1 + atomicAdd(hub, 1)] = n;
+      continue;
     }
     float s1[VEC], s2[VEC], mx[VEC], mn[VEC];
 #pragma unroll
@@ -269,6 +277,136 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
   }
 }
 
+// One 1024-thread workgroup per hub destination (4 channels per lane; groups of F/4 lanes take strided rows, four in
+// flight; the partial (sum, sum of squares, max, min) meet in LDS in group order: deterministic).
+template <typename T, bool SORTED>
+__global__ void __launch_bounds__(1024) k_pna_aggregate_fwd_hub(const T* __restrict__ h, const int* __restrict__ rowptr,
+                                                                 const int* __restrict__ perm, T* __restrict__ agg, int F,
+                                                                 const int* __restrict__ hub) {
+  constexpr int VEC = 4;
+  extern __shared__ float part[];                     // [groups][4][F]
+  const int lpn = F / VEC, groups = 1024 / lpn;
+  const int gi = threadIdx.x / lpn, c = (threadIdx.x % lpn) * VEC;
+  const int nh = hub[0];
+  for (int hIdx = blockIdx.x; hIdx < nh; hIdx += gridDim.x) {
+    const int n = hub[1 + hIdx];
+    const int s = rowptr[n], e = rowptr[n + 1];
+    if (gi < groups) {
+      float s1[VEC], s2[VEC], mx[VEC], mn[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; mx[j] = -INFINITY; mn[j] = INFINITY; }
+      for (int q = s + gi; q < e; q += groups * 4) {
+        float v[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int qq = q + u * groups < e ? q + u * groups : q;          // clamped: no load behind a branch
+          loadv<T, VEC>(h + (long long)(SORTED ? qq : perm[qq]) * F + c, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = q + u * groups < e;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            const float x = v[u][j];
+            s1[j] += ok ? x : 0.f; s2[j] += ok ? x * x : 0.f;
+            mx[j] = ok ? fmaxf(mx[j], x) : mx[j]; mn[j] = ok ? fminf(mn[j], x) : mn[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        part[(gi * 4 + 0) * F + c + j] = s1[j]; part[(gi * 4 + 1) * F + c + j] = s2[j];
+        part[(gi * 4 + 2) * F + c + j] = mx[j]; part[(gi * 4 + 3) * F + c + j] = mn[j];
+      }
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < F; f += 1024) {
+      float s1 = 0.f, s2 = 0.f, mx = -INFINITY, mn = INFINITY;
+      for (int g2 = 0; g2 < groups; ++g2) {
+        s1 += part[(g2 * 4 + 0) * F + f]; s2 += part[(g2 * 4 + 1) * F + f];
+        mx = fmaxf(mx, part[(g2 * 4 + 2) * F + f]); mn = fminf(mn, part[(g2 * 4 + 3) * F + f]);
+      }
+      const float cnt = (float)(e - s);
+      const float mean = s1 / cnt;
+      const float t = sqrtf(fmaxf(s2 / cnt - mean * mean, STD_EPS));
+      T* o = agg + (long long)n * 4 * F + f;
+      o[0] = from_f<T>(mean); o[F] = from_f<T>(mx); o[2 * F] = from_f<T>(mn);
+      o[3 * F] = from_f<T>(t <= sqrtf(STD_EPS) ? 0.f : t);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, bool SORTED>
+__global__ void __launch_bounds__(1024) k_pna_aggregate_bwd_hub(const T* __restrict__ h, const T* __restrict__ agg,
+                                                                 const T* __restrict__ dagg, const int* __restrict__ rowptr,
+                                                                 const int* __restrict__ perm, T* __restrict__ dh, int F,
+                                                                 const int* __restrict__ hub) {
+  constexpr int VEC = 4;
+  extern __shared__ float part[];                     // [groups][2][F] tie counts, then totals in part[0..2F)
+  const int lpn = F / VEC, groups = 1024 / lpn;
+  const int gi = threadIdx.x / lpn, c = (threadIdx.x % lpn) * VEC;
+  const int nh = hub[0];
+  for (int hIdx = blockIdx.x; hIdx < nh; hIdx += gridDim.x) {
+    const int n = hub[1 + hIdx];
+    const int s = rowptr[n], e = rowptr[n + 1];
+    const T* a = agg + (long long)n * 4 * F + c;
+    const T* d = dagg + (long long)n * 4 * F + c;
+    float mean[VEC], mx[VEC], mn[VEC], sd[VEC], gm[VEC], gx[VEC], gn[VEC], gs[VEC];
+    if (gi < groups) {
+      loadv<T, VEC>(a, mean); loadv<T, VEC>(a + F, mx); loadv<T, VEC>(a + 2 * F, mn); loadv<T, VEC>(a + 3 * F, sd);
+      loadv<T, VEC>(d, gm); loadv<T, VEC>(d + F, gx); loadv<T, VEC>(d + 2 * F, gn); loadv<T, VEC>(d + 3 * F, gs);
+      float tx[VEC], tn[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { tx[j] = 0.f; tn[j] = 0.f; }
+      for (int q = s + gi; q < e; q += groups * 4) {
+        float v[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int qq = q + u * groups < e ? q + u * groups : q;
+          loadv<T, VEC>(h + (long long)(SORTED ? qq : perm[qq]) * F + c, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = q + u * groups < e;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { tx[j] += (ok && v[u][j] == mx[j]); tn[j] += (ok && v[u][j] == mn[j]); }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { part[(gi * 2 + 0) * F + c + j] = tx[j]; part[(gi * 2 + 1) * F + c + j] = tn[j]; }
+    }
+    __syncthreads();
+    float totx = 0.f, totn = 0.f;                     // thread f < F sums the group counts of channel f
+    if ((int)threadIdx.x < F) {
+      for (int g2 = 0; g2 < groups; ++g2) { totx += part[(g2 * 2 + 0) * F + threadIdx.x]; totn += part[(g2 * 2 + 1) * F + threadIdx.x]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < F) { part[threadIdx.x] = totx; part[F + threadIdx.x] = totn; }
+    __syncthreads();
+    if (gi < groups) {
+      const float inv = 1.f / (float)(e - s);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        gm[j] *= inv;
+        gx[j] = gx[j] / fmaxf(part[c + j], 1.f);
+        gn[j] = gn[j] / fmaxf(part[F + c + j], 1.f);
+        gs[j] = sd[j] > 0.f ? gs[j] * inv / sd[j] : 0.f;
+      }
+      for (int q = s + gi; q < e; q += groups) {
+        const long long row = SORTED ? q : perm[q];
+        float v[VEC], o[VEC];
+        loadv<T, VEC>(h + row * F + c, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+          o[j] = gm[j] + (v[j] == mx[j] ? gx[j] : 0.f) + (v[j] == mn[j] ? gn[j] : 0.f) + gs[j] * (v[j] - mean[j]);
+        storev<T, VEC>(dh + row * F + c, o);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // backward: dh[e] = g_mean/cnt + [h==max] g_max/ties + [h==min] g_min/ties + g_std (h-mean)/(cnt*std)
 // (ties share the gradient evenly, as torch.scatter_reduce amax/amin backward does)
 // Destination-sorted messages, staged: a block owns NPB consecutive destinations, whose message rows are ONE contiguous
@@ -285,7 +423,8 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd(const T* __restrict__
 constexpr int AGG_NPB = 32;
 template <typename T, int VEC, int NPB>
 __global__ void __launch_bounds__(256) k_pna_aggregate_fwd_staged(const T* __restrict__ h, const int* __restrict__ rowptr,
-                                                                   T* __restrict__ agg, int N, int F, int cap_rows) {
+                                                                   T* __restrict__ agg, int N, int F, int cap_rows,
+                                                                   int* __restrict__ hub) {
   static_assert(NPB + 1 <= 256, "one thread per staged rowptr entry");
   extern __shared__ __align__(16) unsigned char agg_smem[];
   __shared__ int rp[NPB + 1];
@@ -314,6 +453,10 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_fwd_staged(const T* __res
   const int g = threadIdx.x / lpn, c = (threadIdx.x % lpn) * VEC;
   for (int i = g; i < nn; i += groups) {
     const int s = rp[i] - r0, e = rp[i + 1] - r0;
+    if (hub && e - s > AGG_HUB) {
+      if (c == 0) hub[1 + atomicAdd(hub, 1)] = n0 + i;
+      continue;
+    }
     float s1[VEC], s2[VEC], mx[VEC], mn[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; mx[j] = -INFINITY; mn[j] = INFINITY; }
@@ -375,7 +518,7 @@ template <typename T, int VEC, bool SORTED>
 __global__ void __launch_bounds__(256) k_pna_aggregate_bwd(const T* __restrict__ h, const T* __restrict__ agg,
                                                             const T* __restrict__ dagg, const int* __restrict__ rowptr,
                                                             const int* __restrict__ perm, T* __restrict__ dh, int N,
-                                                            int F) {
+                                                            int F, int* __restrict__ hub) {
   const int lpn = F / VEC;
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
@@ -384,6 +527,10 @@ __global__ void __launch_bounds__(256) k_pna_aggregate_bwd(const T* __restrict__
     int n = (int)(gid / lpn), c = (int)(gid % lpn) * VEC;
     int s = rowptr[n], e = rowptr[n + 1];
     if (e == s) continue;
+    if (hub && e - s > AGG_HUB) {
+      if (c == 0) hub[1 + atomicAdd(hub, 1)] = n;
+      continue;
+    }
     const T* a = agg + (long long)n * 4 * F + c;
     const T* d = dagg + (long long)n * 4 * F + c;
     float mean[VEC], mx[VEC], mn[VEC], sd[VEC], gm[VEC], gx[VEC], gn[VEC], gs[VEC];
@@ -555,17 +702,46 @@ extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, con
   return 0;
 }
 
+// hub_work: tg_segment_hub_ints(E) ints with hub_work[0] == 0 on entry, or NULL (then every destination is reduced by
+// one lane group).  The main launches only LIST the hub destinations; tg_pna_aggregate_hubs reduces them.
+static bool agg_hub_ok(int F) { return 1024 % (F / 4) == 0 && (size_t)(1024 / (F / 4)) * 4 * F * sizeof(float) <= 150 * 1024; }
+
+template <typename T> static void launch_agg_hub(bool fwd, const void* h, const void* agg, const void* dagg,
+                                                 const int32_t* rowptr, const int32_t* perm, void* out, int F,
+                                                 const int32_t* hub, hipStream_t st) {
+  const int groups = 1024 / (F / 4);
+  const size_t shm = (size_t)groups * (fwd ? 4 : 2) * F * sizeof(float);
+  if (fwd) {
+    if (perm) {
+      (void)hipFuncSetAttribute((const void*)k_pna_aggregate_fwd_hub<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_pna_aggregate_fwd_hub<T, false>), dim3(64), dim3(1024), shm, st, (const T*)h, rowptr, perm, (T*)out, F, hub);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_pna_aggregate_fwd_hub<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_pna_aggregate_fwd_hub<T, true>), dim3(64), dim3(1024), shm, st, (const T*)h, rowptr, perm, (T*)out, F, hub);
+    }
+  } else {
+    if (perm) {
+      (void)hipFuncSetAttribute((const void*)k_pna_aggregate_bwd_hub<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_pna_aggregate_bwd_hub<T, false>), dim3(64), dim3(1024), shm, st, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm, (T*)out, F, hub);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_pna_aggregate_bwd_hub<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      hipLaunchKernelGGL((k_pna_aggregate_bwd_hub<T, true>), dim3(64), dim3(1024), shm, st, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm, (T*)out, F, hub);
+    }
+  }
+}
+
 extern "C" int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const int32_t* perm, void* agg, int32_t N,
-                                    int32_t F, int64_t E, int32_t dt, void* stream) {
+                                    int32_t F, int64_t E, int32_t* hub_work, int32_t dt, void* stream) {
   TG_CHECK(F % 8 == 0 && N > 0, "tg_pna_aggregate_fwd: F must be a multiple of 8 (F=%d)", F);
+  hipStream_t st = (hipStream_t)stream;
+  if (hub_work && !agg_hub_ok(F)) hub_work = nullptr;
   if (dt == BF16 && !perm && 256 % (F / 4) == 0) {
     // destination-sorted bf16 messages: rows staged through LDS by blocks of 32 destinations, 8-byte lanes for the
     // reduction and the stores (2x the lanes per destination of 16-byte lanes: measured fastest on MI355X)
     const int tile_bytes = 16 * 1024;            // 8 blocks (all 32 waves) resident per CU; 64 rows at F=128
     const int cap_rows = tile_bytes / (F * 2);
     hipLaunchKernelGGL((k_pna_aggregate_fwd_staged<bf16_t, 4, AGG_NPB>), dim3(ceil_div((long long)N, AGG_NPB)),
-                       dim3(256), tile_bytes, (hipStream_t)stream, (const bf16_t*)h, rowptr, (bf16_t*)agg, N, F,
-                       cap_rows);
+                       dim3(256), tile_bytes, st, (const bf16_t*)h, rowptr, (bf16_t*)agg, N, F, cap_rows, hub_work);
     TG_LAUNCH_CHECK();
     return 0;
   }
@@ -573,29 +749,46 @@ extern "C" int tg_pna_aggregate_fwd(const void* h, const int32_t* rowptr, const 
     long long total = (long long)N * (F / VEC);
     if (perm)
       hipLaunchKernelGGL((k_pna_aggregate_fwd<T, VEC, false>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
-                         dim3(256), 0, (hipStream_t)stream, (const T*)h, rowptr, perm, (T*)agg, N, F);
+                         dim3(256), 0, st, (const T*)h, rowptr, perm, (T*)agg, N, F, hub_work);
     else
       hipLaunchKernelGGL((k_pna_aggregate_fwd<T, VEC, true>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
-                         dim3(256), 0, (hipStream_t)stream, (const T*)h, rowptr, perm, (T*)agg, N, F);
+                         dim3(256), 0, st, (const T*)h, rowptr, perm, (T*)agg, N, F, hub_work);
   })
   TG_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int tg_pna_aggregate_bwd(const void* h, const void* agg, const void* dagg, const int32_t* rowptr,
-                                    const int32_t* perm, void* dh, int32_t N, int32_t F, int32_t dt, void* stream) {
+                                    const int32_t* perm, void* dh, int32_t N, int32_t F, int32_t* hub_work, int32_t dt,
+                                    void* stream) {
   TG_CHECK(F % 8 == 0 && N > 0, "tg_pna_aggregate_bwd: F must be a multiple of 8 (F=%d)", F);
+  hipStream_t st = (hipStream_t)stream;
+  if (hub_work && !agg_hub_ok(F)) hub_work = nullptr;
   DISPATCH_T(dt, {
     long long total = (long long)N * (F / VEC);
     if (perm)
       hipLaunchKernelGGL((k_pna_aggregate_bwd<T, VEC, false>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
-                         dim3(256), 0, (hipStream_t)stream, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm,
-                         (T*)dh, N, F);
+                         dim3(256), 0, st, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm, (T*)dh, N, F,
+                         hub_work);
     else
       hipLaunchKernelGGL((k_pna_aggregate_bwd<T, VEC, true>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)),
-                         dim3(256), 0, (hipStream_t)stream, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm,
-                         (T*)dh, N, F);
+                         dim3(256), 0, st, (const T*)h, (const T*)agg, (const T*)dagg, rowptr, perm, (T*)dh, N, F,
+                         hub_work);
   })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// second pass over the destinations the main launch listed in hub_work (forward: dagg == dh == NULL, writes agg;
+// backward: writes dh)
+extern "C" int tg_pna_aggregate_hubs(const void* h, const void* agg, const void* dagg, const int32_t* rowptr,
+                                     const int32_t* perm, void* dh, int32_t F, const int32_t* hub_work, int32_t dt,
+                                     void* stream) {
+  TG_CHECK(F % 8 == 0 && hub_work, "tg_pna_aggregate_hubs: bad arguments (F=%d)", F);
+  if (!agg_hub_ok(F)) return 0;        // the main launch then handled every destination itself
+  const bool fwd = dh == nullptr;
+  if (dt == F32) launch_agg_hub<float>(fwd, h, agg, dagg, rowptr, perm, fwd ? const_cast<void*>(agg) : dh, F, hub_work, (hipStream_t)stream);
+  else launch_agg_hub<bf16_t>(fwd, h, agg, dagg, rowptr, perm, fwd ? const_cast<void*>(agg) : dh, F, hub_work, (hipStream_t)stream);
   TG_LAUNCH_CHECK();
   return 0;
 }

@@ -49,8 +49,9 @@ SIGNATURES = {
                           _i32, _vp],
     "tg_segment_hub_ints": [_i64],
     "tg_segment_sum2": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp],
-    "tg_pna_aggregate_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp],
-    "tg_pna_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_pna_aggregate_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp],
+    "tg_pna_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp],
+    "tg_pna_aggregate_hubs": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "tg_pna_scale_combine_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_pna_scale_combine_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -671,8 +671,11 @@ class _PNAAggregate(torch.autograd.Function):
             perm = None
         ctx.sorted_rows = sorted_rows
         agg = torch.empty(graph.N, 4 * F, dtype=h.dtype, device=h.device)
-        _launch("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rowptr), L.ptr(perm), L.ptr(agg), graph.N, F, E, L.dt(h),
-                L.stream())
+        hub = torch.zeros(L.load().tg_segment_hub_ints(max(E, 1)), dtype=torch.int32, device=h.device)
+        _launch("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rowptr), L.ptr(perm), L.ptr(agg), graph.N, F, E, L.ptr(hub),
+                L.dt(h), L.stream())
+        L.call("tg_pna_aggregate_hubs", L.ptr(h), L.ptr(agg), None, L.ptr(rowptr), L.ptr(perm), None, F, L.ptr(hub),
+               L.dt(h), L.stream())                     # destinations with > 512 rows (listed by the launch above)
         ctx.save_for_backward(h, agg)
         ctx.graph = graph
         return agg
@@ -684,8 +687,12 @@ class _PNAAggregate(torch.autograd.Function):
         if ctx.sorted_rows:
             perm = None
         dh = torch.empty_like(h)
-        _launch("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(g.contiguous()), L.ptr(rowptr), L.ptr(perm),
-                L.ptr(dh), ctx.graph.N, h.shape[1], L.dt(h), L.stream())
+        hub = torch.zeros(L.load().tg_segment_hub_ints(max(h.shape[0], 1)), dtype=torch.int32, device=h.device)
+        g = g.contiguous()
+        _launch("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(g), L.ptr(rowptr), L.ptr(perm),
+                L.ptr(dh), ctx.graph.N, h.shape[1], L.ptr(hub), L.dt(h), L.stream())
+        L.call("tg_pna_aggregate_hubs", L.ptr(h), L.ptr(agg), L.ptr(g), L.ptr(rowptr), L.ptr(perm), L.ptr(dh),
+               h.shape[1], L.ptr(hub), L.dt(h), L.stream())
         return dh, None, None
 
 

@@ -348,3 +348,33 @@ def test_encoder_layer_composite_equals_op_by_op_composition(T, C, H, dtype, p):
     for k in p1:      # bf16: sums over R*S rows of rounded products -> compare in the Frobenius norm
         rel = (p1[k] - p2[k]).norm().item() / max(p2[k].norm().item(), 1e-6)
         assert rel < (0.05 if dtype == torch.bfloat16 else 2e-4), (k, rel)
+
+
+@pytest.mark.parametrize("F,hubdeg", [(32, 3000), (128, 1500)])
+def test_pna_aggregate_hub_destinations(T, F, hubdeg):
+    """Destinations with more than 512 in-edges (reverse message passing makes the heavy-tailed sources destinations)
+    are reduced by a whole workgroup: forward and backward against the fp32 oracle, and bf16 sorted == indexed."""
+    from oracle.pna import multi_aggregate
+    torch.manual_seed(F)
+    N, E = 400, 6000
+    ei = _graph(N, E, 7)
+    ei[1, :hubdeg] = 11                                # one hub destination
+    ei[1, hubdeg:hubdeg + 600] = 12                    # and one just above the threshold
+    h = torch.randn(E, F)
+    h[3] = h[2]                                        # a tie on the hub (shared max/min gradient)
+    go = torch.randn(N, 4 * F)
+    hr = h.clone().requires_grad_(True)
+    ref, _ = multi_aggregate(hr, ei[1], N)
+    ref.backward(go)
+    g = T.ops.SubgraphIndex.build(ei.to(DEV), N)
+    hd = h.to(DEV).requires_grad_(True)
+    out = T.ops.pna_aggregate(hd, g)
+    out.backward(go.to(DEV))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-4)
+    close(hd.grad, hr.grad, 5e-4, 'dh')
+    hb = h.to(DEV).bfloat16()
+    perm = g.by_dst[1].long()
+    gob = go.to(DEV).bfloat16()
+    h1 = hb.clone().requires_grad_(True); a1 = T.ops.pna_aggregate(h1, g); a1.backward(gob)
+    h2 = hb[perm].contiguous().requires_grad_(True); a2 = T.ops.pna_aggregate(h2, g, sorted_rows=True); a2.backward(gob)
+    assert torch.equal(a1, a2) and torch.equal(h1.grad[perm], h2.grad)

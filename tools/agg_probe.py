@@ -12,10 +12,10 @@ for dt, b in ((torch.bfloat16, 2), (torch.float32, 4)):
     h = torch.randn(E, F, device=dev, dtype=dt)
     agg = torch.empty(N, 4 * F, device=dev, dtype=dt); dagg = torch.randn_like(agg); dh = torch.empty_like(h)
     rp, pm = g.by_dst
-    def f(): L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rp), L.ptr(pm), L.ptr(agg), N, F, E, L.dt(h), L.stream())
-    def bw(): L.call("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(dagg), L.ptr(rp), L.ptr(pm), L.ptr(dh), N, F, L.dt(h), L.stream())
-    def fs(): L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rp), None, L.ptr(agg), N, F, E, L.dt(h), L.stream())
-    def bws(): L.call("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(dagg), L.ptr(rp), None, L.ptr(dh), N, F, L.dt(h), L.stream())
+    def f(): L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rp), L.ptr(pm), L.ptr(agg), N, F, E, None, L.dt(h), L.stream())
+    def bw(): L.call("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(dagg), L.ptr(rp), L.ptr(pm), L.ptr(dh), N, F, None, L.dt(h), L.stream())
+    def fs(): L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(rp), None, L.ptr(agg), N, F, E, None, L.dt(h), L.stream())
+    def bws(): L.call("tg_pna_aggregate_bwd", L.ptr(h), L.ptr(agg), L.ptr(dagg), L.ptr(rp), None, L.ptr(dh), N, F, None, L.dt(h), L.stream())
     for name, fn, nbytes in (("fwd", f, E * (F * b + 4) + N * 4 * F * b), ("bwd", bw, E * (2 * F * b + 4) + 2 * N * 4 * F * b),
                              ("fwd SORTED", fs, E * (F * b + 4) + N * 4 * F * b), ("bwd SORTED", bws, E * (2 * F * b + 4) + 2 * N * 4 * F * b)):
         for _ in range(3): fn()
@@ -31,7 +31,7 @@ for dt, b in ((torch.bfloat16, 2), (torch.float32, 4)):
 z = torch.zeros(N + 1, dtype=torch.int32, device=dev)
 for dt, b in ((torch.bfloat16, 2), (torch.float32, 4)):
     h = torch.randn(E, F, device=dev, dtype=dt); agg = torch.empty(N, 4 * F, device=dev, dtype=dt)
-    def f0(): L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(z), L.ptr(g.by_dst[1]), L.ptr(agg), N, F, E, L.dt(h), L.stream())
+    def f0(): L.call("tg_pna_aggregate_fwd", L.ptr(h), L.ptr(z), L.ptr(g.by_dst[1]), L.ptr(agg), N, F, E, None, L.dt(h), L.stream())
     for _ in range(3): f0()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
