@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch-size", type=int, default=256)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--reverse-mp", action="store_true", help="PNAConvHetero (forward + reverse message passing); "
+                    "not the BASELINE configuration")
     ap.add_argument("--no-e2e", action="store_true", help="skip the sampling-inclusive loop reported beside `value`")
     ap.add_argument("--e2e-steps", type=int, default=8)
     return ap.parse_args()
@@ -200,6 +202,7 @@ def main():
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     torch.manual_seed(1234)
     cfg = S.make_config(args.hidden, args.layers, args.nhead, args.batch_size, compute_dtype=cdt)
+    cfg["reverse_mp"] = bool(args.reverse_mp)
     model = T.TABGNNFusedS(cfg).to(dev).train()
     flat = T.FlatParams(model, shadow_dtype=cdt)
     opt = T.FusedAdam(flat, lr=cfg["lr"])
@@ -269,7 +272,7 @@ def main():
         "config": {"workload": f"HI-Small-shaped AML sampled subgraphs, fused supervised (configs[1]): d={args.hidden}, "
                                f"{args.nhead}-head FT-Transformer + {args.layers}-layer PNA, B={args.batch_size} seed "
                                f"edges/step/GPU, E={int(E_mean)} sampled edges, N={int(N_mean)} nodes, 5 edge columns "
-                               f"(3 cat, 1 num, 1 ts), dropout 0.5/0.083, Adam",
+                               f"(3 cat, 1 num, 1 ts), dropout 0.5/0.083, Adam" + (", reverse_mp" if args.reverse_mp else ""),
                    "batch_size": args.batch_size, "edges_per_step": int(E_mean), "nodes_per_step": int(N_mean),
                    "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}"},
         "roofline": {"kernel": "k_pna_aggregate_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
