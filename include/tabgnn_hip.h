@@ -154,6 +154,17 @@ int tg_pna_scale_combine_fwd(const void* xw, const void* G /*[N,3F]*/, const int
                              void* out, int32_t N, int32_t F, int32_t dt, void* stream);
 int tg_pna_scale_combine_bwd(const void* gout, const int32_t* rowptr, const float* avg_log, void* dG, int32_t N,
                              int32_t F, int32_t dt, void* stream);
+/* GINEConv aggregation (src/nn/gnn/gine.py:18-19,62-72 through torch_geometric 2.5.3 GINEConv.forward/message):
+ * out[n] = self_scale*x[n] + sum_{e: dst[e]=n} relu(x[src[e]] + le[e]), le = lin(edge_attr) [E,F]; rowptr/perm = the
+ * stable by-destination CSR (tg_csr_build); self_scale = 1+eps, or 0 for the (x, None) form of GINEConvHetero
+ * (gine.py:31-32).  hub_work: tg_segment_hub_ints(E) ints (destinations with > 256 rows get a block each). */
+int tg_gine_aggregate_fwd(const void* x, const void* le, const int32_t* src, const int32_t* rowptr,
+                          const int32_t* perm, float self_scale, void* out, int32_t N, int32_t F, int32_t* hub_work,
+                          int32_t dt, void* stream);
+/* its message gradient: dle[e] = (x[src[e]] + le[e] > 0) ? dout[dst[e]] : 0; dx is then the by-source
+ * tg_segment_sum2 of dle (+ self_scale*dout). */
+int tg_gine_message_bwd(const void* x, const void* le, const void* dout, const int32_t* src, const int32_t* dst,
+                        void* dle, int64_t E, int32_t F, int32_t dt, void* stream);
 /* seed-endpoint pooling of the fused layer, fused.py:261-268 (unique / index_add_ / bincount / mean) */
 int tg_seed_pool_fwd(const void* x, const void* xf, const int32_t* rowptr, const int32_t* perm, void* out, int32_t N,
                      int32_t F, int32_t B, int32_t C, int32_t dt, void* stream);

@@ -31,6 +31,12 @@ int tg_sampler_sample(void* handle, const int64_t* seed_src, const int64_t* seed
 int tg_negative_sample(const int64_t* src, const int64_t* dst, int64_t E, const int64_t* pos_src,
                        const int64_t* pos_dst, int64_t B, int32_t num_neg_samples, uint64_t seed, int32_t num_threads,
                        int64_t* out_src, int64_t* out_dst);
+/* Port numbering: replaces to_adj_nodes_with_times + ports + add_ports
+ * (src/datasets/util/graph.py:68-101).  in_port[e]: rank of src[e] among the distinct in-neighbours of dst[e] ordered
+ * by earliest timestamp; out_port[e]: rank of dst[e] among the distinct out-neighbours of src[e].  ts may be NULL
+ * (all zero, graph.py:70); equal timestamps are ordered by edge position. */
+int tg_edge_ports(const int64_t* src, const int64_t* dst, const int64_t* ts, int64_t E, int64_t num_nodes,
+                  int32_t num_threads, int32_t* in_port, int32_t* out_port);
 #ifdef __cplusplus
 }
 #endif

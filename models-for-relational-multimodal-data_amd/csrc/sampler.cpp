@@ -322,4 +322,58 @@ int tg_negative_sample(const int64_t* src, const int64_t* dst, int64_t E, const 
   return 0;
 }
 
+// Port numbering of a multigraph (src/datasets/util/graph.py:68-101: to_adj_nodes_with_times + ports + add_ports, an
+// O(E) Python dict/.numpy() loop per edge there).  in_port[e] of edge e = (u -> v): rank of u among the DISTINCT
+// in-neighbours of v ordered by their earliest timestamp on an edge into v; out_port[e]: rank of v among the distinct
+// out-neighbours of u ordered by earliest timestamp (graph.py:99-100: the second call runs on the flipped edge_index
+// with the out-adjacency).  Equal timestamps are ordered by edge position (the reference's np.argsort default is not
+// a stable sort, so its order among ties is unspecified; with distinct timestamps the two agree exactly).
+// ts == NULL: all timestamps 0 (graph.py:70).  One node at a time per thread, per-thread stamp arrays, no hashing.
+int tg_edge_ports(const int64_t* src, const int64_t* dst, const int64_t* ts, int64_t E, int64_t num_nodes,
+                  int32_t num_threads, int32_t* in_port, int32_t* out_port) {
+  if (E < 0 || num_nodes < 0 || (E > 0 && (!src || !dst || !in_port || !out_port))) {
+    snprintf(g_err, sizeof(g_err), "tg_edge_ports: bad arguments (E=%lld, num_nodes=%lld)", (long long)E, (long long)num_nodes);
+    return 1;
+  }
+  for (int64_t e = 0; e < E; ++e)
+    if (src[e] < 0 || dst[e] < 0 || src[e] >= num_nodes || dst[e] >= num_nodes) {
+      snprintf(g_err, sizeof(g_err), "tg_edge_ports: edge %lld has a node id outside [0, %lld)", (long long)e, (long long)num_nodes);
+      return 1;
+    }
+#ifdef _OPENMP
+  const int nthreads = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  const int nthreads = 1;
+#endif
+  for (int dir = 0; dir < 2; ++dir) {
+    const int64_t* key = dir == 0 ? dst : src;       // the node whose ports are numbered
+    const int64_t* nbr = dir == 0 ? src : dst;       // the neighbour that receives a port at that node
+    int32_t* out = dir == 0 ? in_port : out_port;
+    std::vector<int64_t> ptr((size_t)num_nodes + 1, 0);
+    for (int64_t e = 0; e < E; ++e) ptr[(size_t)key[e] + 1]++;
+    for (int64_t v = 0; v < num_nodes; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
+    std::vector<int64_t> eids((size_t)E), cur(ptr.begin(), ptr.end() - 1);
+    for (int64_t e = 0; e < E; ++e) eids[(size_t)cur[(size_t)key[e]]++] = e;     // edge order within a node
+#pragma omp parallel num_threads(nthreads) if (E >= 65536)
+    {
+      std::vector<int64_t> owner((size_t)num_nodes, -1);   // owner[u] == v  <=>  u already has a port at v
+      std::vector<int32_t> port((size_t)num_nodes, 0);
+#pragma omp for schedule(dynamic, 256)
+      for (int64_t v = 0; v < num_nodes; ++v) {
+        int64_t* b = eids.data() + ptr[(size_t)v];
+        int64_t* e_ = eids.data() + ptr[(size_t)v + 1];
+        if (b == e_) continue;
+        if (ts) std::stable_sort(b, e_, [&](int64_t a, int64_t c) { return ts[a] < ts[c]; });
+        int32_t next = 0;
+        for (int64_t* q = b; q < e_; ++q) {
+          const int64_t u = nbr[*q];
+          if (owner[(size_t)u] != v) { owner[(size_t)u] = v; port[(size_t)u] = next++; }
+          out[*q] = port[(size_t)u];
+        }
+      }
+    }
+  }
+  return 0;
+}
+
 }  // extern "C"

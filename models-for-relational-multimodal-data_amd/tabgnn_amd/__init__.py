@@ -13,8 +13,8 @@ from .encoders import (EmbeddingEncoder, LinearEncoder, ProjectionEncoder,  # no
 from .frame import TensorFrame, stype  # noqa: E402
 from .heads import ClassifierHead, LinkPredHead, MCMHead, NodeClassificationHead, SelfSupervisedHead  # noqa: E402
 from .losses import SSLoss  # noqa: E402
-from .layers import BatchNorm, ColumnTransformerLayer, PNAConv, PNAConvHetero  # noqa: E402
-from .models import (CPNA, PNAS, TABGNN, FTTransformerLayer, FTTransformerPNAFusedLayer,  # noqa: E402
+from .layers import BatchNorm, ColumnTransformerLayer, GINEConv, GINEConvHetero, PNAConv, PNAConvHetero  # noqa: E402
+from .models import (CPNA, PNAS, TABGNN, GINe, FTTransformerLayer, FTTransformerPNAFusedLayer,  # noqa: E402
                      FTTransformerPNAInterleavedLayer, PNALayer, TABGNNFused, TABGNNInterleaved)
 from .train import DataParallel, FlatParams, FusedAdam, train_step  # noqa: E402
 from .wrappers import GNN, TABGNNFusedS, TABGNNS, degree_histogram  # noqa: E402

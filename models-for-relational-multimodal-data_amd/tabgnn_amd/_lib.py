@@ -54,6 +54,8 @@ SIGNATURES = {
     "tg_pna_aggregate_hubs": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "tg_pna_scale_combine_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_pna_scale_combine_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_gine_aggregate_fwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _i32, _vp],
+    "tg_gine_message_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "tg_seed_pool_inplace": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "tg_seed_pool_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

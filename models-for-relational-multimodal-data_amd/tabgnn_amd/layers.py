@@ -4,6 +4,7 @@
   dim_feedforward, dropout, 'relu', batch_first=True)`` as built at ``src/nn/models/fused.py:83-92,187-196``.
 * ``PNAConv`` / ``BatchNorm`` — state-dict compatible with torch_geometric 2.5.3 (``fused.py:204-214``).
 * ``PNAConvHetero`` — ``src/nn/gnn/pna.py:17-46``.
+* ``GINEConv`` / ``GINEConvHetero`` — torch_geometric 2.5.3 ``GINEConv(nn, edge_dim=...)`` and ``src/nn/gnn/gine.py:15-35``.
 """
 from __future__ import annotations
 
@@ -189,4 +190,62 @@ class PNAConvHetero(nn.Module):
         g = ops.SubgraphIndex.build(edge_index, x.shape[0])
         a_in = self.conv_forw(x, g, edge_attr)
         a_out = self.conv_back(x, g.flip(), edge_attr)
+        return self.lin(torch.cat([x, a_in, a_out], dim=1))
+
+
+class GINEConv(nn.Module):
+    """``GINEConv(nn, edge_dim=F)`` (torch_geometric 2.5.3; built at ``src/nn/gnn/gine.py:62-72``):
+    ``nn((1+eps)*x_i + sum_j relu(x_j + lin(e_ji)))``, state-dict ``nn.*``, ``lin.*`` and the ``eps`` buffer (train_eps=False).
+    ``self_term=False`` is the ``(x, None)`` call of ``GINEConvHetero`` (gine.py:31-32): no ``(1+eps)*x_i`` term."""
+
+    def __init__(self, nn_seq, eps=0.0, train_eps=False, edge_dim=None):
+        super().__init__()
+        if (train_eps or edge_dim is None or not isinstance(nn_seq, nn.Sequential) or len(nn_seq) != 3
+                or not isinstance(nn_seq[0], nn.Linear) or not isinstance(nn_seq[1], nn.ReLU)
+                or not isinstance(nn_seq[2], nn.Linear)):
+            raise ValueError("GINEConv: only the reference's configuration (Linear-ReLU-Linear network, edge_dim given, "
+                             "fixed eps; gine.py:62-72) is implemented")
+        self.nn = nn_seq
+        self.initial_eps = eps
+        self.register_buffer("eps", torch.full((1,), float(eps)))
+        self.lin = nn.Linear(edge_dim, nn_seq[0].in_features)
+
+    def reset_parameters(self):
+        for m in (self.nn[0], self.nn[2], self.lin):
+            m.reset_parameters()
+        self.eps.fill_(self.initial_eps)
+
+    def _eps_value(self):
+        """Host copy of the ``eps`` buffer, re-read only when the buffer object or its version changes (a checkpoint
+        may carry a different eps; one device read per load, none per step)."""
+        key = (id(self.eps), self.eps._version)
+        if getattr(self, "_eps_key", None) != key:
+            self._eps_key, self._eps_host = key, float(self.eps)
+        return self._eps_host
+
+    def forward(self, x, edge_index, edge_attr, self_term=True):
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        le = ops.linear(edge_attr, self.lin.weight, self.lin.bias)
+        out = ops.gine_aggregate(x, le, g, 1.0 + self._eps_value() if self_term else 0.0)
+        return ops.mlp_relu(out, self.nn[0], self.nn[2])
+
+
+class GINEConvHetero(nn.Module):
+    """Forward + reverse message passing (src/nn/gnn/gine.py:15-35)."""
+
+    def __init__(self, network, n_hidden):
+        super().__init__()
+        self.conv_forw = GINEConv(network, edge_dim=n_hidden)
+        self.conv_back = GINEConv(network, edge_dim=n_hidden)      # the SAME network object, as gine.py:18-19: shared weights
+        self.lin = Linear(n_hidden * 3, n_hidden)
+
+    def reset_parameters(self):
+        self.conv_forw.reset_parameters()
+        self.conv_back.reset_parameters()
+        self.lin.reset_parameters()
+
+    def forward(self, x, edge_index, edge_attr):
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        a_in = self.conv_forw(x, g, edge_attr, self_term=False)
+        a_out = self.conv_back(x, g.flip(), edge_attr, self_term=False)
         return self.lin(torch.cat([x, a_in, a_out], dim=1))

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .layers import BatchNorm, ColumnTransformerLayer, PNAConv, PNAConvHetero
+from .layers import BatchNorm, ColumnTransformerLayer, GINEConv, GINEConvHetero, PNAConv, PNAConvHetero
 
 _AGGR = ["mean", "max", "min", "std"]
 _SCAL = ["identity", "amplification", "attenuation"]
@@ -425,3 +425,35 @@ class CPNA(nn.Module):
                     col = ops.axpby(col, ops.mlp_relu(ops.edge_gather(x, col, g, "src"), mlp[0], mlp[2]), 1.0, 0.5)
             cols.append(col)
         return x, torch.stack(cols, dim=1)
+
+
+class GINe(nn.Module):
+    """``GINe`` (``src/nn/gnn/gine.py:37-115``), ``--model gin``: node/edge embeddings then L x {GINEConv (sum of
+    ``relu(x_j + lin(e))`` messages, Linear-ReLU-Linear network) + BatchNorm + residual average; edge update
+    ``e + MLP/2``}.  Parameter names ``node_emb, edge_emb, convs.{i}, emlps.{i}, batch_norms.{i}``; with ``reverse_mp``
+    the two directions of a layer share ONE network object as the reference does (gine.py:18-19)."""
+
+    def __init__(self, num_features=1, num_gnn_layers=2, n_hidden=100, edge_updates=False, edge_dim=None,
+                 reverse_mp=False):
+        super().__init__()
+        self.n_hidden, self.num_gnn_layers, self.edge_updates, self.reverse_mp = n_hidden, num_gnn_layers, edge_updates, reverse_mp
+        self.node_emb = nn.Linear(num_features, n_hidden)
+        self.edge_emb = nn.Linear(edge_dim, n_hidden)
+        self.convs, self.emlps, self.batch_norms = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for _ in range(num_gnn_layers):
+            net = nn.Sequential(nn.Linear(n_hidden, n_hidden), nn.ReLU(), nn.Linear(n_hidden, n_hidden))
+            conv = GINEConvHetero(net, n_hidden=n_hidden) if reverse_mp else GINEConv(net, edge_dim=n_hidden)
+            if edge_updates:
+                self.emlps.append(nn.Sequential(nn.Linear(3 * n_hidden, n_hidden), nn.ReLU(), nn.Linear(n_hidden, n_hidden)))
+            self.convs.append(conv)
+            self.batch_norms.append(BatchNorm(n_hidden))
+
+    def forward(self, x, edge_index, edge_attr):
+        g = ops.SubgraphIndex.build(edge_index, x.shape[0])
+        x = ops.linear(x.reshape(x.shape[0], -1), self.node_emb.weight, self.node_emb.bias)
+        e = ops.linear(edge_attr.reshape(edge_attr.shape[0], -1), self.edge_emb.weight, self.edge_emb.bias)
+        for i in range(self.num_gnn_layers):
+            x = self.batch_norms[i](self.convs[i](x, g, e), res=x, relu=True, alpha=0.5, beta_c=0.5)
+            if self.edge_updates:
+                e = ops.axpby(e, ops.mlp_relu(ops.edge_gather(x, e, g, "src"), self.emlps[i][0], self.emlps[i][2]), 1.0, 0.5)
+        return x, e

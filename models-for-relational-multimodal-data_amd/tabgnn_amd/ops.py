@@ -729,6 +729,46 @@ def pna_scale_combine(xw, G, graph, avg_log):
     return _ScaleCombine.apply(xw, G, graph, avg_log)
 
 
+class _GINEAggregate(torch.autograd.Function):
+    """out[n] = self_scale*x[n] + sum_{e: dst[e]=n} relu(x[src[e]] + le[e])  (GINEConv.propagate + the (1+eps)*x_r term,
+    src/nn/gnn/gine.py:18-19 through torch_geometric GINEConv); the [E,F] message tensor never exists."""
+
+    @staticmethod
+    def forward(ctx, x, le, graph, self_scale):
+        x, le = x.contiguous(), le.contiguous()
+        N, F = x.shape
+        out = torch.empty_like(x)
+        rowptr, perm = graph.by_dst
+        hub = torch.empty(L.load().tg_segment_hub_ints(max(graph.E, 1)), dtype=torch.int32, device=x.device)
+        _launch("tg_gine_aggregate_fwd", L.ptr(x), L.ptr(le), L.ptr(graph.src), L.ptr(rowptr), L.ptr(perm),
+                float(self_scale), L.ptr(out), N, F, L.ptr(hub), L.dt(x), L.stream())
+        ctx.save_for_backward(x, le)
+        ctx.graph, ctx.self_scale = graph, float(self_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, le = ctx.saved_tensors
+        graph = ctx.graph
+        g = g.contiguous()
+        N, F = x.shape
+        dle = torch.empty_like(le)
+        L.call("tg_gine_message_bwd", L.ptr(x), L.ptr(le), L.ptr(g), L.ptr(graph.src), L.ptr(graph.dst), L.ptr(dle),
+               graph.E, F, L.dt(x), L.stream())
+        dx = torch.empty_like(x)
+        hub = torch.empty(L.load().tg_segment_hub_ints(max(graph.E, 1)), dtype=torch.int32, device=x.device)
+        L.call("tg_segment_sum2", L.ptr(dle), F, 0, L.ptr(graph.by_src[0]), L.ptr(graph.by_src[1]), 0, None, None, 0,
+               None, L.ptr(dx), N, F, L.ptr(hub), L.dt(x), L.stream())
+        if ctx.self_scale != 0.0:
+            L.call("tg_axpby", L.ptr(dx), L.ptr(g), L.ptr(dx), dx.numel(), 1.0, ctx.self_scale, L.dt(dx), L.stream())
+        return dx, dle, None, None
+
+
+def gine_aggregate(x, le, graph, self_scale=1.0):
+    """x [N,F], le [E,F] (edge embeddings through GINEConv.lin, edge order) -> [N,F]."""
+    return _GINEAggregate.apply(x, le, graph, self_scale)
+
+
 # --------------------------------------------------------------------------- fused-layer tail: CLS merge + pooling
 
 

@@ -200,3 +200,56 @@ def generate_negative_samples(edge_index, pos_edge_index, num_neg_samples, seed=
     if rc != 0:
         raise RuntimeError(lib.tg_sampler_last_error().decode())
     return torch.from_numpy(out)
+
+
+def edge_ports(edge_index, timestamps=None, num_nodes=None, num_threads=0):
+    """Port numbers of every edge: replaces ``to_adj_nodes_with_times`` + ``ports`` + the two calls of ``add_ports``
+    (``src/datasets/util/graph.py:68-101``; 22 s of Python on the reference's dummy file).  Returns
+    ``(in_ports, out_ports)`` as float32 ``[E, 1]`` tensors like the reference's ``ports`` (graph.py:82)."""
+    lib = _load()
+    if not hasattr(lib.tg_edge_ports, "_bound"):
+        i64p, i32p = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        lib.tg_edge_ports.argtypes = [i64p, i64p, i64p, C.c_int64, C.c_int64, C.c_int32, i32p, i32p]
+        lib.tg_edge_ports.restype = C.c_int
+        lib.tg_edge_ports._bound = True
+    as_np = lambda a: np.ascontiguousarray(a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a), dtype=np.int64)
+    ei = as_np(edge_index)
+    if ei.ndim != 2 or ei.shape[0] != 2:
+        raise ValueError("edge_index must be [2, E]")
+    E = ei.shape[1]
+    N = int(num_nodes) if num_nodes is not None else (int(ei.max()) + 1 if E else 0)
+    src, dst = np.ascontiguousarray(ei[0]), np.ascontiguousarray(ei[1])
+    ts = None
+    if timestamps is not None:
+        ts = as_np(timestamps).reshape(-1)          # graph.py:72,75: int(t)
+        if ts.shape[0] != E:
+            raise ValueError("timestamps must hold one value per edge")
+    inp, outp = np.empty(E, dtype=np.int32), np.empty(E, dtype=np.int32)
+    p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = lib.tg_edge_ports(_p64(src), _p64(dst), _p64(ts) if ts is not None else None, E, N, int(num_threads),
+                           p32(inp), p32(outp))
+    if rc != 0:
+        raise ValueError(lib.tg_sampler_last_error().decode())
+    f = lambda a: torch.from_numpy(a.astype(np.float32)).reshape(-1, 1)
+    return f(inp), f(outp)
+
+
+def add_ego_ids(x, seed_edge_index, column="EgoID"):
+    """``add_EgoIDs`` (src/datasets/util/graph.py:121-145): the ``EgoID`` relation column of the node frame is 1 for
+    the endpoints of the seed edges and 0 elsewhere; written in place on the frame's device, no ``unique``."""
+    from .frame import stype
+    rel = x.feat_dict[stype.relation]
+    idx = x.col_names_dict[stype.relation].index(column)
+    rel[:, idx] = 0
+    rel[seed_edge_index.reshape(-1).to(rel.device), idx] = 1
+    return x
+
+
+def add_ego_ids_from_nodes(x, batch_size, column="EgoID"):
+    """``add_EgoIDs_from_nodes`` (graph.py:110-119): the first ``batch_size`` node rows are the seeds."""
+    from .frame import stype
+    rel = x.feat_dict[stype.relation]
+    idx = x.col_names_dict[stype.relation].index(column)
+    rel[:, idx] = 0
+    rel[:batch_size, idx] = 1
+    return x

@@ -10,7 +10,7 @@ from torch import nn
 
 from . import ops
 from .heads import ClassifierHead, NodeClassificationHead
-from .models import CPNA, PNAS, TABGNN, TABGNNFused, TABGNNInterleaved
+from .models import CPNA, PNAS, TABGNN, GINe, TABGNNFused, TABGNNInterleaved
 
 
 def degree_histogram(in_degrees):
@@ -108,10 +108,10 @@ class TABGNNS(nn.Module):
 
 
 class GNN(nn.Module):
-    """``utils.py:111-233`` for ``--model pna`` (``PNAS``) and ``--model cpna`` (``CPNA``: the head then sees all
-    ``num_edge_features`` column embeddings of a seed edge, ``e_hidden = ncols * n_hidden``, :120-122,142-144):
-    encoders -> backbone -> head on the first ``batch_size`` (seed) edges, or on the nodes.  Not built: gin, cpnatab
-    (whose reference forward returns nothing, pna.py:285-302)."""
+    """``utils.py:111-233`` for ``--model gin`` (``GINe``), ``--model pna`` (``PNAS``) and ``--model cpna`` (``CPNA``: the
+    head then sees all ``num_edge_features`` column embeddings of a seed edge, ``e_hidden = ncols * n_hidden``,
+    :120-122,142-144): encoders -> backbone -> head on the first ``batch_size`` (seed) edges, or on the nodes.  Not
+    built: cpnatab (whose reference forward returns nothing, pna.py:285-302)."""
 
     def __init__(self, config):
         super().__init__()
@@ -120,16 +120,22 @@ class GNN(nn.Module):
         self.node_encoder = config["node_encoder"]
         self.edge_encoder = config["edge_encoder"]
         name = config.get("model", "pna")
-        if name not in ("pna", "cpna"):
+        if name not in ("gin", "pna", "cpna"):
             raise ValueError("Invalid model name!")
-        if config.get("in_degrees") is None:
-            raise ValueError("In degrees are not provided for PNA model!")
         n_dim = config["num_node_features"] * config["n_hidden"]
         e_dim = config["num_edge_features"] * config["n_hidden"]
-        cls = PNAS if name == "pna" else CPNA
-        self.model = cls(num_features=n_dim, n_hidden=config["n_hidden"], num_gnn_layers=config["n_gnn_layers"],
-                         edge_dim=e_dim, deg=degree_histogram(config["in_degrees"]),
-                         edge_updates=config.get("emlps", True), reverse_mp=config.get("reverse_mp", False))
+        if name == "gin":      # utils.py:170-175 passes num_features=n_feats, which cannot multiply the encoders'
+            # [N, n_feats*n_hidden] node rows; the flattened width is used here so the route runs
+            self.model = GINe(num_features=n_dim, num_gnn_layers=config["n_gnn_layers"], n_hidden=config["n_hidden"],
+                              edge_updates=config.get("emlps", True), edge_dim=e_dim,
+                              reverse_mp=config.get("reverse_mp", False))
+        else:
+            if config.get("in_degrees") is None:
+                raise ValueError("In degrees are not provided for PNA model!")
+            cls = PNAS if name == "pna" else CPNA
+            self.model = cls(num_features=n_dim, n_hidden=config["n_hidden"], num_gnn_layers=config["n_gnn_layers"],
+                             edge_dim=e_dim, deg=degree_histogram(config["in_degrees"]),
+                             edge_updates=config.get("emlps", True), reverse_mp=config.get("reverse_mp", False))
         self.cpna = name == "cpna"
         if config["task"] == "edge_classification":
             e_hidden = config["num_edge_features"] * config["n_hidden"] if self.cpna else None

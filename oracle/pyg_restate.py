@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+from . import gine as G
 from . import pna as P
 
 
@@ -64,3 +65,29 @@ class BatchNorm(nn.Module):
 
     def forward(self, x):
         return self.module(x)
+
+
+class GINEConv(nn.Module):
+    """``torch_geometric.nn.GINEConv(nn, eps=0., train_eps=False, edge_dim=...)`` face over ``oracle.gine.gine_conv``."""
+
+    def __init__(self, nn_, eps=0.0, train_eps=False, edge_dim=None, **kw):
+        super().__init__()
+        assert not train_eps and edge_dim is not None
+        self.nn = nn_
+        self.initial_eps = eps
+        self.register_buffer("eps", torch.full((1,), float(eps)))
+        first = nn_[0] if isinstance(nn_, nn.Sequential) else nn_
+        self.lin = Linear(edge_dim, first.in_features)
+
+    def reset_parameters(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                m.reset_parameters()
+        self.eps.fill_(self.initial_eps)
+
+    def forward(self, x, edge_index, edge_attr=None):
+        self_term = True
+        if isinstance(x, tuple):
+            x, x_r = x
+            self_term = x_r is not None
+        return G.gine_conv(x, edge_index, edge_attr, dict(self.state_dict(keep_vars=True)), "", self_term)

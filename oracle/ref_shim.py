@@ -4,9 +4,9 @@ Only ``tests/golden/make_golden.py`` uses this, and only where ``/root/reference
 (never on the GPU box).  Technique recorded in SURVEY.md §8c: the package ``__init__`` files
 import datasets/LLM code that cannot load here, so ``src``, ``src.nn``, ``src.nn.models`` and
 ``src.nn.gnn`` are pre-registered as bare namespace modules, and the two absent third-party
-packages are represented by ``oracle.pyg_restate`` (``PNAConv``/``BatchNorm``/``Linear`` — parity
+packages are represented by ``oracle.pyg_restate`` (``PNAConv``/``GINEConv``/``BatchNorm``/``Linear`` — parity
 unpinned) plus a type-annotation-only ``StypeWiseFeatureEncoder`` name.  The reference's
-``fused.py``, ``tabgnn.py``, ``pna.py``, ``decoder.py``, ``src/nn/decoder/self_supervised.py`` and
+``fused.py``, ``tabgnn.py``, ``pna.py``, ``gine.py``, ``decoder.py``, ``src/nn/decoder/self_supervised.py`` and
 ``src/utils/loss.py`` then execute unmodified.
 """
 from __future__ import annotations
@@ -35,7 +35,7 @@ def load_reference():
     from . import pyg_restate as R
 
     tg = _ns("torch_geometric"); tgn = _ns("torch_geometric.nn")
-    tgn.PNAConv, tgn.BatchNorm, tgn.Linear = R.PNAConv, R.BatchNorm, R.Linear
+    tgn.PNAConv, tgn.BatchNorm, tgn.Linear, tgn.GINEConv = R.PNAConv, R.BatchNorm, R.Linear, R.GINEConv
     tg.nn = tgn
     dense = _ns("torch_geometric.nn.dense"); lin = _ns("torch_geometric.nn.dense.linear"); lin.Linear = R.Linear
     tgn.dense = dense; dense.linear = lin
@@ -58,8 +58,25 @@ def load_reference():
     spec = importlib.util.spec_from_file_location("tabgnn_ref_loss", f"{REF}/src/utils/loss.py")   # pure torch file
     loss = importlib.util.module_from_spec(spec); spec.loader.exec_module(loss)
     inter = importlib.import_module("src.nn.models.inteleaved")
-    extra = {"TABGNNInterleaved": inter.TABGNNInterleaved, "PNAS": pna.PNAS, "CPNA": pna.CPNA, "LinkPredHead": dec.LinkPredHead, "MCMHead": ssl.MCMHead, "SelfSupervisedHead": ssl.SelfSupervisedHead,
+    gine = importlib.import_module("src.nn.gnn.gine")
+    extra = {"GINe": gine.GINe, "TABGNNInterleaved": inter.TABGNNInterleaved, "PNAS": pna.PNAS, "CPNA": pna.CPNA, "LinkPredHead": dec.LinkPredHead, "MCMHead": ssl.MCMHead, "SelfSupervisedHead": ssl.SelfSupervisedHead,
              "SSLoss": loss.SSLoss}
     return {**extra, "TABGNNFused": fused.TABGNNFused, "FTTransformerPNAFusedLayer": fused.FTTransformerPNAFusedLayer,
             "TABGNN": tabgnn.TABGNN, "PNAConvHetero": pna.PNAConvHetero,
             "ClassifierHead": dec.ClassifierHead, "NodeClassificationHead": dec.NodeClassificationHead}
+
+
+def load_reference_graph_util():
+    """The reference's ``src/datasets/util/graph.py`` (ports / ego-id preprocessing).  Its module-level imports of
+    torch_geometric / torch_frame are only names here (``NeighborSampler``, ``stype``)."""
+    if not os.path.isdir(REF):
+        raise FileNotFoundError(f"{REF} not present (reference never travels to the GPU box)")
+    tg = sys.modules.get("torch_geometric") or _ns("torch_geometric")
+    smp = _ns("torch_geometric.sampler"); smp.NeighborSampler = object
+    tg.sampler = smp
+    tf = sys.modules.get("torch_frame") or _ns("torch_frame")
+    if not hasattr(tf, "stype"):
+        tf.stype = object
+    spec = importlib.util.spec_from_file_location("tabgnn_ref_graph_util", f"{REF}/src/datasets/util/graph.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod

@@ -49,6 +49,20 @@ def tabgnn_wrapper_forward(sd, nhead, batch_size, node_feats, edge_index, edge_f
     return node_classification_head(x, sd, "decoder.", p_head, training)
 
 
+def gnn_wrapper_forward(sd, model_name, batch_size, node_feats, edge_index, edge_feats, p_head=0.0, training=False):
+    """``GNN.forward`` (``utils.py:137-160``), edge classification: encoders on ALL rows, backbone on the whole
+    subgraph, head on the first ``batch_size`` (seed) edges.  ``model_name``: gin | pna | cpna."""
+    from .gine import gine_forward
+    from .siblings import cpna_forward, pnas_forward
+    x = stypewise_encode(node_feats, sd, "node_encoder.")
+    e = stypewise_encode(edge_feats, sd, "edge_encoder.")
+    x = x.reshape(x.shape[0], -1)
+    fwd = {"gin": gine_forward, "pna": pnas_forward, "cpna": cpna_forward}[model_name]
+    x, e = fwd(_sub(sd, "model."), x, edge_index, e, training=training)
+    e = e.reshape(e.shape[0], -1)                                                   # utils.py:141-143
+    return classifier_head(x, edge_index[:, :batch_size], e[:batch_size], sd, "decoder.", p_head, training)
+
+
 def weighted_ce(logits, y, w):
     logp = torch.log_softmax(logits, dim=-1)
     picked = -logp.gather(1, y.view(-1, 1)).squeeze(1)

@@ -224,3 +224,41 @@ def test_transposed_shadows_track_the_optimiser():
     for _ in range(2):
         T.train_step(model, flat, opt, batch, lw)
         check()
+
+
+@pytest.mark.parametrize("name", ["gin", "pna", "cpna"])
+def test_gnn_wrapper_routes_match_oracle(name):
+    """``GNN(config)`` (utils.py:111-233) for --model gin / pna / cpna: fp32 logits within 1e-4 of the oracle's
+    composition on the same synthetic batch, then one bf16 d=128 training step (MFMA paths) with finite gradients."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    from oracle.step import gnn_wrapper_forward
+    B = 48
+    torch.manual_seed(3)
+    cfg = S.make_config(32, 2, 4, B, head_dropout=0.0)
+    cfg.update(model=name, emlps=True)
+    model = T.GNN(cfg)
+    batch = S.make_batch(B, seed=11)
+    node_tf, ei, edge_tf, y = batch
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    nf = {k.value: v for k, v in node_tf.feat_dict.items()}
+    ef = {k.value: v for k, v in edge_tf.feat_dict.items()}
+    with torch.no_grad():
+        ref = gnn_wrapper_forward(sd, name, B, nf, ei, ef)
+    model.to(DEV).eval()
+    with torch.no_grad():
+        got = model(node_tf.to(DEV), ei.to(DEV), edge_tf.to(DEV))
+    assert tuple(got.shape) == (B, 2)
+    np.testing.assert_allclose(got.float().cpu().numpy(), ref.numpy(), atol=1e-4)
+    # bf16, d=128
+    cfg = S.make_config(128, 2, 4, B, head_dropout=0.0, compute_dtype=torch.bfloat16)
+    cfg.update(model=name, emlps=True)
+    model = T.GNN(cfg).to(DEV).train()
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    opt = T.FusedAdam(flat, lr=1e-3)
+    w = torch.tensor([1.0, 9.23], device=DEV)
+    b = (node_tf.to(DEV), ei.to(DEV), edge_tf.to(DEV), y.to(DEV))
+    l0, _ = T.train_step(model, flat, opt, b, w)
+    for _ in range(5):
+        l1, _ = T.train_step(model, flat, opt, b, w)
+    assert np.isfinite(float(l0)) and np.isfinite(float(l1)) and float(l1) < float(l0)

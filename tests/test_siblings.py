@@ -176,3 +176,108 @@ def test_gpu_cpna_matches_reference():
         ref = float(z[f"gradnorm.{k}"])
         got = 0.0 if p.grad is None else p.grad.double().norm().item()
         assert abs(got - ref) < 2e-3 * max(1.0, ref), k
+
+
+def _gine_inputs(cfg, z):
+    seed, N, E, nc, Fh = cfg["seed"], cfg["N"], cfg["E"], cfg["ncols"], cfg["F"]
+    return (det_tensor("in.x", (N, Fh), seed), torch.from_numpy(z["edge_index"].astype(np.int64)),
+            det_tensor("in.edge_attr", (E, nc, Fh), seed))
+
+
+def _gine_state(cfg, z):
+    """The two directions of a GINEConvHetero share ONE network (gine.py:18-19): the state dict lists it under both
+    prefixes and the value written last (``conv_back``) is the one both use; gradients add up on the shared tensor."""
+    sd = build_state(cfg["keys"], z, cfg["seed"])
+    for k in list(sd):
+        if ".conv_forw.nn." in k:
+            sd[k] = sd[k.replace(".conv_forw.nn.", ".conv_back.nn.")]
+    return sd
+
+
+@pytest.mark.parametrize("name", ["gine_f32_l2", "gine_f32_l2_rmp"])
+def test_oracle_gine_matches_reference(name):
+    from oracle.gine import gine_forward
+    cfg, z = load_case(name)
+    x, ei, ea = _gine_inputs(cfg, z)
+    sd = _gine_state(cfg, z)
+    with torch.no_grad():
+        xo, eo = gine_forward({k: v.clone() for k, v in sd.items()}, x, ei, ea)
+    np.testing.assert_allclose(xo.numpy(), z["eval.x"], atol=2e-5)
+    np.testing.assert_allclose(eo.numpy(), z["eval.edge_attr"], atol=2e-5)
+    for k in sd:
+        if sd[k].is_floating_point() and "running" not in k and not k.endswith("eps"):
+            sd[k].requires_grad_(True)
+    xo, eo = gine_forward(sd, x, ei, ea, training=True)
+    loss = _scalar(cfg, xo, eo, cfg["N"], cfg["E"])
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-5
+    checked = 0
+    for k in sd:
+        if f"gradnorm.{k}" in z.files and sd[k].grad is not None:
+            ref = float(z[f"gradnorm.{k}"])
+            assert abs(sd[k].grad.double().norm().item() - ref) < 1e-4 * max(1.0, ref), k
+            checked += 1
+    assert checked >= 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gine_f32_l2", "gine_f32_l2_rmp"])
+def test_gpu_gine_matches_reference(name):
+    import tabgnn_amd as T
+    dev = "cuda:0"
+    cfg, z = load_case(name)
+    Fh, N, E = cfg["F"], cfg["N"], cfg["E"]
+    x, ei, ea = _gine_inputs(cfg, z)
+    m = T.GINe(num_features=Fh, num_gnn_layers=cfg["L"], n_hidden=Fh, edge_updates=True, edge_dim=cfg["ncols"] * Fh,
+               reverse_mp=cfg["reverse_mp"])
+    assert set(m.state_dict().keys()) == set(cfg["keys"].keys())
+    m.load_state_dict(build_state(cfg["keys"], z, cfg["seed"]))
+    m.to(dev).eval()
+    with torch.no_grad():
+        xo, eo = m(x.to(dev), ei.to(dev), ea.to(dev))
+    np.testing.assert_allclose(xo.cpu().numpy(), z["eval.x"], atol=1e-4)
+    np.testing.assert_allclose(eo.cpu().numpy(), z["eval.edge_attr"], atol=1e-4)
+    m.load_state_dict(build_state(cfg["keys"], z, cfg["seed"]))
+    m.train()
+    xo, eo = m(x.to(dev), ei.to(dev), ea.to(dev))
+    np.testing.assert_allclose(xo.detach().cpu().numpy(), z["train.x"], atol=1e-4)
+    loss = _scalar(cfg, xo, eo, N, E)
+    loss.backward()
+    assert abs(loss.item() - float(z["train.loss"])) < 1e-4
+    for k, p in m.named_parameters():
+        ref = float(z[f"gradnorm.{k}"])
+        got = 0.0 if p.grad is None else p.grad.double().norm().item()
+        assert abs(got - ref) < 2e-3 * max(1.0, ref), k
+
+
+@pytest.mark.gpu
+def test_gpu_gine_aggregate_hubs_and_bf16():
+    """tg_gine_aggregate_fwd / tg_gine_message_bwd against a torch restatement on a graph with hub destinations
+    (> 256 in-edges: the block-per-hub pass) and hub sources, fp32 tight and bf16 at its rounding tolerance."""
+    from tabgnn_amd import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    N, E, F = 3000, 40000, 128
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N, (E,), generator=g)
+    dst[:6000] = 7; dst[6000:6300] = 11; src[20000:29000] = 3          # hub destinations 7 (6000 rows), 11; hub source 3
+    ei = torch.stack([src, dst]).to(dev)
+    graph = ops.SubgraphIndex.build(ei, N)
+    x32 = torch.randn(N, F, generator=g).to(dev)
+    le32 = torch.randn(E, F, generator=g).to(dev)
+    co = torch.randn(N, F, generator=g).to(dev)
+    for dt, tol, gtol in ((torch.float32, 2e-3, 2e-3), (torch.bfloat16, 0.02, 0.02)):
+        for scale in (1.25, 0.0):
+            x = x32.to(dt).requires_grad_(True); le = le32.to(dt).requires_grad_(True)
+            out = ops.gine_aggregate(x, le, graph, scale)
+            (out.float() * co).sum().backward()
+            xr = x.detach().float().requires_grad_(True); lr = le.detach().float().requires_grad_(True)
+            ref = torch.zeros(N, F, device=dev).index_add_(0, ei[1], torch.relu(xr[ei[0]] + lr)) + scale * xr
+            (ref * co).sum().backward()
+            rel = lambda a, b: ((a.float() - b).norm() / b.norm().clamp_min(1e-12)).item()
+            assert rel(out, ref.detach()) < tol, (dt, scale, rel(out, ref.detach()))
+            assert rel(x.grad, xr.grad) < gtol and rel(le.grad, lr.grad) < gtol, (dt, scale)
+    # determinism: same inputs, bit-identical outputs
+    a = ops.gine_aggregate(x32, le32, graph, 1.0)
+    b = ops.gine_aggregate(x32, le32, graph, 1.0)
+    assert torch.equal(a, b)
