@@ -268,7 +268,7 @@ def test_gpu_gine_aggregate_hubs_and_bf16():
     co = torch.randn(N, F, generator=g).to(dev)
     for dt, tol, gtol in ((torch.float32, 2e-3, 2e-3), (torch.bfloat16, 0.02, 0.02)):
         for scale in (1.25, 0.0):
-            x = x32.to(dt).requires_grad_(True); le = le32.to(dt).requires_grad_(True)
+            x = x32.to(dt).clone().requires_grad_(True); le = le32.to(dt).clone().requires_grad_(True)
             out = ops.gine_aggregate(x, le, graph, scale)
             (out.float() * co).sum().backward()
             xr = x.detach().float().requires_grad_(True); lr = le.detach().float().requires_grad_(True)
