@@ -47,11 +47,20 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
                                                        const unsigned short* __restrict__ X,
                                                        float* __restrict__ partial, float* __restrict__ colsum_part,
                                                        long long R, int M, int N, long long ldg, long long ldx,
-                                                       long long rows_per_slab) {
+                                                       long long rows_per_slab, int tm, int tn, int nslab) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];   // [buf][G|X][64 x 256 B] = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
-  const long long r_begin = (long long)blockIdx.z * rows_per_slab;
+  // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2.  The tm*tn
+  // output tiles of one row slab take consecutive slots of the SAME XCD, so they stream the slab together and the
+  // G / X column blocks they share (each G block feeds tn tiles, each X block tm tiles) are fetched from HBM once
+  // and hit that L2 afterwards.  With one output tile (M = N = 128) the map is the identity.
+  const int T_ = tm * tn;
+  const int slot = blockIdx.x >> 3;
+  const int slab = (slot / T_) * 8 + (blockIdx.x & 7), tile = slot % T_;
+  if (slab >= nslab) return;
+  const int bx = tile % tm, by = tile / tm;
+  const int m0 = bx * GM, n0 = by * GN;
+  const long long r_begin = (long long)slab * rows_per_slab;
   long long r_end = r_begin + rows_per_slab;
   if (r_end > R) r_end = R;
   const int wm = wave >> 1, wn = wave & 1;
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
   }
 
   // bias gradient: thread t sums column (t & 127) over rows (t >> 7)*32 .. +31 of every G tile
-  const bool do_cs = colsum_part != nullptr && blockIdx.y == 0;
+  const bool do_cs = colsum_part != nullptr && by == 0;
   float cs = 0.f;
   const int cs_col = tid & 127, cs_r0 = (tid >> 7) * 32;
 
@@ -140,11 +149,11 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
     float* red = reinterpret_cast<float*>(lds);
     if (tid >= 128) red[cs_col] = cs;
     __syncthreads();
-    if (tid < 128 && m0 + cs_col < M) colsum_part[(long long)blockIdx.z * M + m0 + cs_col] = cs + red[cs_col];
+    if (tid < 128 && m0 + cs_col < M) colsum_part[(long long)slab * M + m0 + cs_col] = cs + red[cs_col];
   }
 
   // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
-  float* out = partial + (long long)blockIdx.z * M * N;
+  float* out = partial + (long long)slab * M * N;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -255,9 +264,11 @@ extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* 
   long long rps;
   tn_geometry(R, M, N, tm, tn, nslab, rps);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gemm_tn_bf16, dim3(tm, tn, nslab), dim3(256), 0, st, (const unsigned short*)G,
+  const long long blocks = (long long)((nslab + 7) / 8) * 8 * tm * tn;
+  TG_CHECK(blocks <= 2147483647LL, "tg_gemm_tn_bf16: too many tiles");
+  hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
                      (const unsigned short*)X, workspace, colsum ? workspace + (long long)nslab * M * N : nullptr,
-                     (long long)R, M, N, (long long)ldg, (long long)ldx, rps);
+                     (long long)R, M, N, (long long)ldg, (long long)ldx, rps, tm, tn, nslab);
   long long mn = (long long)M * N;
   const int nb1 = ceil_div(ceil_div(mn, 4), 16), nb2 = colsum ? ceil_div(ceil_div(M, 4), 16) : 0;
   hipLaunchKernelGGL(k_sum_slabs, dim3(nb1 + nb2), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
