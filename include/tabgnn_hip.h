@@ -154,6 +154,19 @@ int tg_pna_scale_combine_fwd(const void* xw, const void* G /*[N,3F]*/, const int
                              void* out, int32_t N, int32_t F, int32_t dt, void* stream);
 int tg_pna_scale_combine_bwd(const void* gout, const int32_t* rowptr, const float* avg_log, void* dG, int32_t N,
                              int32_t F, int32_t dt, void* stream);
+/* The same post projection with the degree scalers folded INTO the GEMMs (the [N,3F] tensor G and its gradient
+ * never exist).  scales = fp32 (amp, att) pairs per node from tg_pna_degree_scalers, in a buffer of ceil(N/128)*128
+ * rows (the NT kernel reads whole 128-row tiles; rows >= N are never used in a stored result) (DegreeScalerAggregation:
+ * amp = log(deg+1)/avg_log, att = avg_log/log(max(deg,1)+1)).
+ *  tg_gemm_nt_scaled_bf16: Y[R,N] (+)= X W_0^T + amp*X W_1^T + att*X W_2^T, X [R,kreal], W [N,3*kreal] with
+ *    128-column block 3c+s = W_s[:, 128c:128c+128]
+ *    (forward: X = agg [N,4F], W_s = post-projection block of scaler s; input gradient: X = dOut [N,F], W_s = W_s^T);
+ *  tg_gemm_tn_scaled_bf16: out[3*mreal,N] fp32 (+)= [G | amp*G | att*G]^T X (weight gradient; G = dOut, X = agg). */
+int tg_pna_degree_scalers(const int32_t* rowptr, const float* avg_log, float* out /*[N,2]*/, int32_t N, void* stream);
+int tg_gemm_nt_scaled_bf16(const void* X, const void* W, const float* scales, void* Y, int64_t R, int32_t N,
+                           int32_t kreal, int64_t ldx, int64_t ldy, int32_t flags /*0 | 4 (Y +=)*/, void* stream);
+int tg_gemm_tn_scaled_bf16(const void* G, const void* X, const float* scales, float* out, float* workspace, int64_t R,
+                           int32_t mreal, int32_t N, int64_t ldg, int64_t ldx, int32_t accumulate, void* stream);
 /* GINEConv aggregation (src/nn/gnn/gine.py:18-19,62-72 through torch_geometric 2.5.3 GINEConv.forward/message):
  * out[n] = self_scale*x[n] + sum_{e: dst[e]=n} relu(x[src[e]] + le[e]), le = lin(edge_attr) [E,F]; rowptr/perm = the
  * stable by-destination CSR (tg_csr_build); self_scale = 1+eps, or 0 for the (x, None) form of GINEConvHetero

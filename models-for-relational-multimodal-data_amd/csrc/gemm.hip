@@ -29,6 +29,16 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 }
 
 // 8 consecutive k (rows r0..r0+7 of the tile) of column (cb*32 + lane&31): MFMA 32x32x16 A/B fragment
+__device__ __forceinline__ uint4 tn_scale8(uint4 v, float s) {   // 8 packed bf16 times s, round to nearest even
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = __uint_as_float(w[j] << 16) * s, hi = __uint_as_float(w[j] & 0xffff0000u) * s;
+    w[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __device__ __forceinline__ v8bf frag_tr(const char* tile, int ks, int cb, int lane) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
   const int r0 = ks * 16 + (g >> 1) * 8;
@@ -43,11 +53,17 @@ __device__ __forceinline__ v8bf frag_tr(const char* tile, int ks, int cb, int la
   return __builtin_bit_cast(v8bf, r);
 }
 
+// SCALED (the PNA post projection's weight gradient with the degree scalers folded in): G is [R, mreal] and M = 3*mreal
+// is virtual — output row block s = m0 / mreal holds (f_s(r) * G)^T X with f = (1, amp(r), att(r)), scales = fp32
+// [R,2] (amp, att); the G pieces of blocks 1 and 2 are multiplied in registers on their way into LDS (re-rounded to
+// bf16, exactly what the materialised [g | amp*g | att*g] operand of the unfused path held).
+template <bool SCALED>
 __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __restrict__ G,
                                                        const unsigned short* __restrict__ X,
                                                        float* __restrict__ partial, float* __restrict__ colsum_part,
                                                        long long R, int M, int N, long long ldg, long long ldx,
-                                                       long long rows_per_slab, int tm, int tn, int nslab) {
+                                                       long long rows_per_slab, int tm, int tn, int nslab,
+                                                       const float* __restrict__ scales, int mreal) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * TILE_BYTES];   // [buf][G|X][64 x 256 B] = 64 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware order: workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has its own L2.  The tm*tn
@@ -60,6 +76,8 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
   if (slab >= nslab) return;
   const int bx = tile % tm, by = tile / tm;
   const int m0 = bx * GM, n0 = by * GN;
+  const int gset = SCALED ? m0 / mreal : 0;           // which scaler this output block carries (uniform)
+  const int gcol0 = SCALED ? m0 % mreal : m0;         // first real G column of the block
   const long long r_begin = (long long)slab * rows_per_slab;
   long long r_end = r_begin + rows_per_slab;
   if (r_end > R) r_end = R;
@@ -75,6 +93,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
 
   // staging map: piece = tid + 256*p -> row = piece >> 4 (0..63), chunk = piece & 15
   uint4 rg0, rg1, rg2, rg3, rx0, rx1, rx2, rx3;
+  float sg0 = 1.f, sg1 = 1.f, sg2 = 1.f, sg3 = 1.f;
 #define TG_LOAD_PIECE(P, RG, RX)                                                                              \
   {                                                                                                           \
     int piece = tid + 256 * P, row = piece >> 4, ch = piece & 15;                                             \
@@ -82,10 +101,13 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
     /* unconditional loads from clamped (always valid) addresses, zeroed by select: no branch, no early wait */ \
     bool okr = r < r_end;                                                                                     \
     long long rc_ = okr ? r : r_end - 1;                                                                      \
-    int mc_ = m0 + ch * 8 < M ? m0 + ch * 8 : M - 8;                                                          \
+    int mc_ = SCALED ? gcol0 + ch * 8 : (m0 + ch * 8 < M ? m0 + ch * 8 : M - 8);                              \
     int nc_ = n0 + ch * 8 < N ? n0 + ch * 8 : N - 8;                                                          \
     uint4 vg_ = *reinterpret_cast<const uint4*>(G + rc_ * ldg + mc_);                                         \
     uint4 vx_ = *reinterpret_cast<const uint4*>(X + rc_ * ldx + nc_);                                         \
+    if constexpr (SCALED) {                                                                                   \
+      if (gset > 0) sg##P = scales[2 * rc_ + gset - 1];   /* applied at store time: no wait on the loads here */ \
+    }                                                                                                         \
     bool okg_ = okr && m0 + ch * 8 < M, okx_ = okr && n0 + ch * 8 < N;                                        \
     RG = make_uint4(okg_ ? vg_.x : 0u, okg_ ? vg_.y : 0u, okg_ ? vg_.z : 0u, okg_ ? vg_.w : 0u);              \
     RX = make_uint4(okx_ ? vx_.x : 0u, okx_ ? vx_.y : 0u, okx_ ? vx_.z : 0u, okx_ ? vx_.w : 0u);              \
@@ -98,6 +120,9 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
 #define TG_STORE_PIECE(P, RG, RX)                                                                             \
   {                                                                                                           \
     int piece = tid + 256 * P, off = lds_off(piece >> 4, piece & 15);                                         \
+    if constexpr (SCALED) {                                                                                   \
+      if (gset > 0) RG = tn_scale8(RG, sg##P);                                                                \
+    }                                                                                                         \
     *reinterpret_cast<uint4*>(tg_w + off) = RG;                                                               \
     *reinterpret_cast<uint4*>(tg_w + TILE_BYTES + off) = RX;                                                  \
   }
@@ -266,13 +291,43 @@ extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* 
   hipStream_t st = (hipStream_t)stream;
   const long long blocks = (long long)((nslab + 7) / 8) * 8 * tm * tn;
   TG_CHECK(blocks <= 2147483647LL, "tg_gemm_tn_bf16: too many tiles");
-  hipLaunchKernelGGL(k_gemm_tn_bf16, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
+  hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
                      (const unsigned short*)X, workspace, colsum ? workspace + (long long)nslab * M * N : nullptr,
-                     (long long)R, M, N, (long long)ldg, (long long)ldx, rps, tm, tn, nslab);
+                     (long long)R, M, N, (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0);
   long long mn = (long long)M * N;
   const int nb1 = ceil_div(ceil_div(mn, 4), 16), nb2 = colsum ? ceil_div(ceil_div(M, 4), 16) : 0;
   hipLaunchKernelGGL(k_sum_slabs, dim3(nb1 + nb2), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
                      workspace + (long long)nslab * mn, (long long)M, colsum, accumulate);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[3*mreal, N] (fp32) = [G | amp*G | att*G]^T X with G [R,mreal], X [R,N] bf16 and scales fp32 [R,2] = (amp, att):
+// the weight gradient of the PNA post projection with the degree scalers folded in ([dG0 | dG1 | dG2] never exists).
+// workspace: tg_gemm_tn_workspace_floats(R, 3*mreal, N) floats.
+extern "C" int tg_gemm_tn_scaled_bf16(const void* G, const void* X, const float* scales, float* out, float* workspace,
+                                      int64_t R, int32_t mreal, int32_t N, int64_t ldg, int64_t ldx, int32_t accumulate,
+                                      void* stream) {
+  TG_CHECK(R > 0 && mreal > 0 && N > 0 && mreal % GM == 0 && N % 8 == 0 && ldg % 8 == 0 && ldx % 8 == 0 && ldg >= mreal,
+           "tg_gemm_tn_scaled_bf16: need mreal %% 128 == 0, N %% 8 == 0 (mreal=%d N=%d)", mreal, N);
+  TG_CHECK(G && X && scales && out && workspace, "tg_gemm_tn_scaled_bf16: null operand");
+  TG_CHECK((reinterpret_cast<uintptr_t>(G) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+           "tg_gemm_tn_scaled_bf16: operands and output must be 16-byte aligned");
+  const int M = 3 * mreal;
+  int tm, tn, nslab;
+  long long rps;
+  tn_geometry(R, M, N, tm, tn, nslab, rps);
+  hipStream_t st = (hipStream_t)stream;
+  const long long blocks = (long long)((nslab + 7) / 8) * 8 * tm * tn;
+  TG_CHECK(blocks <= 2147483647LL, "tg_gemm_tn_scaled_bf16: too many tiles");
+  hipLaunchKernelGGL(k_gemm_tn_bf16<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
+                     (const unsigned short*)X, workspace, (float*)nullptr, (long long)R, M, N, (long long)ldg,
+                     (long long)ldx, rps, tm, tn, nslab, scales, mreal);
+  long long mn = (long long)M * N;
+  const int nb1 = ceil_div(ceil_div(mn, 4), 16);
+  hipLaunchKernelGGL(k_sum_slabs, dim3(nb1), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
+                     workspace + (long long)nslab * mn, (long long)M, (float*)nullptr, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }

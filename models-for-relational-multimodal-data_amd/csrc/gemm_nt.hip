@@ -38,11 +38,30 @@ __device__ __forceinline__ nt_v8bf nt_frag(const char* tile, int row, int ch) {
 
 enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4, NT_GATE = 8 };
 
+__device__ __forceinline__ uint4 nt_scale8(uint4 v, float s) {   // 8 packed bf16 times s, round to nearest even
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = __uint_as_float(w[j] << 16) * s, hi = __uint_as_float(w[j] & 0xffff0000u) * s;
+    w[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // WIDE (K == 128, N > 128: the QKV projection, edge_emb's input gradient): ONE workgroup per row tile walks the
 // N/128 column tiles with the X image staged once; each W tile is prefetched into registers under the previous
 // tile's MFMAs and the output tile is restaged through the (dead) W image.  The narrow form gives every column tile
 // its own workgroup (XCD-aware order) and loops over k chunks instead.
-template <bool WIDE>
+//
+// SCALED (narrow form only; the PNA post projection with its degree scalers folded in, layers.py PNAConv):
+//     Y[r,:] (+)= sum_s f_s(r) * X[r, 0:kreal] W[:, s*kreal:(s+1)*kreal]^T,   s = 0..2,
+//     f = (1, amp(r), att(r));  K is the VIRTUAL depth 3*kreal and W is laid out by virtual chunk: column block 3c+s
+// holds W_s[:, 128c:128c+128].  The X pieces of the amp / att sets are
+// multiplied by the row's scale in registers on their way into LDS (re-rounded to bf16, as the materialised
+// [amp*agg] / [amp*g] operands of the unfused path were).  Rescaling the accumulators instead (one scale per MFMA B
+// column) was tried first: 64 accumulators through the VALU cost 133 spilled VGPRs.
+// scales = fp32 (amp, att) per row, padded to a whole number of 128-row tiles (rows >= R are never stored).
+template <bool WIDE, bool SCALED>
 __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* __restrict__ X,
                                                            const unsigned short* __restrict__ W,
                                                            const float* __restrict__ bias,
@@ -50,7 +69,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
                                                            unsigned short* __restrict__ Y, long long R, int N, int K,
                                                            long long ldx, long long ldy,
                                                            int flags, unsigned thresh, float inv_keep,
-                                                           unsigned long long seed, unsigned rstream) {
+                                                           unsigned long long seed, unsigned rstream,
+                                                           const float* __restrict__ scales, int kreal) {
   __shared__ __attribute__((aligned(16))) char lds[2 * NT_TILE_BYTES];   // [X image | W image] = 64 KiB
   char* xs = lds;
   char* ws = lds + NT_TILE_BYTES;
@@ -98,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
 #define NT_LOADW(N0, K0)                                                                              \
   NT_LOADW1(0, rw0, N0, K0) NT_LOADW1(1, rw1, N0, K0) NT_LOADW1(2, rw2, N0, K0) NT_LOADW1(3, rw3, N0, K0) \
   NT_LOADW1(4, rw4, N0, K0) NT_LOADW1(5, rw5, N0, K0) NT_LOADW1(6, rw6, N0, K0) NT_LOADW1(7, rw7, N0, K0)
-#define NT_ST1(BUF, P, RV) *reinterpret_cast<uint4*>((BUF) + nt_off(st_row + 16 * (P), st_ch)) = RV;
+#define NT_ST1(BUF, P, RV) *reinterpret_cast<uint4*>((BUF) + nt_off(st_row + 16 * (P), st_ch)) = (RV);
 #define NT_STOREX()                                                                                   \
   NT_ST1(xs, 0, rx0) NT_ST1(xs, 1, rx1) NT_ST1(xs, 2, rx2) NT_ST1(xs, 3, rx3)                         \
   NT_ST1(xs, 4, rx4) NT_ST1(xs, 5, rx5) NT_ST1(xs, 6, rx6) NT_ST1(xs, 7, rx7)
@@ -121,7 +141,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
 #define NT_LOAD_BIAS(N0)                                                                              \
   _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int g = 0; g < 4; ++g) {       \
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
-    if (bias) t = *reinterpret_cast<const float4*>(bias + (N0) + wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5)); \
+    if (!SCALED && bias) t = *reinterpret_cast<const float4*>(bias + (N0) + wn * 64 + a * 32 + 8 * g + 4 * (lane >> 5)); \
     bv[a][g][0] = t.x; bv[a][g][1] = t.y; bv[a][g][2] = t.z; bv[a][g][3] = t.w;                       \
   }
 
@@ -208,6 +228,49 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
     }
   } else {
     NT_LOAD_BIAS(n0)
+    if constexpr (SCALED) {
+      // Virtual chunk v = 3c+s pairs X chunk c with W block (c, s); the X pieces of sets 1 / 2 are multiplied by
+      // amp(row) / att(row) in registers (fp32, re-rounded to bf16) on their way into LDS.  This thread stages tile
+      // rows st_row + 16*p; their scales for the next chunk are fetched with its X pieces.  (Keeping one fetched X
+      // chunk for all three sets was tried: the longer live ranges cost 57-102 spilled VGPRs at two workgroups per
+      // CU; re-reading it from L2 does not.)
+      float sc0 = 1.f, sc1 = 1.f, sc2 = 1.f, sc3 = 1.f, sc4 = 1.f, sc5 = 1.f, sc6 = 1.f, sc7 = 1.f;
+      // scales is padded to whole 128-row tiles, so one base pointer + immediates address every row of the tile
+      const float* scp = scales + 2 * (r0 + st_row) - 1;
+#define NT_LOADS1(P, SC, SET) SC = scp[32 * (P) + (SET)];
+#define NT_LOADSCALES(SET)                                                                            \
+  if ((SET) > 0) {                                    /* uniform */                                   \
+    NT_LOADS1(0, sc0, SET) NT_LOADS1(1, sc1, SET) NT_LOADS1(2, sc2, SET) NT_LOADS1(3, sc3, SET)       \
+    NT_LOADS1(4, sc4, SET) NT_LOADS1(5, sc5, SET) NT_LOADS1(6, sc6, SET) NT_LOADS1(7, sc7, SET)       \
+  }
+#define NT_SCALEX(SET)                                                                                \
+  if ((SET) > 0) {                                                                                    \
+    rx0 = nt_scale8(rx0, sc0); rx1 = nt_scale8(rx1, sc1); rx2 = nt_scale8(rx2, sc2); rx3 = nt_scale8(rx3, sc3); \
+    rx4 = nt_scale8(rx4, sc4); rx5 = nt_scale8(rx5, sc5); rx6 = nt_scale8(rx6, sc6); rx7 = nt_scale8(rx7, sc7); \
+  }
+      const int nv = K / NT_BK;                       // 3 * kreal / 128 virtual chunks
+      NT_LOADX(0)
+      NT_LOADW(n0, 0)
+      int v = 0;
+      for (; v + 1 < nv; ++v) {                       // last chunk peeled: every load unconditional and in bounds
+        NT_SCALEX(v % 3)
+        NT_STOREX()
+        NT_STOREW()
+        __syncthreads();
+        const int vn = v + 1;
+        NT_LOADX((vn / 3) * NT_BK)
+        NT_LOADW(n0, vn * NT_BK)
+        NT_LOADSCALES(vn % 3)
+        NT_MFMA_CHUNK()
+        __syncthreads();
+      }
+      NT_SCALEX(v % 3)
+      NT_STOREX()
+      NT_STOREW()
+      __syncthreads();
+      NT_MFMA_CHUNK()
+      __syncthreads();
+    } else {
     // The last k chunk is peeled off the loop so that EVERY load in the loop body is unconditional and in bounds:
     // with `if (more) load(next)` hipcc hoisted 14 of the 16 next-chunk loads out of the guard (speculative reads
     // 256 bytes past each row; a fault when the operand ends on its mapping's last page).
@@ -228,6 +291,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
     __syncthreads();
     NT_MFMA_CHUNK()
     __syncthreads();
+    }
     NT_EPILOGUE(xs, n0)                               // the X image is dead: output tile
     __syncthreads();
     NT_WRITE_OUT(xs, n0)
@@ -255,6 +319,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_ln_bf16(const unsigned short
   char* xs = lds;
   char* ws = lds + NT_TILE_BYTES;
   const int N = NT_BN;
+  constexpr bool SCALED = false;                      // (the shared NT_LOAD_BIAS macro tests it)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long row_tile = blockIdx.x;
   if (row_tile * NT_BM >= R) return;
@@ -400,18 +465,42 @@ extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, 
   const long long row_tiles = (R + NT_BM - 1) / NT_BM;
   if (K == NT_BK && N > NT_BN) {       // wide outputs of a 128-deep product: one workgroup per row tile
     TG_CHECK(row_tiles <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
-    hipLaunchKernelGGL((k_gemm_nt_bf16<true>), dim3((unsigned)row_tiles), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_gemm_nt_bf16<true, false>), dim3((unsigned)row_tiles), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
                        (unsigned short*)Y, (long long)R, N, K, (long long)ldx, (long long)ldy, flags, thresh, inv_keep,
-                       (unsigned long long)seed, rstream);
+                       (unsigned long long)seed, rstream, (const float*)nullptr, 0);
   } else {
     const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
     TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
-    hipLaunchKernelGGL((k_gemm_nt_bf16<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_gemm_nt_bf16<false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
                        (unsigned short*)Y, (long long)R, N, K, (long long)ldx, (long long)ldy, flags, thresh, inv_keep,
-                       (unsigned long long)seed, rstream);
+                       (unsigned long long)seed, rstream, (const float*)nullptr, 0);
   }
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Y[R,N] (+)= X W_0^T + amp(r) * X W_1^T + att(r) * X W_2^T; W is [N, 3*kreal] with 128-column block 3c+s =
+// W_s[:, 128c:128c+128] (s: 0 identity, 1 amp, 2 att) and scales fp32 [R,2] = (amp, att): the PNA post projection with the degree scalers folded in
+// (forward: X = agg [R,4F], N = F; input gradient: X = dOut [R,F], N = 4F).  flags: 0 or 4 (Y +=).
+extern "C" int tg_gemm_nt_scaled_bf16(const void* X, const void* W, const float* scales, void* Y, int64_t R, int32_t N,
+                                      int32_t kreal, int64_t ldx, int64_t ldy, int32_t flags, void* stream) {
+  TG_CHECK(R > 0 && N > 0 && kreal > 0 && N % NT_BN == 0 && kreal % NT_BK == 0,
+           "tg_gemm_nt_scaled_bf16: need N %% 128 == 0 and kreal %% 128 == 0 (R=%lld N=%d kreal=%d)", (long long)R, N, kreal);
+  TG_CHECK(X && W && scales && Y, "tg_gemm_nt_scaled_bf16: null operand");
+  TG_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= kreal && ldy >= N, "tg_gemm_nt_scaled_bf16: bad row strides");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(scales) & 7) == 0,
+           "tg_gemm_nt_scaled_bf16: operands must be 16-byte aligned");
+  TG_CHECK((flags & ~NT_ACCUM) == 0, "tg_gemm_nt_scaled_bf16: only the accumulate flag is supported");
+  const long long row_tiles = (R + NT_BM - 1) / NT_BM;
+  const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
+  TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_scaled_bf16: too many tiles (R=%lld)", (long long)R);
+  hipLaunchKernelGGL((k_gemm_nt_bf16<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)X, (const unsigned short*)W, (const float*)nullptr,
+                     (const unsigned short*)nullptr, (unsigned short*)Y, (long long)R, N, 3 * kreal, (long long)ldx,
+                     (long long)ldy, flags, 0u, 1.f, 0ull, 0u, scales, kreal);
   TG_LAUNCH_CHECK();
   return 0;
 }

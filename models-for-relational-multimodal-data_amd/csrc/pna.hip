@@ -603,6 +603,17 @@ __device__ __forceinline__ void scalers(const int* rowptr, int n, float avg_log,
   att = avg_log / logf(fmaxf(deg, 1.f) + 1.f);
 }
 
+// (amp, att) of every node as fp32 pairs: the row scales of the fused post projection (tg_gemm_*_scaled_bf16)
+__global__ void k_degree_scalers(const int* __restrict__ rowptr, const float* __restrict__ avg_log,
+                                 float2* __restrict__ out, int N) {
+  const float al = avg_log[0];
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    float amp, att;
+    scalers(rowptr, n, al, amp, att);
+    out[n] = make_float2(amp, att);
+  }
+}
+
 template <typename T, int VEC>
 __global__ void k_scale_combine_fwd(const T* __restrict__ xw, const T* __restrict__ G, const int* __restrict__ rowptr,
                                     const float* __restrict__ avg_log, T* __restrict__ out, int N, int F) {
@@ -813,6 +824,15 @@ extern "C" int tg_pna_scale_combine_bwd(const void* gout, const int32_t* rowptr,
     hipLaunchKernelGGL((k_scale_combine_bwd<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0,
                        (hipStream_t)stream, (const T*)gout, rowptr, avg_log, (T*)dG, N, F);
   })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_pna_degree_scalers(const int32_t* rowptr, const float* avg_log, float* out, int32_t N, void* stream) {
+  TG_CHECK(rowptr && avg_log && out && (reinterpret_cast<uintptr_t>(out) & 7) == 0, "tg_pna_degree_scalers: bad argument");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(k_degree_scalers, dim3(grid_cap(ceil_div(N, 256))), dim3(256), 0, (hipStream_t)stream, rowptr,
+                     avg_log, (float2*)out, N);
   TG_LAUNCH_CHECK();
   return 0;
 }

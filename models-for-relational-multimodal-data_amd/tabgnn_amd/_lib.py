@@ -54,6 +54,9 @@ SIGNATURES = {
     "tg_pna_aggregate_hubs": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp],
     "tg_pna_scale_combine_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
     "tg_pna_scale_combine_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp],
+    "tg_pna_degree_scalers": [_vp, _vp, _vp, _i32, _vp],
+    "tg_gemm_nt_scaled_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
+    "tg_gemm_tn_scaled_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
     "tg_gine_aggregate_fwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _i32, _vp],
     "tg_gine_message_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -158,12 +158,14 @@ class PNAConv(nn.Module):
         # lin(post([x, agg, amp*agg, att*agg])) = x Wx^T + b + (agg Wid^T) + amp (agg Wamp^T) + att (agg Watt^T)
         w_eff = self.lin.weight @ post.weight                            # [F,13F]
         b_eff = self.lin.weight @ post.bias + self.lin.bias
-        xw = ops.linear(x, w_eff[:, :F], b_eff)
         if self.agg_order == [0, 1, 2, 3]:
             w_st = torch.cat([w_eff[:, F:5 * F], w_eff[:, 5 * F:9 * F], w_eff[:, 9 * F:]], dim=0)   # [3F,4F]
         else:                                                           # column blocks re-ordered to the kernel's layout
             blk = lambda sc, j: w_eff[:, F + (sc * 4 + j) * F:F + (sc * 4 + j + 1) * F]
             w_st = torch.cat([torch.cat([blk(sc, j) for j in self.agg_order], dim=1) for sc in range(3)], dim=0)
+        if ops.post_scaled_ok(x, agg):          # scalers inside the GEMMs: G [N,3F] and its gradient never exist
+            return ops.pna_post_scaled(x, w_eff[:, :F], b_eff, agg, w_st, g, self.aggr_module.avg_deg_log)
+        xw = ops.linear(x, w_eff[:, :F], b_eff)
         G = ops.linear(agg, w_st, None)
         return ops.pna_scale_combine(xw, G, g, self.aggr_module.avg_deg_log)
 

@@ -7,6 +7,7 @@ everything else (gather, attention core, norms, aggregation, pooling, loss, opti
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -727,6 +728,75 @@ class _ScaleCombine(torch.autograd.Function):
 
 def pna_scale_combine(xw, G, graph, avg_log):
     return _ScaleCombine.apply(xw, G, graph, avg_log)
+
+
+def degree_scalers(graph, avg_log):
+    """fp32 (amp, att) per node of ``graph`` (by-destination degrees), cached on the graph per scaler buffer.  Rows are
+    padded (with zeros) to a whole number of 128-row GEMM tiles, as tg_gemm_nt_scaled_bf16 addresses them."""
+    cache = graph.__dict__.setdefault("_scalers", {})
+    key = (avg_log.data_ptr(), avg_log._version)
+    sc = cache.get(key)
+    if sc is None:
+        sc = torch.zeros((graph.N + 127) // 128 * 128, 2, dtype=torch.float32, device=avg_log.device)
+        L.call("tg_pna_degree_scalers", L.ptr(graph.by_dst[0]), L.ptr(avg_log), L.ptr(sc), graph.N, L.stream())
+        cache[key] = sc
+    return sc
+
+
+_FUSED_POST = os.environ.get("TABGNN_NO_FUSED_POST") != "1"
+
+
+def post_scaled_ok(x, agg):
+    """bf16, F = 128 node width, 4F-wide aggregate: the shapes tg_gemm_nt_scaled_bf16 / tg_gemm_tn_scaled_bf16 take."""
+    return (_FUSED_POST and agg.dtype == torch.bfloat16 and agg.is_cuda and x.dtype == torch.bfloat16
+            and x.dim() == 2 and nt_ok(x, x.shape[1], x.shape[1]) and agg.shape[1] % 128 == 0
+            and agg.shape[0] == x.shape[0])
+
+
+class _PNAPostScaled(torch.autograd.Function):
+    """out = x w_x^T + b + agg W_0^T + amp*(agg W_1^T) + att*(agg W_2^T) with w_st = [W_0; W_1; W_2] ([3F,4F], fp32,
+    the folded post projection): the degree scalers live inside the GEMMs (tg_gemm_nt_scaled_bf16 /
+    tg_gemm_tn_scaled_bf16), so neither G = agg w_st^T [N,3F] nor its gradient exists."""
+
+    @staticmethod
+    def forward(ctx, x, w_x, b_x, agg, w_st, graph, avg_log):
+        x, agg = x.contiguous(), agg.contiguous()
+        N, F = x.shape
+        K = agg.shape[1]
+        wx_lp = w_x.detach().to(torch.bfloat16).contiguous()
+        out = gemm_nt(x, wx_lp, b_x.detach().float().contiguous())
+        w_lp = w_st.detach().to(torch.bfloat16).view(3, F, K)
+        # [F, 3K], 128-column block 3c+s = W_s[:, 128c:128c+128] (the kernel's virtual-chunk order)
+        w_cat = w_lp.view(3, F, K // 128, 128).permute(1, 2, 0, 3).reshape(F, 3 * K).contiguous()
+        scales = degree_scalers(graph, avg_log)
+        L.call("tg_gemm_nt_scaled_bf16", L.ptr(agg), L.ptr(w_cat), L.ptr(scales), L.ptr(out), N, F, K, agg.stride(0),
+               out.stride(0), NT_ACCUM, L.stream())
+        ctx.save_for_backward(x, wx_lp, agg, w_lp, scales)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wx_lp, agg, w_lp, scales = ctx.saved_tensors
+        g = g.contiguous()
+        N, F = g.shape
+        K = agg.shape[1]
+        dx = gemm_nt(g, wx_lp.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dwx, dbx = weight_grad(g, x, True)
+        if dbx is None:
+            dbx = g.sum(0, dtype=torch.float32)
+        wt_cat = w_lp.permute(2, 0, 1).reshape(K, 3 * F).contiguous()          # [K, 3F] = [W_0^T | W_1^T | W_2^T]
+        dagg = torch.empty_like(agg)
+        L.call("tg_gemm_nt_scaled_bf16", L.ptr(g), L.ptr(wt_cat), L.ptr(scales), L.ptr(dagg), N, K, F, g.stride(0),
+               dagg.stride(0), 0, L.stream())
+        dw = torch.empty(3 * F, K, dtype=torch.float32, device=g.device)
+        ws = _workspace(L.load().tg_gemm_tn_workspace_floats(N, 3 * F, K), g.device)
+        L.call("tg_gemm_tn_scaled_bf16", L.ptr(g), L.ptr(agg), L.ptr(scales), L.ptr(dw), L.ptr(ws), N, F, K, g.stride(0),
+               agg.stride(0), 0, L.stream())
+        return dx, dwx, dbx, dagg, dw, None, None
+
+
+def pna_post_scaled(x, w_x, b_x, agg, w_st, graph, avg_log):
+    return _PNAPostScaled.apply(x, w_x, b_x, agg, w_st, graph, avg_log)
 
 
 class _GINEAggregate(torch.autograd.Function):

@@ -161,3 +161,55 @@ def test_gemm_nt_ln_equals_gemm_then_layernorm(R, K, p):
     assert (da1.float() - da2.float()).abs().max().item() < 0.06 * max(1.0, da2.float().abs().max().item())
     assert torch.equal(db1 == 0, db2 == 0) and (db1.float() - db2.float()).abs().max().item() < 0.06 * max(1.0, db2.float().abs().max().item())
     assert (dp1 - dp2).abs().max().item() < 0.02 * max(1.0, dp2.abs().max().item())
+
+
+@pytest.mark.parametrize("N,E", [(1000, 3000), (4099, 20000), (128, 50)])
+def test_pna_post_projection_with_scalers_inside_the_gemms(N, E):
+    """tg_gemm_nt_scaled_bf16 / tg_gemm_tn_scaled_bf16 (+ tg_pna_degree_scalers) against the unfused composition
+    G = agg w_st^T, out = x w_x^T + b + G0 + amp*G1 + att*G2 in fp32: output and every gradient.  Isolated nodes (amp = 0),
+    a hub destination, N not a multiple of the 128-row tile."""
+    from tabgnn_amd import ops
+    g = torch.Generator().manual_seed(N)
+    F = 128
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, max(N - 7, 1), (E,), generator=g)         # the last nodes stay isolated
+    dst[: E // 4] = 3                                                # hub
+    graph = ops.SubgraphIndex.build(torch.stack([src, dst]).to(DEV), N)
+    avg_log = torch.tensor([1.3], device=DEV)
+    x32 = torch.randn(N, F, generator=g).to(DEV)
+    wx32 = (torch.randn(F, F, generator=g) / 11.0).to(DEV)
+    b32 = torch.randn(F, generator=g).to(DEV)
+    agg32 = torch.randn(N, 4 * F, generator=g).to(DEV)
+    w32 = (torch.randn(3 * F, 4 * F, generator=g) / 22.0).to(DEV)
+    co = torch.randn(N, F, generator=g).to(DEV)
+    # fp32 reference on the bf16-rounded operands
+    xr = x32.bfloat16().float().requires_grad_(True)
+    wxr = wx32.bfloat16().float().requires_grad_(True)
+    br = b32.clone().requires_grad_(True)
+    ar = agg32.bfloat16().float().requires_grad_(True)
+    wr = w32.bfloat16().float().requires_grad_(True)
+    deg = torch.bincount(dst, minlength=N).float().to(DEV).view(-1, 1)
+    amp = torch.log(deg + 1) / avg_log
+    att = avg_log / torch.log(deg.clamp(min=1) + 1)
+    G = ar @ wr.t()
+    ref = xr @ wxr.t() + br + G[:, :F] + amp * G[:, F:2 * F] + att * G[:, 2 * F:]
+    (ref * co).sum().backward()
+    # fused
+    x = x32.bfloat16().requires_grad_(True)
+    wx = wx32.bfloat16().float().requires_grad_(True)
+    b = b32.clone().requires_grad_(True)
+    agg = agg32.bfloat16().requires_grad_(True)
+    w = w32.bfloat16().float().requires_grad_(True)
+    assert ops.post_scaled_ok(x, agg)
+    out = ops.pna_post_scaled(x, wx, b, agg, w, graph, avg_log)
+    (out.float() * co).sum().backward()
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm().clamp_min(1e-12)).item()
+    assert rel(out, ref.detach()) < 0.01, rel(out, ref.detach())
+    assert rel(x.grad, xr.grad) < 0.01
+    assert rel(wx.grad, wxr.grad) < 0.01 and rel(b.grad, br.grad) < 0.01
+    assert rel(agg.grad, ar.grad) < 0.02, rel(agg.grad, ar.grad)
+    assert rel(w.grad, wr.grad) < 0.02, rel(w.grad, wr.grad)
+    sc = ops.degree_scalers(graph, avg_log)
+    assert sc.shape[0] % 128 == 0 and sc.shape[0] >= N
+    torch.testing.assert_close(sc[:N, 0:1], amp, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sc[:N, 1:2], att, rtol=1e-5, atol=1e-6)
