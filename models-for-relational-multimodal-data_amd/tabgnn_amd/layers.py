@@ -148,24 +148,17 @@ class PNAConv(nn.Module):
         F = self.F
         g = ops.SubgraphIndex.build(edge_index, x.shape[0])
         pre, post = self.pre_nns[0][0], self.post_nns[0][0]
-        # message: W_pre [x_i, x_j, W_e e + b_e] + b_pre
-        w3 = pre.weight[:, 2 * F:] @ self.edge_encoder.weight
-        w_msg = torch.cat([pre.weight[:, :2 * F], w3], dim=1)
-        b_msg = pre.bias + pre.weight[:, 2 * F:] @ self.edge_encoder.bias
+        # message: W_pre [x_i, x_j, W_e e + b_e] + b_pre;  lin(post([x, agg, amp*agg, att*agg])) = x Wx^T + b +
+        # (agg Wid^T) + amp (agg Wamp^T) + att (agg Watt^T): both folds on the (tiny) weights, one autograd node
+        w_msg, b_msg, w_x, b_eff, w_st = ops.fold_pna_weights(pre.weight, pre.bias, self.edge_encoder.weight,
+                                                              self.edge_encoder.bias, post.weight, post.bias,
+                                                              self.lin.weight, self.lin.bias, self.agg_order)
         # messages are produced directly in destination-sorted order: the aggregation then streams contiguous rows
         h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst_sorted"), w_msg, b_msg)
         agg = ops.pna_aggregate(h, g, sorted_rows=True)                 # [N,4F]
-        # lin(post([x, agg, amp*agg, att*agg])) = x Wx^T + b + (agg Wid^T) + amp (agg Wamp^T) + att (agg Watt^T)
-        w_eff = self.lin.weight @ post.weight                            # [F,13F]
-        b_eff = self.lin.weight @ post.bias + self.lin.bias
-        if self.agg_order == [0, 1, 2, 3]:
-            w_st = torch.cat([w_eff[:, F:5 * F], w_eff[:, 5 * F:9 * F], w_eff[:, 9 * F:]], dim=0)   # [3F,4F]
-        else:                                                           # column blocks re-ordered to the kernel's layout
-            blk = lambda sc, j: w_eff[:, F + (sc * 4 + j) * F:F + (sc * 4 + j + 1) * F]
-            w_st = torch.cat([torch.cat([blk(sc, j) for j in self.agg_order], dim=1) for sc in range(3)], dim=0)
         if ops.post_scaled_ok(x, agg):          # scalers inside the GEMMs: G [N,3F] and its gradient never exist
-            return ops.pna_post_scaled(x, w_eff[:, :F], b_eff, agg, w_st, g, self.aggr_module.avg_deg_log)
-        xw = ops.linear(x, w_eff[:, :F], b_eff)
+            return ops.pna_post_scaled(x, w_x, b_eff, agg, w_st, g, self.aggr_module.avg_deg_log)
+        xw = ops.linear(x, w_x, b_eff)
         G = ops.linear(agg, w_st, None)
         return ops.pna_scale_combine(xw, G, g, self.aggr_module.avg_deg_log)
 

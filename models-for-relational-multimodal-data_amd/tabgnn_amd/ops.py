@@ -730,6 +730,75 @@ def pna_scale_combine(xw, G, graph, avg_log):
     return _ScaleCombine.apply(xw, G, graph, avg_log)
 
 
+class _FoldPNAWeights(torch.autograd.Function):
+    """The two weight folds of PNAConv as ONE autograd node with a hand-written backward (the op-by-op version cost
+    ~40 five-microsecond launches per convolution: slice/cat backward fills and copies, AccumulateGrad adds):
+
+        w_msg = [P[:, :2F] | P[:, 2F:] We],  b_msg = pb + P[:, 2F:] be          (edge_encoder into pre_nn)
+        w_eff = Lw Qw,  b_eff = Lw qb + lb;  w_x = w_eff[:, :F]                  (lin into post_nn)
+        w_st[s] = [w_eff block (s, agg_order[k])  for k in mean, max, min, std]  ([3F,4F], the kernel's layout)
+
+    Parameter gradients are added straight into existing ``.grad`` buffers (FlatParams views) with addmm_/addmv_."""
+
+    @staticmethod
+    def forward(ctx, P, pb, We, be, Qw, qb, Lw, lb, agg_order):
+        F = P.shape[0]
+        P3 = P[:, 2 * F:]
+        w_msg = torch.cat([P[:, :2 * F], P3 @ We], dim=1)
+        b_msg = torch.addmv(pb, P3, be)
+        w_eff = Lw @ Qw                                                         # [F,13F]
+        b_eff = torch.addmv(lb, Lw, qb)
+        w4 = w_eff[:, F:].view(F, 3, 4, F)
+        if list(agg_order) != [0, 1, 2, 3]:
+            w4 = w4[:, :, list(agg_order), :]
+        w_st = w4.permute(1, 0, 2, 3).reshape(3 * F, 4 * F)
+        w_x = w_eff[:, :F].contiguous()
+        ctx.save_for_backward(P, We, be, Qw, qb, Lw)
+        ctx.agg_order = list(agg_order)
+        ctx.params = (P, pb, We, be, Qw, qb, Lw, lb)
+        return w_msg, b_msg, w_x, b_eff, w_st
+
+    @staticmethod
+    def backward(ctx, dw_msg, db_msg, dw_x, db_eff, dw_st):
+        P, We, be, Qw, qb, Lw = ctx.saved_tensors
+        F = P.shape[0]
+        z = lambda t, *shape: P.new_zeros(*shape) if t is None else t
+        dw_msg, db_msg = z(dw_msg, F, 2 * F + We.shape[1]), z(db_msg, F)
+        dw_x, db_eff, dw_st = z(dw_x, F, F), z(db_eff, F), z(dw_st, 3 * F, 4 * F)
+        P3 = P[:, 2 * F:]
+        d3 = dw_msg[:, 2 * F:]
+        dP = torch.cat([dw_msg[:, :2 * F], torch.addmm(torch.outer(db_msg, be), d3, We.t())], dim=1)
+        dWe = P3.t() @ d3
+        dbe = P3.t() @ db_msg
+        d4 = dw_st.view(3, F, 4, F).permute(1, 0, 2, 3)                          # [F,3,4,F] in the kernel's order
+        if ctx.agg_order != [0, 1, 2, 3]:
+            inv = [ctx.agg_order.index(j) for j in range(4)]
+            d4 = d4[:, :, inv, :]
+        dw_eff = torch.cat([dw_x, d4.reshape(F, 12 * F)], dim=1)                # [F,13F]
+        grads = [dP, db_msg, dWe, dbe, None, None, None, db_eff]
+        out = []
+        # Qw, qb, Lw: GEMM-shaped gradients; add into the flat gradient buffer in the same launch when there is one
+        tq, tqb, tl = (_grad_target(p) if isinstance(p, torch.nn.Parameter) else None for p in ctx.params[4:7])
+        if tq is not None:
+            tq.addmm_(Lw.t(), dw_eff)
+        else:
+            grads[4] = Lw.t() @ dw_eff
+        if tqb is not None:
+            tqb.addmv_(Lw.t(), db_eff)
+        else:
+            grads[5] = Lw.t() @ db_eff
+        if tl is not None:
+            tl.addmm_(dw_eff, Qw.t())
+            tl.addr_(db_eff, qb)
+        else:
+            grads[6] = torch.addmm(torch.outer(db_eff, qb), dw_eff, Qw.t())
+        return (*grads, None)
+
+
+def fold_pna_weights(P, pb, We, be, Qw, qb, Lw, lb, agg_order):
+    return _FoldPNAWeights.apply(P, pb, We, be, Qw, qb, Lw, lb, tuple(agg_order))
+
+
 def degree_scalers(graph, avg_log):
     """fp32 (amp, att) per node of ``graph`` (by-destination degrees), cached on the graph per scaler buffer.  Rows are
     padded (with zeros) to a whole number of 128-row GEMM tiles, as tg_gemm_nt_scaled_bf16 addresses them."""
