@@ -542,7 +542,9 @@ class _Axpby(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         alpha, beta = ctx.cfg
-        return g * alpha, g * beta, None, None
+        ga = g if alpha == 1.0 else g * alpha                 # one scaled copy serves both inputs when alpha == beta
+        gb = ga if beta == alpha else (g if beta == 1.0 else g * beta)
+        return ga, gb, None, None
 
 
 def axpby(a, b, alpha, beta):
