@@ -759,7 +759,7 @@ extern "C" int tg_act_dropout_fwd(const void* x, void* y, int64_t n, int32_t act
   unsigned thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   DISPATCH_T(dt, {
-    hipLaunchKernelGGL((k_act_dropout_fwd<T, VEC>), dim3(grid_cap(ceil_div(ceil_div(n, VEC), 256))), dim3(256), 0,
+    hipLaunchKernelGGL((k_act_dropout_fwd<T, VEC>), dim3(grid_full(ceil_div(ceil_div(n, VEC), 256))), dim3(256), 0,
                        (hipStream_t)stream, (const T*)x, (T*)y, (long long)n, act, thresh, inv_keep,
                        (unsigned long long)seed, rstream);
   })
@@ -773,7 +773,7 @@ extern "C" int tg_act_dropout_bwd(const void* x, const void* dy, void* dx, int64
   unsigned thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   DISPATCH_T(dt, {
-    hipLaunchKernelGGL((k_act_dropout_bwd<T, VEC>), dim3(grid_cap(ceil_div(ceil_div(n, VEC), 256))), dim3(256), 0,
+    hipLaunchKernelGGL((k_act_dropout_bwd<T, VEC>), dim3(grid_full(ceil_div(ceil_div(n, VEC), 256))), dim3(256), 0,
                        (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, (long long)n, act, thresh, inv_keep,
                        (unsigned long long)seed, rstream);
   })
@@ -786,7 +786,7 @@ extern "C" int tg_axpby(const void* a, const void* b, void* y, int64_t n, float 
   TG_CHECK(n % 8 == 0, "tg_axpby: n must be a multiple of 8 (n=%lld)", (long long)n);
   if (n == 0) return 0;
   DISPATCH_T(dt, {
-    hipLaunchKernelGGL((k_axpby<T, VEC>), dim3(grid_cap(ceil_div(n / VEC, 256))), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((k_axpby<T, VEC>), dim3(grid_full(ceil_div(n / VEC, 256))), dim3(256), 0, (hipStream_t)stream,
                        (const T*)a, (const T*)b, (T*)y, (long long)n, alpha, beta);
   })
   TG_LAUNCH_CHECK();
