@@ -256,11 +256,11 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
         NT_SCALEX(v % 3)
         NT_STOREX()
         NT_STOREW()
-        __syncthreads();
         const int vn = v + 1;
-        NT_LOADX((vn / 3) * NT_BK)
-        NT_LOADW(n0, vn * NT_BK)
+        NT_LOADX((vn / 3) * NT_BK)                    // issued before the barrier: the wait for the other waves'
+        NT_LOADW(n0, vn * NT_BK)                      // LDS stores overlaps the next chunk's HBM/L2 latency
         NT_LOADSCALES(vn % 3)
+        __syncthreads();
         NT_MFMA_CHUNK()
         __syncthreads();
       }
@@ -280,9 +280,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
     for (; k0 + NT_BK < K; k0 += NT_BK) {
       NT_STOREX()                                     // waits for the chunk's loads; registers free again
       NT_STOREW()
+      NT_LOADX(k0 + NT_BK)                            // next k chunk's loads fly under the barrier and this chunk's
+      NT_LOADW(n0, k0 + NT_BK)                        // MFMAs
       __syncthreads();
-      NT_LOADX(k0 + NT_BK)                            // next k chunk's loads fly under this chunk's MFMAs
-      NT_LOADW(n0, k0 + NT_BK)
       NT_MFMA_CHUNK()
       __syncthreads();                                // both images consumed
     }
@@ -339,9 +339,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_ln_bf16(const unsigned short
   for (; k0 + NT_BK < K; k0 += NT_BK) {
     NT_STOREX()
     NT_STOREW()
-    __syncthreads();
     NT_LOADX(k0 + NT_BK)
     NT_LOADW(n0, k0 + NT_BK)
+    __syncthreads();
     NT_MFMA_CHUNK()
     __syncthreads();
   }
