@@ -241,7 +241,7 @@ def main():
         return edges
 
     run(args.warmup, 0)
-    timer = ops.KernelTimer()
+    timer = ops.KernelTimer(only=("tg_pna_aggregate_fwd", "tg_pna_aggregate_bwd"))   # 4 event pairs per step
     ops.KernelTimer.active = timer
     if use_dist:
         dist.barrier()
@@ -302,6 +302,22 @@ def main():
                      "launches_timed": timer.count("tg_pna_aggregate_fwd"),
                      "bwd_avg_launch_ms": timer.mean_ms("tg_pna_aggregate_bwd")},
     }
+    # the kernels that dominate the step by TIME, measured the same way (HIP events on the launching stream,
+    # algorithmic bytes R*(K+N)*2 (+ gate / accumulate reads) and R*(M+N)*2 per launch) in a few extra steps AFTER the
+    # timed region: 75 more event pairs per step would cost the headline number ~0.5 ms
+    gemms = {}
+    if world == 1 and args.dtype == "bf16":
+        gt = ops.KernelTimer(only=("tg_gemm_nt_bf16", "tg_gemm_tn_bf16"))
+        ops.KernelTimer.active = gt
+        run(3, args.warmup + args.steps)
+        torch.cuda.synchronize()
+        ops.KernelTimer.active = None
+        for name in gt.only:
+            if gt.count(name):
+                gemms[name] = {"launches_per_step": gt.count(name) / 3, "ms_per_step": gt.total_ms(name) / 3,
+                               "achieved": gt.gbs(name), "frac": gt.gbs(name) / HBM_PEAK_GBS}
+    if gemms:
+        out["roofline_gemm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": gemms}
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(model.state_dict(), args.nhead, args.cpu_batch_size, args.cpu_steps,
                                            cfg["lr"], cfg["loss_weights"])

@@ -37,15 +37,26 @@ class KernelTimer:
     """HIP-event timing of selected launches on the stream they run on (bench.py's live roofline measurement)."""
     active = None
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.spans = {}
+        self.nbytes = {}
+        self.only = None if only is None else set(only)      # time just these entry points (None = every _launch)
 
-    def timed(self, name, fn):
+    def timed(self, name, fn, nbytes=0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
         self.spans.setdefault(name, []).append((e0, e1))
+        self.nbytes[name] = self.nbytes.get(name, 0) + int(nbytes)
+
+    def total_ms(self, name):
+        return sum(a.elapsed_time(b) for a, b in self.spans.get(name, []))
+
+    def gbs(self, name):
+        """Algorithmic bytes of all timed launches of ``name`` over their summed duration."""
+        t = self.total_ms(name)
+        return self.nbytes.get(name, 0) / (t * 1e-3) / 1e9 if t > 0 else float("nan")
 
     def mean_ms(self, name):
         sp = self.spans.get(name, [])
@@ -55,12 +66,12 @@ class KernelTimer:
         return len(self.spans.get(name, []))
 
 
-def _launch(name, *args):
+def _launch(name, *args, nbytes=0):
     t = KernelTimer.active
-    if t is None:
+    if t is None or (t.only is not None and name not in t.only):
         L.call(name, *args)
     else:
-        t.timed(name, lambda: L.call(name, *args))
+        t.timed(name, lambda: L.call(name, *args), nbytes)
 
 
 def _workspace(n_floats, device):
@@ -169,8 +180,10 @@ def gemm_nt(x2, w, bias=None, flags=0, p=0.0, seed=0, rs=0, out=None, gate=None)
         out = torch.empty(R, N, dtype=x2.dtype, device=x2.device)
     if bias is not None and bias.dtype != torch.float32:
         bias = bias.float()
-    L.call("tg_gemm_nt_bf16", x2.data_ptr(), L.ptr(w), L.ptr(bias), L.ptr(gate), L.ptr(out), R, N, K, x2.stride(0), out.stride(0),
-            int(flags), float(p), int(seed), int(rs), L.stream())
+    # algorithmic bytes (bench.py's live roofline of the GEMMs): X in, Y out, + the gate / the old Y when read
+    nb = 2 * R * (K + N + (N if flags & NT_GATE else 0) + (N if flags & NT_ACCUM else 0))
+    _launch("tg_gemm_nt_bf16", x2.data_ptr(), L.ptr(w), L.ptr(bias), L.ptr(gate), L.ptr(out), R, N, K, x2.stride(0),
+            out.stride(0), int(flags), float(p), int(seed), int(rs), L.stream(), nbytes=nb)
     return out
 
 
@@ -279,8 +292,8 @@ def weight_grad(g2, x2, want_bias=False, wparam=None, bparam=None):
         out = wg if acc else torch.empty(M, N, dtype=torch.float32, device=g2.device)
         db = (bg if acc else torch.empty(M, dtype=torch.float32, device=g2.device)) if want_bias else None
         ws = _workspace(L.load().tg_gemm_tn_workspace_floats(R, M, N), g2.device)
-        L.call("tg_gemm_tn_bf16", g2.data_ptr(), x2.data_ptr(), L.ptr(out), L.ptr(db), L.ptr(ws), R, M, N,
-               g2.stride(0), x2.stride(0), int(acc), L.stream())
+        _launch("tg_gemm_tn_bf16", g2.data_ptr(), x2.data_ptr(), L.ptr(out), L.ptr(db), L.ptr(ws), R, M, N,
+                g2.stride(0), x2.stride(0), int(acc), L.stream(), nbytes=2 * R * (M + N))
         return (None, None) if acc else (out, db)
     if wg is not None and wg.dtype == g2.dtype:          # fp32 parity mode: one GEMM with beta = 1
         wg.addmm_(g2.t(), x2)
