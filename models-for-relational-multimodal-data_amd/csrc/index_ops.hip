@@ -26,10 +26,38 @@ __global__ void k_ids_to_i32(const long long* __restrict__ in, int* __restrict__
 }
 
 // ------------------------------------------------------------------ histogram / scan / fill / rank
-__global__ void k_hist(const int* __restrict__ key, long long M, int* __restrict__ rowptr) {
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < M; i += stride) atomicAdd(&rowptr[key[i] + 1], 1);
+// Hot keys (a hub account with 12.8 k of the 438 k edges) serialise global atomics on one address: 147 us here and
+// again in k_fill.  Each block therefore counts its CSR_CH consecutive keys in a small LDS table first (slot =
+// hash(key); the first key to arrive owns the slot, other keys hashing there go straight to global memory) and
+// flushes one global atomic per occupied slot: the hub costs one global atomic per block instead of ~60.
+constexpr int CSR_KPT = 8, CSR_CH = 256 * CSR_KPT, CSR_HS = 512;
+__device__ __forceinline__ int csr_slot(int k) { return (int)(((unsigned)k * 2654435761u) >> 23) & (CSR_HS - 1); }
+__device__ __forceinline__ bool csr_own(int* tag, int slot, int k) {
+  int t = tag[slot];
+  if (t == -1) {
+    t = atomicCAS(&tag[slot], -1, k);
+    if (t == -1) t = k;
+  }
+  return t == k;
+}
+
+__global__ void __launch_bounds__(256) k_hist(const int* __restrict__ key, long long M, int* __restrict__ rowptr) {
+  __shared__ int tag[CSR_HS], cnt[CSR_HS];
+  for (int i = threadIdx.x; i < CSR_HS; i += 256) { tag[i] = -1; cnt[i] = 0; }
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * CSR_CH;
+#pragma unroll
+  for (int j = 0; j < CSR_KPT; ++j) {
+    const long long i = base + j * 256 + threadIdx.x;
+    if (i < M) {
+      const int k = key[i], slot = csr_slot(k);
+      if (csr_own(tag, slot, k)) atomicAdd(&cnt[slot], 1);
+      else atomicAdd(&rowptr[k + 1], 1);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CSR_HS; i += 256)
+    if (cnt[i]) atomicAdd(&rowptr[tag[i] + 1], cnt[i]);
 }
 
 constexpr int SCAN_T = 256, SCAN_E = 8, SCAN_CHUNK = SCAN_T * SCAN_E;
@@ -109,12 +137,33 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_add(int* __restrict__ a, long l
   }
 }
 
-__global__ void k_fill(const int* __restrict__ key, long long M, int* __restrict__ cursor, int* __restrict__ tmp) {
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < M; i += stride) {
-    int pos = atomicAdd(&cursor[key[i]], 1);
-    tmp[pos] = (int)i;
+// slot of every element inside its key's segment (any order: k_rank makes it stable afterwards); hot keys take their
+// positions from the block's LDS table and ONE global cursor bump per (block, key), see k_hist
+__global__ void __launch_bounds__(256) k_fill(const int* __restrict__ key, long long M, int* __restrict__ cursor,
+                                              int* __restrict__ tmp) {
+  __shared__ int tag[CSR_HS], cnt[CSR_HS];
+  for (int i = threadIdx.x; i < CSR_HS; i += 256) { tag[i] = -1; cnt[i] = 0; }
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * CSR_CH;
+  int local[CSR_KPT];                                 // >= 0: rank inside the block's share of the key; -1: done / none
+#pragma unroll
+  for (int j = 0; j < CSR_KPT; ++j) {
+    const long long i = base + j * 256 + threadIdx.x;
+    local[j] = -1;
+    if (i < M) {
+      const int k = key[i], slot = csr_slot(k);
+      if (csr_own(tag, slot, k)) local[j] = atomicAdd(&cnt[slot], 1);
+      else tmp[atomicAdd(&cursor[k], 1)] = (int)i;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CSR_HS; i += 256)
+    if (cnt[i]) cnt[i] = atomicAdd(&cursor[tag[i]], cnt[i]);      // cnt := the block's base position for that key
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CSR_KPT; ++j) {
+    const long long i = base + j * 256 + threadIdx.x;
+    if (local[j] >= 0) tmp[cnt[csr_slot(key[i])] + local[j]] = (int)i;
   }
 }
 
@@ -362,13 +411,13 @@ extern "C" int tg_csr_build(const int32_t* key, int64_t M, int32_t N, int32_t* r
   int* totals = work + n1 + M;     // [nchunks]
   zero_async(rowptr, (size_t)n1 * sizeof(int), st);
   if (M > 0) {
-    hipLaunchKernelGGL(k_hist, dim3(grid_cap(ceil_div(M, 256))), dim3(256), 0, st, key, (long long)M, rowptr);
+    hipLaunchKernelGGL(k_hist, dim3(ceil_div(M, CSR_CH)), dim3(256), 0, st, key, (long long)M, rowptr);
   }
   hipLaunchKernelGGL(k_scan_chunks, dim3(nchunks), dim3(SCAN_T), 0, st, rowptr, n1, totals);
   hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, st, totals, nchunks);
   hipLaunchKernelGGL(k_scan_add, dim3(nchunks), dim3(SCAN_T), 0, st, rowptr, n1, totals, cursor);
   if (M > 0) {
-    hipLaunchKernelGGL(k_fill, dim3(grid_cap(ceil_div(M, 256))), dim3(256), 0, st, key, (long long)M, cursor, tmp);
+    hipLaunchKernelGGL(k_fill, dim3(ceil_div(M, CSR_CH)), dim3(256), 0, st, key, (long long)M, cursor, tmp);
     int* hub = totals + nchunks + 8;   // [2 + M / RANK_HUB]
     zero_async(hub, sizeof(int), st);
     hipLaunchKernelGGL(k_rank, dim3(grid_cap(ceil_div(M, 256), 256 * 16)), dim3(256), 0, st, key, rowptr, tmp, perm,
