@@ -98,6 +98,17 @@ int tg_ln_bwd(const void* a, const void* b, const float* bias_b, const float* ga
               these [C] buffers (the parameters' .grad) instead of being written to dparams; a NULL one is skipped */,
               int32_t dt, void* stream);
 
+/* The last two LayerNorm backwards of the encoder layer (tab_norm after norm2: out = alpha*x + beta_c*LN_t(x2),
+ * x2 = LN_2(z2), z2 = x1 + dropout(y2 + b2), fused.py:249 over torch's post-norm layer) in one pass: the gradient of
+ * x2 never reaches HBM.  Inputs x2, z2 [M,C], their statistics (mean, rstd) pairs, dout; outputs dres = alpha*dout
+ * (NULL when alpha == 0), d_x1 = dL/dz2, d_y2 = d_x1 * dropout mask (same counter RNG site as the forward).
+ * dparams [5C] = (dgamma_t, dbeta_t, dgamma_2, dbeta_2, dbias_2) is written, or — acc != NULL: five [C] pointers,
+ * NULL entries skipped — the sums are ADDED to those buffers.  partials: 2048*5*C floats. */
+int tg_ln_tail_ln_bwd(const void* x2, const void* z2, const float* gamma_t, const float* stats3, const float* gamma_2,
+                      const float* stats2, const void* dout, void* dres, void* d_x1, void* d_y2, float* dparams,
+                      float* partials, int64_t M, int32_t C, float alpha, float beta_c, float p_drop, uint64_t seed,
+                      uint32_t rstream, float* const* acc, int32_t dt, void* stream);
+
 /* ---- BatchNorm1d (+ReLU) with residual combine: out = alpha*res + beta_c*relu(BN(x))
  *      (torch_geometric BatchNorm -> BatchNorm1d; fused.py:214,252; tabgnn.py:172,188) ------------------- */
 int tg_bn_partials_floats(int64_t N, int32_t F);

@@ -589,6 +589,176 @@ __global__ void k_cls_merge_fwd(const T* __restrict__ xtab, const T* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------ tail LayerNorm + norm2 backward in one pass
+// The encoder layer ends  x2 = LN2(z2),  out = alpha*x + beta_c*LN_t(x2)  (encoder_layer.py).  Run as two k_ln_bwd
+// launches the gradient d_x2 [rows, C] is written by the first and read back by the second; here it stays in
+// registers:  dout -> (d_x2) -> d_x1 = dLN2/dz2,  d_y2 = d_x1 * dropout mask,  plus dres = alpha*dout and the five
+// parameter-gradient column sums (dgamma_t, dbeta_t, dgamma_2, dbeta_2, dbias_2) through per-block partials.
+// Reads x2, z2, dout (+ two stats pairs); writes dres, d_x1, d_y2: 6 row streams instead of 8.
+template <typename T, int VEC, int VPL>
+__global__ void __launch_bounds__(LN_BLOCK) k_ln_tail_ln_bwd(const T* __restrict__ x2, const T* __restrict__ z2,
+                                                              const float* __restrict__ gamma_t,
+                                                              const float* __restrict__ stats3,
+                                                              const float* __restrict__ gamma_2,
+                                                              const float* __restrict__ stats2,
+                                                              const T* __restrict__ dout, T* __restrict__ dres,
+                                                              T* __restrict__ d_x1, T* __restrict__ d_y2,
+                                                              float* __restrict__ partials, long long M, int C, int lpr,
+                                                              float alpha, float beta_c, unsigned thresh, float inv_keep,
+                                                              unsigned long long seed, unsigned rstream) {
+  extern __shared__ float red[];  // [groups][5][C]
+  const int groups = LN_BLOCK / lpr;
+  const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
+  long long row = (long long)blockIdx.x * groups + gi;
+  const long long rstride = (long long)gridDim.x * groups;
+  const int nvec = C / VEC;
+  float agt[VPL][VEC], abt[VPL][VEC], ag2[VPL][VEC], ab2[VPL][VEC], abs_[VPL][VEC];   // the five column sums
+  float gtr[VPL][VEC], g2r[VPL][VEC];                                                  // gamma_t, gamma_2 in registers
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int vi = gl + k * lpr;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      agt[k][j] = abt[k][j] = ag2[k][j] = ab2[k][j] = abs_[k][j] = 0.f;
+      const bool ok = vi < nvec;
+      gtr[k][j] = ok ? gamma_t[vi * VEC + j] : 0.f;
+      g2r[k][j] = ok ? gamma_2[vi * VEC + j] : 0.f;
+    }
+  }
+  for (; row < M; row += rstride) {
+    const float mu3 = stats3[2 * row], rstd3 = stats3[2 * row + 1];
+    const float mu2 = stats2[2 * row], rstd2 = stats2[2 * row + 1];
+    float xh[VPL][VEC], gx[VPL][VEC], zh[VPL][VEC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int vi = gl + k * lpr;
+      if (vi < nvec) {
+        const int c = vi * VEC;
+        float x[VEC], g[VEC], z[VEC];
+        loadv<T, VEC>(x2 + row * C + c, x);
+        loadv<T, VEC>(dout + row * C + c, g);
+        loadv<T, VEC>(z2 + row * C + c, z);          // needed after the first reduction: in flight with the others
+        if (dres) {
+          float r[VEC];
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) r[j] = alpha * g[j];
+          storev<T, VEC>(dres + row * C + c, r);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float gj = g[j] * beta_c;
+          xh[k][j] = (x[j] - mu3) * rstd3;
+          zh[k][j] = (z[j] - mu2) * rstd2;
+          agt[k][j] += gj * xh[k][j];
+          abt[k][j] += gj;
+          gx[k][j] = gj * gtr[k][j];
+          s1 += gx[k][j];
+          s2 += gx[k][j] * xh[k][j];
+        }
+      }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int vi = gl + k * lpr;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float dx2 = rstd3 * (gx[k][j] - m1 - xh[k][j] * m2);     // gradient of x2, never leaves the registers
+          ag2[k][j] += dx2 * zh[k][j];
+          ab2[k][j] += dx2;
+          gx[k][j] = dx2 * g2r[k][j];
+          t1 += gx[k][j];
+          t2 += gx[k][j] * zh[k][j];
+        }
+      }
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+    const float n1 = t1 / (float)C, n2 = t2 / (float)C;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+      const int vi = gl + k * lpr;
+      if (vi < nvec) {
+        const int c = vi * VEC;
+        float d[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d[j] = rstd2 * (gx[k][j] - n1 - zh[k][j] * n2);
+        storev<T, VEC>(d_x1 + row * C + c, d);
+        const unsigned long long e0 = (unsigned long long)(row * C + c);
+        const unsigned key = rng_key(seed, rstream, (unsigned)(e0 >> 32));
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float m = drop_scale_key(key, (unsigned)e0 + j, thresh, inv_keep);
+          m = thresh ? m : 1.f;
+          d[j] *= m;
+          abs_[k][j] += d[j];
+        }
+        storev<T, VEC>(d_y2 + row * C + c, d);
+      }
+    }
+  }
+  // block reduction of the five column sums (fixed order -> deterministic)
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int vi = gl + k * lpr;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const int c = vi * VEC + j;
+        red[(gi * 5 + 0) * C + c] = agt[k][j];
+        red[(gi * 5 + 1) * C + c] = abt[k][j];
+        red[(gi * 5 + 2) * C + c] = ag2[k][j];
+        red[(gi * 5 + 3) * C + c] = ab2[k][j];
+        red[(gi * 5 + 4) * C + c] = abs_[k][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 5 * C; i += LN_BLOCK) {
+    float t = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) t += red[g2 * 5 * C + i];
+    partials[(long long)blockIdx.x * 5 * C + i] = t;
+  }
+}
+
+struct AccPtrs5 { float* o[5]; };
+// out_s[c] += sum over blocks of partials[blk][s][c] for the five column sums (NULL targets are skipped)
+__global__ void __launch_bounds__(1024) k_reduce_partials_acc5(const float* __restrict__ partials, int nblk, int C,
+                                                                AccPtrs5 acc) {
+  __shared__ float red[RP_STRIPS][64];
+  const int width = 5 * C;
+  const int lane = threadIdx.x & 63, strip = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float t = 0.f;
+  if (col < width) {
+    const int per = (nblk + RP_STRIPS - 1) / RP_STRIPS, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    int b = b0;
+    for (; b + 7 < b1; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += partials[(long long)(b + u) * width + col];
+    }
+    for (; b < b1; ++b) a[0] += partials[(long long)b * width + col];
+    t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+  red[strip][lane] = t;
+  __syncthreads();
+  if (strip == 0 && col < width) {
+    float r = 0.f;
+#pragma unroll
+    for (int u = 0; u < RP_STRIPS; ++u) r += red[u][lane];
+    const int seg = col / C, c = col - seg * C;
+    float* o = acc.o[seg];
+    if (o) o[c] += r;
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -676,6 +846,48 @@ extern "C" int tg_ln_bwd(const void* a, const void* b, const float* bias_b, cons
                        acc_beta, acc_bias);
   else
     hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(3 * C, 64)), dim3(1024), 0, st, partials, grid, 3 * C, dparams);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Tail LayerNorm backward + norm2 backward ("z mode") of the encoder layer in one pass (k_ln_tail_ln_bwd).
+// dparams: float[5*C] = (dgamma_t, dbeta_t, dgamma_2, dbeta_2, dbias_2), written — or, when acc != NULL (five [C]
+// pointers, NULL entries skipped), added into the parameters' gradient buffers instead.
+// partials: 2048 * 5 * C floats.  dres may be NULL (alpha == 0).
+extern "C" int tg_ln_tail_ln_bwd(const void* x2, const void* z2, const float* gamma_t, const float* stats3,
+                                 const float* gamma_2, const float* stats2, const void* dout, void* dres, void* d_x1,
+                                 void* d_y2, float* dparams, float* partials, int64_t M, int32_t C, float alpha,
+                                 float beta_c, float p_drop, uint64_t seed, uint32_t rstream, float* const* acc,
+                                 int32_t dt, void* stream) {
+  TG_CHECK(C % 8 == 0 && C <= 2048, "tg_ln_tail_ln_bwd: C must be a multiple of 8 and <= 2048 (C=%d)", C);
+  TG_CHECK(x2 && z2 && gamma_t && stats3 && gamma_2 && stats2 && dout && d_x1 && d_y2 && partials && (dparams || acc),
+           "tg_ln_tail_ln_bwd: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (!acc) zero_async(dparams, 5 * (size_t)C * sizeof(float), st);
+    return 0;
+  }
+  unsigned thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  float inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  int grid = 1;
+  DISPATCH_T(dt, {
+    int lpr, vpl;
+    TG_CHECK(ln_geometry(C, VEC, lpr, vpl) == 0, "tg_ln_tail_ln_bwd: unsupported width C=%d", C);
+    int groups = LN_BLOCK / lpr;
+    grid = grid_cap(ceil_div(M, groups), 2048);
+    size_t shm = (size_t)groups * 5 * C * sizeof(float);
+    TG_CHECK(shm <= 160 * 1024, "tg_ln_tail_ln_bwd: LDS %zu too large", shm);
+    LN_LAUNCH(k_ln_tail_ln_bwd, vpl, dim3(grid), dim3(LN_BLOCK), shm, st, (const T*)x2, (const T*)z2, gamma_t, stats3,
+              gamma_2, stats2, (const T*)dout, (T*)dres, (T*)d_x1, (T*)d_y2, partials, (long long)M, C, lpr, alpha,
+              beta_c, thresh, inv_keep, (unsigned long long)seed, rstream);
+  })
+  if (acc) {
+    AccPtrs5 a;
+    for (int i = 0; i < 5; ++i) a.o[i] = acc[i];
+    hipLaunchKernelGGL(k_reduce_partials_acc5, dim3(ceil_div(5 * C, 64)), dim3(1024), 0, st, partials, grid, C, a);
+  } else {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(5 * C, 64)), dim3(1024), 0, st, partials, grid, 5 * C, dparams);
+  }
   TG_LAUNCH_CHECK();
   return 0;
 }

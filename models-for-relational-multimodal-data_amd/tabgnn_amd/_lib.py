@@ -36,6 +36,8 @@ SIGNATURES = {
     "tg_ln_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _u64, _u32, _i32, _vp],
     "tg_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _u64, _u32,
                   _i32, _vp, _vp, _vp, _i32, _vp],
+    "tg_ln_tail_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _u64,
+                          _u32, _vp, _i32, _vp],
     "tg_bn_partials_floats": [_i64, _i32],
     "tg_bn_act_res_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _i32, _f32,
                           _f32, _i64, _i32, _i32, _vp],

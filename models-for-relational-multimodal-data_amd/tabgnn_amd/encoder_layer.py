@@ -13,10 +13,15 @@ schedule is past them.
 """
 from __future__ import annotations
 
+import ctypes
+import os
+
 import torch
 
 from . import _lib as L
 from . import ops
+
+_FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B switch
 
 
 def _ln_fwd(a, b, bias_b, gamma, beta, res, alpha, beta_c, p, seed, rs, eps=1e-5):
@@ -103,21 +108,43 @@ class _EncoderLayerFn(torch.autograd.Function):
         g = g.contiguous().view(T, C)
         dgt = dbt = None
         d_x = None
-        if tail:                                         # out = alpha*x + beta_c*LN_t(x2)
-            d_x2 = torch.empty_like(x2)
-            d_x = torch.empty_like(x2) if alpha != 0.0 else None
-            _, dp = _ln_bwd(x2, None, None, gt, st3, g, d_x2, False, d_x, alpha, beta_c, 0.0, 0, 0, False,
-                            ops.ln_grad_targets(*ctx.ln_params[2]))
-            dgt, dbt = dp[0], dp[1]
-        else:
-            d_x2 = g
         tg1, tg2 = ops.ln_grad_targets(*ctx.ln_params[0]), ops.ln_grad_targets(*ctx.ln_params[1])
-        # x2 = LN2(x1 + drop(y2 + b2))
         d_x1 = torch.empty_like(x1)
-        if ctx.nt:  # y2 holds z2 = x1 + drop(h W2^T + b2): the LayerNorm backward's "z mode"
-            d_y2, dp2 = _ln_bwd(y2, None, None, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False, tg2)
+        if tail and ctx.nt and _FUSED_TAIL:
+            # out = alpha*x + beta_c*LN_t(x2), x2 = LN2(z2): both LayerNorm backwards in one kernel, the gradient of x2
+            # stays in registers (6 row streams instead of 8)
+            d_x = torch.empty_like(x2) if alpha != 0.0 else None
+            d_y2 = torch.empty_like(y2)
+            tgt = ops.ln_grad_targets(*ctx.ln_params[2])
+            acc = dparams = None
+            if tgt is not None and tg2 is not None:
+                acc = (ctypes.c_void_p * 5)(tgt[0], tgt[1], tg2[0], tg2[1], tg2[2])
+            else:
+                dparams = torch.empty(5, C, dtype=torch.float32, device=g.device)
+            partials = torch.empty(2048 * 5 * C, dtype=torch.float32, device=g.device)
+            L.call("tg_ln_tail_ln_bwd", L.ptr(x2), L.ptr(y2), L.ptr(gt), L.ptr(st3), L.ptr(g2), L.ptr(st2), L.ptr(g),
+                   L.ptr(d_x), L.ptr(d_x1), L.ptr(d_y2), L.ptr(dparams), L.ptr(partials), T, C, alpha, beta_c, p, seed,
+                   rs[3], acc, L.dt(x2), L.stream())
+            if dparams is not None:
+                dgt, dbt = dparams[0], dparams[1]
+                dp2 = (dparams[2], dparams[3], dparams[4])
+            else:
+                dp2 = (None, None, None)
+            d_x2 = None
         else:
-            d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False, tg2)
+            if tail:                                         # out = alpha*x + beta_c*LN_t(x2)
+                d_x2 = torch.empty_like(x2)
+                d_x = torch.empty_like(x2) if alpha != 0.0 else None
+                _, dp = _ln_bwd(x2, None, None, gt, st3, g, d_x2, False, d_x, alpha, beta_c, 0.0, 0, 0, False,
+                                ops.ln_grad_targets(*ctx.ln_params[2]))
+                dgt, dbt = dp[0], dp[1]
+            else:
+                d_x2 = g
+            # x2 = LN2(x1 + drop(y2 + b2))
+            if ctx.nt:  # y2 holds z2 = x1 + drop(h W2^T + b2): the LayerNorm backward's "z mode"
+                d_y2, dp2 = _ln_bwd(y2, None, None, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False, tg2)
+            else:
+                d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False, tg2)
         del d_x2
         dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
         nt = ctx.nt

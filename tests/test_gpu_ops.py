@@ -378,3 +378,53 @@ def test_pna_aggregate_hub_destinations(T, F, hubdeg):
     h1 = hb.clone().requires_grad_(True); a1 = T.ops.pna_aggregate(h1, g); a1.backward(gob)
     h2 = hb[perm].contiguous().requires_grad_(True); a2 = T.ops.pna_aggregate(h2, g, sorted_rows=True); a2.backward(gob)
     assert torch.equal(a1, a2) and torch.equal(h1.grad[perm], h2.grad)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("alpha,p", [(1.0, 0.3), (0.0, 0.0)])
+def test_tail_and_norm2_backward_in_one_kernel(dtype, alpha, p):
+    """tg_ln_tail_ln_bwd against the two tg_ln_bwd launches it replaces (tail LayerNorm, then norm2 in z mode):
+    dres, d_x1, d_y2 and the five parameter-gradient sums, written and accumulated."""
+    import ctypes
+    from tabgnn_amd import _lib as L
+    M, C = 4099, 128
+    g = torch.Generator().manual_seed(17)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    x2, z2, dout = r(M, C).to(dtype), r(M, C).to(dtype), r(M, C).to(dtype)
+    gt, g2 = 1 + 0.1 * r(C), 1 + 0.1 * r(C)
+    st = lambda x: torch.stack([x.float().mean(1), (x.float().var(1, unbiased=False) + 1e-5).rsqrt()], 1).contiguous()
+    st3, st2 = st(x2), st(z2)
+    beta_c, seed, rs = 0.5, 1234, 7
+    e = lambda: torch.empty(M, C, dtype=dtype, device=DEV)
+    part = lambda n: torch.empty(2048 * n * C, dtype=torch.float32, device=DEV)
+    # reference: two launches
+    d_x2, dres_r, d_x1_r = e(), e(), e()
+    dp_t, dp_2 = torch.empty(3, C, device=DEV), torch.empty(3, C, device=DEV)
+    L.call("tg_ln_bwd", L.ptr(x2), None, None, L.ptr(gt), L.ptr(st3), L.ptr(dout), L.ptr(d_x2), None,
+           L.ptr(dres_r) if alpha else None, L.ptr(dp_t), L.ptr(part(3)), M, C, alpha, beta_c, 0.0, 0, 0, 0, None, None,
+           None, L.dt(x2), L.stream())
+    d_y2_r = e()
+    L.call("tg_ln_bwd", L.ptr(z2), None, None, L.ptr(g2), L.ptr(st2), L.ptr(d_x2), L.ptr(d_x1_r), L.ptr(d_y2_r), None,
+           L.ptr(dp_2), L.ptr(part(3)), M, C, 0.0, 1.0, p, seed, rs, 0, None, None, None, L.dt(x2), L.stream())
+    # fused, written
+    dres, d_x1, d_y2, dp = e(), e(), e(), torch.empty(5, C, device=DEV)
+    L.call("tg_ln_tail_ln_bwd", L.ptr(x2), L.ptr(z2), L.ptr(gt), L.ptr(st3), L.ptr(g2), L.ptr(st2), L.ptr(dout),
+           L.ptr(dres) if alpha else None, L.ptr(d_x1), L.ptr(d_y2), L.ptr(dp), L.ptr(part(5)), M, C, alpha, beta_c, p,
+           seed, rs, None, L.dt(x2), L.stream())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2        # bf16: the unfused path rounds d_x2 to bf16 in between
+    rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+    if alpha:
+        assert torch.equal(dres, dres_r)
+    assert rel(d_x1, d_x1_r) < tol and rel(d_y2, d_y2_r) < tol
+    assert (d_y2 == 0).float().mean().item() == pytest.approx((d_y2_r == 0).float().mean().item(), abs=1e-3)
+    for got, want in ((dp[0], dp_t[0]), (dp[1], dp_t[1]), (dp[2], dp_2[0]), (dp[3], dp_2[1]), (dp[4], dp_2[2])):
+        assert rel(got, want) < max(tol, 1e-4)
+    # fused, accumulated into existing buffers (one target skipped)
+    acc_t = [torch.full((C,), 2.0, device=DEV) for _ in range(5)]
+    ptrs = (ctypes.c_void_p * 5)(acc_t[0].data_ptr(), acc_t[1].data_ptr(), acc_t[2].data_ptr(), None, acc_t[4].data_ptr())
+    L.call("tg_ln_tail_ln_bwd", L.ptr(x2), L.ptr(z2), L.ptr(gt), L.ptr(st3), L.ptr(g2), L.ptr(st2), L.ptr(dout),
+           L.ptr(dres) if alpha else None, L.ptr(d_x1), L.ptr(d_y2), None, L.ptr(part(5)), M, C, alpha, beta_c, p, seed,
+           rs, ptrs, L.dt(x2), L.stream())
+    for i in (0, 1, 2, 4):
+        torch.testing.assert_close(acc_t[i], dp[i] + 2.0, rtol=1e-5, atol=1e-4)
+    assert torch.all(acc_t[3] == 2.0)
