@@ -43,8 +43,13 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--distinct-batches", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch-size", type=int, default=256)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-batch-size", type=int, default=200, help="reference default --batch_size (utils.py:40-44)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="timed oracle steps per thread count (median reported)")
+    ap.add_argument("--no-extras", action="store_true", help="skip every extra object (reference_batch, eval, "
+                    "other_workloads, roofline_gemm, cpu_baseline, end_to_end): the bare contract line, for profiling")
+    ap.add_argument("--workload", default="aml-fused", choices=["aml-fused", "tabgnn-arxiv", "wide64-c256"],
+                    help="aml-fused = the headline (BASELINE configs[1]); the other two run ONE extra leg alone "
+                         "(configs[3] / configs[4] shapes) and print its object — for profiling, never the headline")
     ap.add_argument("--reverse-mp", action="store_true", help="PNAConvHetero (forward + reverse message passing); "
                     "not the BASELINE configuration")
     ap.add_argument("--no-e2e", action="store_true", help="skip the sampling-inclusive loop reported beside `value`")
@@ -142,50 +147,331 @@ def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
 
     for w in range(n_workers):
         threading.Thread(target=work, args=(w,), daemon=True).start()
-    edges = 0
+    edges = n_nodes = 0
     for i in range(total):
         eid, lei, nodes = slots[i].get()
         ahead.release()
         if i == warm:
-            torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0
+            torch.cuda.synchronize(); t0 = time.perf_counter(); edges = n_nodes = 0
         eid_d, nodes_d = eid.to(dev, non_blocking=True), nodes.to(dev, non_blocking=True)
         edge_tf = T.frame.TensorFrame({k: v.index_select(0, eid_d) for k, v in store.edge_feats.items()}, store.edge_cols)
         node_tf = T.frame.TensorFrame({k: v.index_select(0, nodes_d) for k, v in store.node_feats.items()}, store.node_cols)
         y = store.labels.index_select(0, eid_d[:batch_size])
         T.train_step(model, flat, opt, (node_tf, lei.to(dev, non_blocking=True), edge_tf, y), loss_w)
         edges += eid.numel()
+        n_nodes += nodes.numel()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return dict(value=edges / dt, unit="edges/s", ms_per_step=1e3 * dt / steps, steps=steps,
-                edges_per_step=edges / steps, sampler_ms_per_batch=1e3 * float(np.mean(t_sample[warm:])),
+                edges_per_step=edges / steps, nodes_per_step=n_nodes / steps, sampler_ms_per_batch=1e3 * float(np.mean(t_sample[warm:])),
                 sampler=f"libtabgnn_sampler.so k-hop [100,100], {n_workers} host threads (one handle each), prefetch <= "
                         f"{2 * n_workers} batches",
                 graph="synthetic HI-Small-shaped: 515080 nodes, 5078345 edges, raw columns resident in HBM")
 
 
 def cpu_baseline(model_sd, nhead, bs, steps, lr, loss_w):
-    """Oracle (CPU restatement) train step timed on the host cores: bounded sample of the same workload."""
+    """Oracle (CPU restatement) train step timed on the host cores, model-only (batches pre-built), at the reference's
+    default batch (B=200): ``steps`` timed steps after 2 warm-ups, MEDIAN step time, once on all granted cores and once
+    on 4 threads (``benchmark.py:50``).  A bounded sample (~10-30 s), a reported baseline, not the target."""
     from oracle import step as ostep
     from tabgnn_amd import synthetic as S
-    sd = {k: v.detach().float().cpu().clone() for k, v in model_sd.items()}
     cores = host_cores()
-    torch.set_num_threads(cores)
-    opt_state = {}
-    times, edges = [], 0
-    for i in range(steps + 1):
+    batches = []
+    for i in range(4):
         node_tf, ei, edge_tf, y = S.make_batch(bs, seed=900 + i)
-        nf = {k.value: v for k, v in node_tf.feat_dict.items()}
-        ef = {k.value: v for k, v in edge_tf.feat_dict.items()}
+        batches.append(({k.value: v for k, v in node_tf.feat_dict.items()}, ei,
+                        {k.value: v for k, v in edge_tf.feat_dict.items()}, y))
+    E = sum(b[1].shape[1] for b in batches) / len(batches)
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        sd = {k: v.detach().float().cpu().clone() for k, v in model_sd.items()}
+        opt_state, times = {}, []
+        for i in range(steps + 2):
+            nf, ei, ef, y = batches[i % len(batches)]
+            t0 = time.perf_counter()
+            ostep.train_step(sd, opt_state, nhead, bs, nf, ei, ef, y, torch.tensor(loss_w), lr, p_backbone=0.5, p_head=0.083)
+            if i >= 2:
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        med = times[len(times) // 2]
+        return dict(value=E / med, ms_per_step_median=1e3 * med, ms_per_step_min=1e3 * times[0], threads=threads)
+
+    full = run(cores)
+    four = run(min(4, cores))
+    torch.set_num_threads(cores)
+    return dict(value=full["value"], unit="edges/s", cores=cores, kind="port", ms_per_step_median=full["ms_per_step_median"],
+                threads4=four,
+                sample=f"oracle/step.py train step (fp32, dropout on, model-only: batches pre-built), B={bs} seed edges "
+                       f"(E~{int(E)} sampled edges/step, the reference's default batch), median of {steps} steps after "
+                       f"2 warm-ups; `value` on {cores} threads, `threads4` on 4 (benchmark.py:50)")
+
+
+def count_launches(fn):
+    """Device kernels launched by ``fn()`` (one step), counted by torch's profiler; None if the profiler is unavailable
+    (e.g. under rocprofv3)."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        n = 0
+        for ev in prof.events():
+            if getattr(ev, "device_type", None) is not None and "cuda" in str(ev.device_type).lower():
+                n += 1
+        return n or None
+    except Exception:
+        return None
+
+
+def reference_batch(args, cdt, dev):
+    """The reference's default batch (``utils.py:40-44``: --batch_size 200 -> E = 10 702 sampled edges): step time,
+    edges/s and device launches per step of the same train step.  Outside the timed region of `value`."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    B = 200
+    torch.manual_seed(1234)
+    cfg = S.make_config(args.hidden, args.layers, args.nhead, B, compute_dtype=cdt)
+    model = T.TABGNNFusedS(cfg).to(dev).train()
+    flat = T.FlatParams(model, shadow_dtype=cdt)
+    opt = T.FusedAdam(flat, lr=cfg["lr"])
+    lw = torch.tensor(cfg["loss_weights"], device=dev)
+    batches = [S.make_batch(B, seed=77 + i, device=dev) for i in range(4)]
+    step = T.GraphedTrainStep(model, flat, opt, lw) if getattr(T, "GraphedTrainStep", None) and os.environ.get("TABGNN_GRAPH") == "1" else None
+
+    def one(i):
+        if step is not None:
+            step(batches[i % 4])
+        else:
+            T.train_step(model, flat, opt, batches[i % 4], lw)
+    for i in range(10):
+        one(i)
+    torch.cuda.synchronize()
+    n = 50
+    t0 = time.perf_counter()
+    for i in range(n):
+        one(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    E = sum(b[1].shape[1] for b in batches) / 4
+    launches = count_launches(lambda: one(0))
+    return dict(batch_size=B, edges_per_step=int(E), ms_per_step=1e3 * dt, value=E / dt, unit="edges/s",
+                launches_per_step=launches, steps=n, mode="hip-graph replay" if step is not None else "eager",
+                note="reference default --batch_size 200 (utils.py:40-44); launch-bound regime")
+
+
+def eval_throughput(model, batches, dev, steps=10):
+    """Inference (main.py:104-155: eval mode under no_grad) on the bench batches: edges/s of the forward alone."""
+    model.eval()
+    with torch.no_grad():
+        for i in range(3):
+            model(*batches[i % len(batches)][:3])
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ostep.train_step(sd, opt_state, nhead, bs, nf, ei, ef, y, torch.tensor(loss_w), lr, p_backbone=0.5,
-                         p_head=0.083)
-        dt = time.perf_counter() - t0
-        if i > 0:                      # first step = warm-up
-            times.append(dt)
-            edges += ei.shape[1]
-    return dict(value=edges / sum(times), unit="edges/s", cores=cores, kind="port",
-                sample=f"{steps} oracle train steps (fp32, dropout on) at B={bs} seed edges "
-                       f"(E~{int(edges / steps)} sampled edges/step), after 1 warm-up step")
+        edges = 0
+        for i in range(steps):
+            b = batches[i % len(batches)]
+            model(*b[:3])
+            edges += b[1].shape[1]
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.train()
+    return dict(value=edges / dt, unit="edges/s", ms_per_step=1e3 * dt / steps, steps=steps,
+                what="TABGNNFusedS forward, eval mode, no_grad (main.py:104-155)")
+
+
+# ----------------------------------------------------------------------------------------------- other BASELINE shapes
+
+
+def arxiv_batch(B=200, fan=(15, 10), ncol=129, seed=0, device="cpu"):
+    """ogbn-arxiv-shaped node-seeded 2-hop sample (BASELINE configs[3]): B seed nodes, fan-out 15 then 10 in-neighbours;
+    node table = 129 numerical columns ~N(-0.1, 0.11) (data/ogbn-arxiv.ipynb cell 4), edge table = 1 relation column."""
+    import numpy as np
+    import tabgnn_amd as T
+    st = T.stype
+    rs = np.random.RandomState(seed)
+    V = 169_343
+    src, dst, frontier = [], [], rs.choice(V, B, replace=False)
+    for f in fan:
+        nb = rs.randint(0, V, size=(frontier.size, f))
+        src.append(nb.reshape(-1)); dst.append(np.repeat(frontier, f))
+        frontier = np.unique(nb)
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    nodes, inv = np.unique(np.concatenate([src, dst]), return_inverse=True)
+    ei = inv.reshape(2, -1).astype(np.int64)
+    N, E = nodes.size, ei.shape[1]
+    names_n = {st.numerical: [f"f_{i}" for i in range(ncol - 1)] + ["year"]}
+    node_tf = T.TensorFrame({st.numerical: torch.from_numpy((rs.randn(N, ncol) * 0.11 - 0.1).astype(np.float32))}, names_n)
+    edge_tf = T.TensorFrame({st.relation: torch.ones(E, 1)}, {st.relation: ["edge_attr"]})
+    y = torch.from_numpy(rs.randint(0, 40, N))
+    return node_tf.to(device), torch.from_numpy(ei).to(device), edge_tf.to(device), y.to(device)
+
+
+def leg_tabgnn_arxiv(cdt, dev, steps=5, warmup=2):
+    """BASELINE configs[3]: `tabgnn` path (src/nn/models/tabgnn.py:100-151), node classification, S = 130 column
+    attention over every sampled node row.  d = 128, 8 heads (reference default), 2 layers, B = 200 seed nodes."""
+    import tabgnn_amd as T
+    st = T.stype
+    C = 128
+    batches = [arxiv_batch(seed=s, device=dev) for s in range(2)]
+    node_tf, ei, edge_tf, y = batches[0]
+    names_n, names_e = node_tf.col_names_dict, edge_tf.col_names_dict
+    stats_n = {n: dict(mean=-0.1, std=0.11) for n in names_n[st.numerical]}
+    torch.manual_seed(7)
+    cfg = dict(model="tabgnn", task="node_classification", batch_size=200, n_hidden=C, n_gnn_layers=2, n_classes=40,
+               dropout=0.083, backbone_dropout=0.5, nhead=8, num_node_features=129, num_edge_features=1,
+               in_degrees=torch.bincount(ei[1].cpu(), minlength=node_tf.num_rows), reverse_mp=False,
+               node_encoder=T.StypeWiseFeatureEncoder(C, stats_n, names_n, cdt),
+               edge_encoder=T.StypeWiseFeatureEncoder(C, {}, names_e, cdt))
+    model = T.TABGNNS(cfg).to(dev).train()
+    flat = T.FlatParams(model, shadow_dtype=cdt)
+    opt = T.FusedAdam(flat, lr=6e-4)
+
+    def one(i):
+        node_tf, ei, edge_tf, y = batches[i % 2]
+        T.ops.DropoutRNG.new_step()
+        flat.zero_grad()
+        out = model(node_tf, ei, edge_tf)
+        T.ops.weighted_cross_entropy(out, y).backward()
+        opt.step()
+        return ei.shape[1], node_tf.num_rows
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = rows = 0
+    for i in range(steps):
+        e, n = one(i)
+        edges += e; rows += n + e
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(workload="configs[3] ogbn-arxiv-shaped, tabgnn path, node classification: 129 numerical node columns "
+                         "(S=130), 1 relation edge column (S=2), d=128, 8 heads, 2 FT + 2 PNA layers, 200 seed nodes, "
+                         "fan-out 15/10, Adam", value=edges / dt, unit="edges/s", rows_per_sec=rows / dt,
+                ms_per_step=1e3 * dt / steps, steps=steps, edges_per_step=edges // steps,
+                nodes_per_step=(rows - edges) // steps, attention_tokens_per_step=(130 * (rows - edges) + 2 * edges) // steps,
+                dtype="bf16" if cdt == torch.bfloat16 else "fp32")
+
+
+def leg_wide64(cdt, dev, steps=5, warmup=2, B=512):
+    """BASELINE configs[4] per-GPU shape: fused model on a 64-column mixed table (32 categorical with cardinalities
+    log-uniform 2..10^4, 24 numerical, 8 timestamp), d = 256, S = 65; HI-Small-shaped sampled subgraphs."""
+    import numpy as np
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    st = T.stype
+    C = 256
+    rs = np.random.RandomState(5)
+    cards = [int(c) for c in np.exp(rs.uniform(np.log(2), np.log(1e4), 32))]
+    names = {st.numerical: [f"n{i}" for i in range(24)], st.categorical: [f"c{i}" for i in range(32)],
+             st.timestamp: [f"t{i}" for i in range(8)]}
+    stats = {**{f"n{i}": dict(mean=0.0, std=1.0) for i in range(24)},
+             **{f"c{i}": dict(cardinality=cards[i]) for i in range(32)}, **{f"t{i}": dict(min_year=2015) for i in range(8)}}
+
+    def batch(seed):
+        ei, N = S.sampled_subgraph(B, seed)
+        E = ei.shape[1]
+        r = np.random.RandomState(seed + 1)
+        cat = np.stack([r.randint(0, c, E) for c in cards], 1).astype(np.int64)
+        num = r.randn(E, 24).astype(np.float32)
+        ts = np.stack([r.randint(2015, 2024, (E, 8)), r.randint(0, 12, (E, 8)), r.randint(0, 28, (E, 8)),
+                       r.randint(0, 7, (E, 8)), r.randint(0, 24, (E, 8)), r.randint(0, 60, (E, 8)),
+                       r.randint(0, 60, (E, 8))], -1).astype(np.int64)
+        etf = T.TensorFrame({st.numerical: torch.from_numpy(num), st.categorical: torch.from_numpy(cat),
+                             st.timestamp: torch.from_numpy(ts)}, names)
+        ntf = T.TensorFrame({st.relation: torch.ones(N, 1)}, S.NODE_COLS)
+        y = torch.from_numpy((r.rand(B) < 0.05).astype(np.int64))
+        return ntf.to(dev), torch.from_numpy(ei).to(dev), etf.to(dev), y.to(dev)
+    batches = [batch(s) for s in range(2)]
+    torch.manual_seed(9)
+    cfg = dict(model="tabgnnfused", task="edge_classification", batch_size=B, n_hidden=C, n_gnn_layers=2, n_classes=2,
+               dropout=0.083, backbone_dropout=0.5, nhead=8, num_node_features=1, num_edge_features=64,
+               in_degrees=S.in_degrees_like(), reverse_mp=False, load_model=None, checkpoint=False,
+               node_encoder=T.StypeWiseFeatureEncoder(C, {}, S.NODE_COLS, cdt),
+               edge_encoder=T.StypeWiseFeatureEncoder(C, stats, names, cdt))
+    model = T.TABGNNFusedS(cfg).to(dev).train()
+    flat = T.FlatParams(model, shadow_dtype=cdt)
+    opt = T.FusedAdam(flat, lr=6e-4)
+    lw = torch.tensor([1.0, 9.23], device=dev)
+    for i in range(warmup):
+        T.train_step(model, flat, opt, batches[i % 2], lw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = 0
+    for i in range(steps):
+        T.train_step(model, flat, opt, batches[i % 2], lw)
+        edges += batches[i % 2][1].shape[1]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return dict(workload=f"configs[4] per-GPU shape: fused supervised on a 64-column mixed table (32 cat up to 10^4 "
+                         f"categories, 24 num, 8 ts), d=256, S=65, 8 heads, 2 layers, B={B} seed edges, Adam",
+                value=edges / dt, unit="edges/s", ms_per_step=1e3 * dt / steps, steps=steps, edges_per_step=edges // steps,
+                attention_tokens_per_step=65 * (edges // steps), dtype="bf16" if cdt == torch.bfloat16 else "fp32")
+
+
+# ----------------------------------------------------------------------------------------------- step roofline (8d)
+
+MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense (MI355X_MICROARCH.md)
+
+
+def step_roofline(E, N, B, S, C, F, L, b, n_params, ms_per_step):
+    """edges/s roofline of the whole step = E / sum_op max(bytes_op / BW, flops_op / MFMA), every operator
+    reading its inputs and writing its outputs ONCE (forward and backward listed separately; backward of a Linear = two
+    products).  b = bytes per activation element.  Shapes: R_e = E - B neighbour rows and B seed rows of S column tokens."""
+    En, D = E - B, C + 2 * F
+    ops_ = []
+
+    def op(name, bytes_, flops=0.0):
+        t_b, t_f = bytes_ / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS * 1e12)
+        ops_.append(dict(op=name, bytes=float(bytes_), flops=float(flops), us=1e6 * max(t_b, t_f),
+                         bound="hbm" if t_b >= t_f else "mfma"))
+    ncols = S - 1
+    raw = 3 * 8 + 1 * 4 + 1 * 56
+    op("stype encoders fwd (E rows)", E * (raw + ncols * C * b))
+    op("stype encoders bwd", E * (raw + ncols * C * b))
+    for rows, tag, times in ((En, "edge rows", 1), (B, "seed rows", 1 + L)):
+        fl = rows * (12 * S * C * C + 4 * S * S * C)
+        op(f"column attention layer fwd ({tag}) x{times}", times * 2 * rows * S * C * b, times * fl)
+        op(f"column attention layer bwd ({tag}) x{times}", times * 3 * rows * S * C * b, times * 2 * fl)
+    op("edge_emb fwd (E_n + B rows)", E * (S * C + F) * b, 2 * E * S * C * F)
+    op("edge_emb bwd", E * (2 * S * C + F) * b, 4 * E * S * C * F)
+    op("node_emb fwd+bwd", 3 * N * F * b, 0)
+    for l in range(L):
+        op(f"L{l} PNA message gather-GEMM fwd", En * (3 * F + F) * b + En * 8, En * 8 * F * F)
+        op(f"L{l} PNA message bwd", En * (3 * F + F + 3 * F) * b + N * F * b, 2 * En * 8 * F * F)
+        op(f"L{l} PNA aggregation fwd", En * (F * b + 4) + N * 4 * F * b)
+        op(f"L{l} PNA aggregation bwd", N * 8 * F * b + En * (2 * F * b + 4))
+        op(f"L{l} PNA post projection fwd", N * (5 * F + F) * b, N * 28 * F * F)
+        op(f"L{l} PNA post projection bwd", N * (F + 5 * F + 5 * F) * b, 2 * N * 28 * F * F)
+        op(f"L{l} BatchNorm+ReLU+residual fwd", N * 4 * F * b)
+        op(f"L{l} BatchNorm bwd", N * 5 * F * b)
+        op(f"L{l} edge update gather-MLP fwd", En * (3 * F + F + F) * b, En * 8 * F * F)
+        op(f"L{l} edge update bwd", En * (3 * F + 2 * F + 3 * F) * b + N * F * b, 2 * En * 8 * F * F)
+        op(f"L{l} fuse MLP fwd+bwd (B rows)", 3 * 36 * D * D * 2 + 12 * B * D * b, 3 * 48 * B * D * D)
+        op(f"L{l} seed pooling fwd+bwd", 8 * B * F * b)
+    op("head + loss fwd+bwd", 6 * B * 3 * F * b, 3 * 2 * B * (3 * F * 50 + 50 * 25 + 25 * 2))
+    op("Adam (16 B read + 14 B written per parameter)", 30 * n_params)
+    t = sum(o["us"] for o in ops_) * 1e-6
+    return dict(edges_per_sec_bound=E / t, ms_per_step_bound=1e3 * t, frac=(t * 1e3) / ms_per_step,
+                peaks=dict(hbm_GBs=HBM_PEAK_GBS, mfma_bf16_TFLOPs=MFMA_PEAK_TFLOPS),
+                total_bytes=sum(o["bytes"] for o in ops_), total_flops=sum(o["flops"] for o in ops_), ops=ops_,
+                definition="E / sum_op max(bytes_op/BW, flops_op/MFMA): each operator reads its inputs and writes its "
+                           "outputs once, no traffic for intermediates inside an operator (SURVEY 8d)")
+
+
+def pmc_profile(args, E_mean):
+    """Counter-derived HBM bytes per launch from the newest committed PMC summary that matches this workload
+    (profiles/rNN_pmc_hbm_traffic.json; collected by separate rocprofv3 --pmc passes, never in this run)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            wl = pmc["workload"]
+            if (wl["batch_size"], wl["F"], wl["dtype"]) == (args.batch_size, args.hidden, args.dtype) and abs(wl["E"] - E_mean) < 1:
+                return os.path.relpath(path, ROOT), pmc
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -218,6 +504,10 @@ def main():
     _lib.call("tg_device_check")
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.workload != "aml-fused":          # one extra leg alone (profiling aid): prints that leg's object
+        leg = leg_tabgnn_arxiv if args.workload == "tabgnn-arxiv" else leg_wide64
+        print(json.dumps(leg(cdt, dev, steps=args.steps, warmup=args.warmup)))
+        return
     torch.manual_seed(1234)
     cfg = S.make_config(args.hidden, args.layers, args.nhead, args.batch_size, compute_dtype=cdt)
     cfg["reverse_mp"] = bool(args.reverse_mp)
@@ -271,22 +561,16 @@ def main():
     agg_ms = timer.mean_ms("tg_pna_aggregate_fwd")
     achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
     rows = E_mean + args.layers * args.batch_size
-    # HBM bytes per launch from the committed PMC passes (profiles/), valid only for the workload they were taken on
+    pmc_path, pmc = pmc_profile(args, E_mean)
     traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        wl = pmc["workload"]
-        if (wl["batch_size"], wl["F"], wl["dtype"]) == (args.batch_size, F, args.dtype) and abs(wl["E"] - E_mean) < 1:
-            key = [k for k in pmc["kernels"] if "k_pna_aggregate_fwd" in k][0]
-            traffic = pmc["kernels"][key]["hbm_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    copy_gbs = copy_rate_gbs(dev)
-    stream_gbs = stream_rate_gbs(dev)
+    if pmc is not None:
+        key = [k for k in pmc["kernels"] if "k_pna_aggregate_fwd" in k]
+        traffic = pmc["kernels"][key[0]]["hbm_bytes_per_launch"] if key else None
+    ms_per_step = elapsed / args.steps * 1e3
     out = {
         "metric": "edges/sec per training step, fused AML supervised (TABGNNFused fwd+CE+bwd+Adam)",
         "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"HI-Small-shaped AML sampled subgraphs, fused supervised (configs[1]): d={args.hidden}, "
                                f"{args.nhead}-head FT-Transformer + {args.layers}-layer PNA, B={args.batch_size} seed "
@@ -296,32 +580,62 @@ def main():
                    "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}"},
         "roofline": {"kernel": "k_pna_aggregate_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": achieved / copy_gbs,
-                     "measured_stream_GBs": stream_gbs, "frac_of_measured_stream": achieved / stream_gbs,
+                     "traffic_source": (f"{pmc_path}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                        "command on this workload (committed file, NOT measured in this run)")
+                     if traffic is not None else None,
                      "algorithmic_bytes_per_launch": agg_bytes, "avg_launch_ms": agg_ms,
                      "launches_timed": timer.count("tg_pna_aggregate_fwd"),
                      "bwd_avg_launch_ms": timer.mean_ms("tg_pna_aggregate_bwd")},
     }
-    # the kernels that dominate the step by TIME, measured the same way (HIP events on the launching stream,
-    # algorithmic bytes R*(K+N)*2 (+ gate / accumulate reads) and R*(M+N)*2 per launch) in a few extra steps AFTER the
-    # timed region: 75 more event pairs per step would cost the headline number ~0.5 ms
-    gemms = {}
-    if world == 1 and args.dtype == "bf16":
-        gt = ops.KernelTimer(only=("tg_gemm_nt_bf16", "tg_gemm_tn_bf16"))
+    if use_dist:
+        out["collective"] = {"backend": backend, "world": world, "all_reduce_calls": ddp.calls,
+                             "bytes_per_step": ddp.bytes / max(1, args.steps + args.warmup), "bucket_MiB": 32,
+                             "what": "flat fp32 gradient buffer, bucketed async all_reduce(SUM), 1/world folded into Adam"}
+    extras = not args.no_extras and world == 1
+    if extras:
+        out["roofline"].update(measured_copy_GBs=copy_rate_gbs(dev), measured_stream_GBs=stream_rate_gbs(dev))
+        out["roofline"]["frac_of_measured_copy"] = achieved / out["roofline"]["measured_copy_GBs"]
+        out["roofline"]["frac_of_measured_stream"] = achieved / out["roofline"]["measured_stream_GBs"]
+        n_params = sum(p.numel() for p in model.parameters())
+        out["step_roofline"] = step_roofline(E_mean, N_mean, args.batch_size, 6, args.hidden, args.hidden, args.layers,
+                                             b_act, n_params, ms_per_step)
+    # the kernels that dominate the step by TIME, measured the same way (HIP events on the launching stream, algorithmic
+    # bytes per launch) in a few extra steps AFTER the timed region: ~80 more event pairs per step inside it would cost
+    # the headline number ~0.5 ms
+    if extras and args.dtype == "bf16":
+        names = ("tg_gemm_nt_bf16", "tg_gemm_tn_bf16", "tg_encoder_fwd_bf16", "tg_encoder_bwd_ffn_bf16",
+                 "tg_encoder_bwd_attn_bf16")
+        gt = ops.KernelTimer(only=names)
         ops.KernelTimer.active = gt
         run(3, args.warmup + args.steps)
         torch.cuda.synchronize()
         ops.KernelTimer.active = None
-        for name in gt.only:
+        gemms = {}
+        for name in names:
             if gt.count(name):
                 gemms[name] = {"launches_per_step": gt.count(name) / 3, "ms_per_step": gt.total_ms(name) / 3,
-                               "achieved": gt.gbs(name), "frac": gt.gbs(name) / HBM_PEAK_GBS}
-    if gemms:
-        out["roofline_gemm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": gemms}
-    if not args.no_cpu_baseline and world == 1:
+                               "achieved": gt.gbs(name), "frac": gt.gbs(name) / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_step": gt.nbytes[name] / 3}
+        if pmc is not None:      # counter bytes / algorithmic bytes of the weight-gradient kernel (incl. its slab reduction)
+            kk = pmc["kernels"]
+            tn = [kk[k] for k in kk if "k_gemm_tn_bf16<false>" in k]
+            sl = [kk[k] for k in kk if "k_sum_slabs" in k]
+            if tn and "tg_gemm_tn_bf16" in gemms:
+                cnt = tn[0]["hbm_bytes_per_launch"] * tn[0]["launches"] + (sl[0]["hbm_bytes_per_launch"] * sl[0]["launches"] if sl else 0)
+                steps_profiled = pmc.get("steps_profiled", 6)
+                gemms["tg_gemm_tn_bf16"]["counter_over_algorithmic"] = cnt / steps_profiled / gemms["tg_gemm_tn_bf16"]["algorithmic_bytes_per_step"]
+                gemms["tg_gemm_tn_bf16"]["counter_source"] = pmc_path
+        if gemms:
+            out["roofline_gemm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": gemms}
+    if extras:
+        out["eval"] = eval_throughput(model, batches, dev)
+        out["reference_batch"] = reference_batch(args, cdt, dev)
+        if args.dtype == "bf16":
+            out["other_workloads"] = {"tabgnn-arxiv": leg_tabgnn_arxiv(cdt, dev), "wide64-c256": leg_wide64(cdt, dev)}
+    if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model.state_dict(), args.nhead, args.cpu_batch_size, args.cpu_steps,
                                            cfg["lr"], cfg["loss_weights"])
-    if not args.no_e2e and world == 1 and args.dtype == "bf16":
+    if extras and not args.no_e2e and args.dtype == "bf16":
         out["end_to_end"] = end_to_end(model, flat, opt, loss_w, args.batch_size, args.e2e_steps, dev)
     print(json.dumps(out))
     if use_dist:

@@ -16,5 +16,5 @@ from .losses import SSLoss  # noqa: E402
 from .layers import BatchNorm, ColumnTransformerLayer, GINEConv, GINEConvHetero, PNAConv, PNAConvHetero  # noqa: E402
 from .models import (CPNA, PNAS, TABGNN, GINe, FTTransformerLayer, FTTransformerPNAFusedLayer,  # noqa: E402
                      FTTransformerPNAInterleavedLayer, PNALayer, TABGNNFused, TABGNNInterleaved)
-from .train import DataParallel, FlatParams, FusedAdam, train_step  # noqa: E402
+from .train import DataParallel, FlatParams, FusedAdam, IndexGuard, train_step  # noqa: E402
 from .wrappers import GNN, TABGNNFusedS, TABGNNS, degree_histogram  # noqa: E402

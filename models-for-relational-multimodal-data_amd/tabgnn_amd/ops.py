@@ -19,6 +19,7 @@ from . import _lib as L
 class DropoutRNG:
     """Counter-based dropout: a mask is a pure function of (seed, stream id, element index), so the
     backward recomputes it.  ``seed`` advances once per training step, ``stream`` once per dropout site."""
+    BASE_SEED = 0x5EED
     seed = 0x5EED
     _stream = 0
 
@@ -31,6 +32,17 @@ class DropoutRNG:
     def new_step(cls, seed=None):
         cls.seed = (cls.seed * 6364136223846793005 + 1442695040888963407) & ((1 << 64) - 1) if seed is None else seed
         cls._stream = 0
+
+
+_index_errors = []          # device error words of the index conversions since the last take_index_errors()
+
+
+def take_index_errors():
+    """The out-of-range flags (int32 [1] device tensors, nonzero = some id was clamped) of every SubgraphIndex /
+    SeedIndex built since the last call; train.IndexGuard turns them into a RuntimeError without a per-call sync."""
+    global _index_errors
+    out, _index_errors = _index_errors, []
+    return out
 
 
 class KernelTimer:
@@ -95,6 +107,8 @@ class SubgraphIndex:
         out = torch.empty(ids.shape, dtype=torch.int32, device=ids.device)
         err = torch.zeros(1, dtype=torch.int32, device=ids.device)
         L.call("tg_ids_to_i32", L.ptr(ids), ids.numel(), num_nodes, L.ptr(out), L.ptr(err), L.stream())
+        if len(_index_errors) < 64:          # bounded: callers that never drain the list (plain inference) keep the newest few
+            _index_errors.append(err)
         return out, err
 
     @staticmethod
@@ -193,8 +207,18 @@ def wt(lp, param=None):
     makes it contiguous with a small kernel)."""
     t = getattr(param, "_lp_t", None) if param is not None else None
     if t is not None and t.dtype == lp.dtype and t.shape == (lp.shape[1], lp.shape[0]) and t.device == lp.device:
+        _fresh(param)
         return t
     return lp.t()
+
+
+def _fresh(p):
+    """Refresh the FlatParams shadows when ``p`` was written through torch since they were taken (checkpoint restore
+    on a sub-module, ``p.copy_()``, a torch optimiser): the masters' version counter moved, the shadows' stamp did not."""
+    if p._version != getattr(p, "_lp_ver", p._version):
+        flat = p._flat_ref() if getattr(p, "_flat_ref", None) is not None else None
+        if flat is not None:
+            flat.refresh_shadow()
 
 
 def gemm_nt_ln(x2, w, bias, res, gamma, beta, p=0.0, seed=0, rs=0, eps=1e-5):
@@ -312,6 +336,7 @@ def shadow(p, dtype):
         return None
     lp = getattr(p, "_lp", None)
     if lp is not None and lp.dtype == dtype:
+        _fresh(p)
         return lp
     return p.detach().to(dtype)
 

@@ -10,6 +10,9 @@
 """
 from __future__ import annotations
 
+import os
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -48,13 +51,27 @@ class FlatParams:
                     p._lp_t = self.shadow_t[off:off + p.numel()].view(p.shape[1], p.shape[0])
                     t_rows.append((off, p.shape[0], p.shape[1]))
         self.t_table = torch.tensor(t_rows, dtype=torch.int64, device=dev).reshape(-1, 3) if t_rows else None
+        ref = weakref.ref(self)
+        for p in uniq:
+            p._flat_ref = ref                 # ops.shadow()/ops.wt() refresh through it when a shadow went stale
         self.refresh_shadow()
+        # a checkpoint restore (main.py:271-274) writes the fp32 views in place: refresh the bf16 shadows right after it
+        if self.shadow is not None:
+            def _after_load(mod, incompatible, ref=ref):
+                f = ref()
+                if f is not None:
+                    f.refresh_shadow()
+            self._load_hook = module.register_load_state_dict_post_hook(_after_load)
 
     @property
     def numel(self):
         return self.flat.numel()
 
     def refresh_shadow(self):
+        """Recompute the bf16 shadows (and their transposes) from the fp32 masters and stamp every parameter with the
+        version the shadow was taken at: an in-place write through torch afterwards (``load_state_dict`` on a child
+        module, ``p.copy_()``, a torch optimiser) bumps ``p._version`` and ``ops.shadow`` / ``ops.wt`` then refresh
+        before handing the shadow out.  The Adam kernel keeps masters and shadows in step itself (``stamp()`` only)."""
         if self.shadow is None:
             return
         if self.flat.is_cuda:
@@ -62,6 +79,11 @@ class FlatParams:
         else:
             self.shadow.copy_(self.flat)
         self.refresh_transposed()
+        self.stamp()
+
+    def stamp(self):
+        for p in self.params:
+            p._lp_ver = p._version
 
     def refresh_transposed(self):
         if getattr(self, "t_table", None) is not None:
@@ -89,6 +111,7 @@ class FusedAdam:
                f.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t, grad_scale, int(zero_grad),
                L.stream())
         f.refresh_transposed()
+        # (the kernel wrote masters and shadows together through raw pointers: versions did not move)
 
 
 class DataParallel:
@@ -102,10 +125,11 @@ class DataParallel:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.bucket = int(bucket_mb * (1 << 20) // 4)
         # TABGNN_FORCE_ALLREDUCE=1 runs the collective path even with one rank (smoke test of the RCCL plumbing)
-        import os
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("TABGNN_FORCE_ALLREDUCE") == "1")
-        if dist.is_initialized():       # per-rank dropout stream (seed + rank): ranks never share a mask
-            ops.DropoutRNG.seed = (ops.DropoutRNG.seed + 0x9E3779B97F4A7C15 * dist.get_rank()) & ((1 << 64) - 1)
+        self.calls = self.bytes = 0        # collective bookkeeping (bench.py's `collective` object)
+        if dist.is_initialized():       # per-rank dropout stream (fixed base + rank): ranks never share a mask,
+            # and constructing a second DataParallel in the same process gives the same stream again
+            ops.DropoutRNG.seed = (ops.DropoutRNG.BASE_SEED + 0x9E3779B97F4A7C15 * dist.get_rank()) & ((1 << 64) - 1)
         if self.active:
             dist.broadcast(flat.flat, src=0)
             if sync_buffers:
@@ -127,12 +151,64 @@ class DataParallel:
                  for i in range(0, g.numel(), self.bucket)]
         for w in works:
             w.wait()
+        self.calls += len(works)
+        self.bytes += 4 * g.numel()
         return 1.0 / self.world
+
+    def sync_buffers(self):
+        """BatchNorm running statistics evolve on rank-local batches (torch DDP re-broadcasts buffers every forward;
+        here they stay local during training, which costs nothing per step): call this before evaluating or saving a
+        checkpoint so that every rank holds the MEAN of the ranks' running statistics (``num_batches_tracked`` and
+        other integer buffers are taken from rank 0)."""
+        if not self.active:
+            return
+        for b in self.module.buffers():
+            if b.is_floating_point():
+                dist.all_reduce(b, op=dist.ReduceOp.SUM)
+                b.div_(self.world)
+            else:
+                dist.broadcast(b, src=0)
+
+
+class IndexGuard:
+    """Out-of-range node ids in ``edge_index`` / ``target_edge_index`` are clamped by the id-conversion kernel so that
+    no kernel faults, and flagged in a device word (``SubgraphIndex.err`` / ``SeedIndex.err``).  The reference raises an
+    IndexError at ``x_gnn[src]``; here the flags of a step are summed and copied to pinned host memory WITHOUT a
+    synchronisation, and the next ``train_step`` (or ``check(wait=True)``) raises once the copy has landed."""
+    _pending = []          # (event, pinned host int32) of earlier steps
+
+    @classmethod
+    def collect(cls):
+        flags = ops.take_index_errors()
+        if not flags:
+            return
+        total = flags[0] if len(flags) == 1 else torch.stack([f.reshape(()) for f in flags]).sum().reshape(1).int()
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(total.reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cls._pending.append((ev, host))
+
+    @classmethod
+    def check(cls, wait=False):
+        keep = []
+        for ev, host in cls._pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                if int(host[0]) != 0:
+                    cls._pending = []
+                    raise RuntimeError("edge_index / target_edge_index held node ids outside [0, num_nodes) "
+                                       "(detected after the step that used them)")
+            else:
+                keep.append((ev, host))
+        cls._pending = keep
 
 
 def train_step(model, flat, opt, batch, loss_weight, ddp=None, step_seed=None):
     """One supervised step (main.py:41-75).  batch = (node_tf, edge_index, edge_tf, y)."""
     node_tf, edge_index, edge_tf, y = batch
+    IndexGuard.check()
     ops.DropoutRNG.new_step(step_seed)
     flat.zero_grad()
     logits = model(node_tf, edge_index, edge_tf)
@@ -141,4 +217,5 @@ def train_step(model, flat, opt, batch, loss_weight, ddp=None, step_seed=None):
     loss.backward()
     scale = ddp.all_reduce_grads() if ddp is not None else 1.0
     opt.step(grad_scale=scale)
+    IndexGuard.collect()
     return loss.detach(), logits.detach()

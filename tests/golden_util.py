@@ -47,3 +47,23 @@ def fused_train_loss(cfg, xg, e, lg, y):
     return torch.nn.functional.cross_entropy(lg.float(), y, weight=w) \
         + 0.01 * (e.float() * det_tensor("co.e", e.shape, seed).to(e.device)).sum() / e.shape[0] \
         + 0.01 * (xg.float() * det_tensor("co.x", xg.shape, seed).to(xg.device)).sum() / xg.shape[0]
+
+
+def tinycsv_state(cfg, z):
+    """Flat wrapper state (``node_encoder. / edge_encoder. / model. / decoder.``) and raw feature dicts of the
+    ``tinycsv_c32_h8_l1`` fixture (make_golden.tiny_csv_case): parameters regenerated from detparams, column statistics
+    from the fixture's config."""
+    seed = cfg["seed"]
+    sd = {"model." + k: v for k, v in build_state(cfg["keys"], z, seed).items()}
+    sd.update({"decoder." + k: v for k, v in build_state(cfg["head_keys"], z, seed + 1).items()})
+    for k, shape in cfg["enc_keys"].items():
+        sd[k] = det_param(k, torch.empty(shape), seed + 2).reshape(shape).clone()
+    for i in range(3):
+        sd[f"edge_encoder.encoder_dict.categorical.embs.{i}.weight"][0].zero_()            # padding row
+    sd["edge_encoder.encoder_dict.numerical.mean"] = torch.tensor([cfg["mean"]], dtype=torch.float32)
+    sd["edge_encoder.encoder_dict.numerical.std"] = torch.tensor([cfg["std"]], dtype=torch.float32) + 1e-6
+    sd["edge_encoder.encoder_dict.timestamp.min_year"] = torch.tensor([float(cfg["min_year"])])
+    ef = {"numerical": torch.from_numpy(z["num"].copy()), "categorical": torch.from_numpy(z["cat"].copy()),
+          "timestamp": torch.from_numpy(z["ts"].copy())}
+    nf = {"relation": torch.ones(cfg["N"], 1)}
+    return sd, nf, ef

@@ -30,3 +30,23 @@ def test_bench_two_ranks_one_json_line():
     # whole-job aggregate: both ranks' edges over the max-over-ranks time
     assert abs(d["value"] - 2 * d["config"]["edges_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
     assert "cpu_baseline" not in d and "end_to_end" not in d            # rank 0 at N = 1 only
+
+
+def test_bench_world1_rccl_allreduce_runs_on_hardware():
+    """The DEFAULT backend ("nccl" = RCCL) with one rank: `init_process_group`, the rank-0 broadcast and the bucketed
+    all-reduce of the flat gradient buffer all execute on the MI355X (TABGNN_FORCE_ALLREDUCE=1 switches the collective
+    path on at world size 1), and the step still trains: same JSON contract, `parallelism` dp1."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, TABGNN_FORCE_ALLREDUCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", TABGNN_LOG_COLLECTIVES="1")
+    env.pop("TABGNN_DIST_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch-size", "512", "--no-cpu-baseline", "--no-e2e", "--no-extras"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    assert d["collective"]["backend"] == "nccl" and d["collective"]["all_reduce_calls"] >= 3       # one per step
+    assert d["collective"]["bytes_per_step"] > 30e6                                               # 8.2 M fp32 parameters

@@ -97,3 +97,63 @@ def test_tabgnn_matches_reference():
     for k, p in model.named_parameters():
         ref = float(z["gradnorm." + k])
         assert abs(p.grad.double().norm().item() - ref) <= 2e-3 * max(ref, 1e-3), k
+
+
+def test_config1_tiny_csv_batch_real_column_values():
+    """BASELINE configs[0]: the sampled subgraph of ``data/Over-Sampled_Tiny_Trans-c.csv`` with its real column values
+    (tests/golden/tinycsv_c32_h8_l1.npz) through the product's wrapper — stype encoders, TABGNNFused(d=32, H=8, L=1),
+    ClassifierHead — on the GPU, against values the reference's own fused.py / decoder.py produced: logits within
+    1e-4 (north_star), loss, every parameter's gradient norm, BatchNorm statistics."""
+    import tabgnn_amd as T
+    from golden_util import tinycsv_state
+    st = T.stype
+    cfg, z = load_case("tinycsv_c32_h8_l1")
+    sd, nf, ef = tinycsv_state(cfg, z)
+    C, B = cfg["C"], cfg["B"]
+    cols = {st.numerical: ["Amount Paid"], st.categorical: cfg["cat_cols"], st.timestamp: ["Timestamp"]}
+    stats = {"Amount Paid": dict(mean=cfg["mean"], std=cfg["std"]), "Timestamp": dict(min_year=cfg["min_year"]),
+             **{n: dict(cardinality=c) for n, c in zip(cfg["cat_cols"], cfg["cards"])}}
+    ncols = {st.relation: ["node_attr"]}
+    # in_degrees whose histogram is the fixture's (train-graph in-degree histogram, main.py:283-286)
+    hist = torch.from_numpy(z["deg_hist"])
+    in_deg = torch.repeat_interleave(torch.arange(hist.numel()), hist)
+    wcfg = dict(model="tabgnnfused", task="edge_classification", batch_size=B, n_hidden=C, n_gnn_layers=cfg["L"],
+                n_classes=2, dropout=0.0, backbone_dropout=0.0, nhead=cfg["H"], num_node_features=1, num_edge_features=5,
+                in_degrees=in_deg, reverse_mp=False, load_model=None, checkpoint=False,
+                node_encoder=T.StypeWiseFeatureEncoder(C, {}, ncols), edge_encoder=T.StypeWiseFeatureEncoder(C, stats, cols))
+    model = T.TABGNNFusedS(wcfg)
+    own = model.state_dict()
+    missing = [k for k in sd if k not in own]
+    assert not missing, missing
+    for k in own:                                   # every parameter comes from the fixture; max_values is a constant
+        assert k in sd or k.endswith("max_values"), k
+    model.load_state_dict(sd, strict=False)
+    np.testing.assert_allclose(own["edge_encoder.encoder_dict.numerical.std"].numpy(),
+                               sd["edge_encoder.encoder_dict.numerical.std"].numpy(), rtol=1e-6)
+    model.to(DEV)
+    node_tf = T.TensorFrame({st.relation: nf["relation"]}, ncols).to(DEV)
+    edge_tf = T.TensorFrame({st.numerical: ef["numerical"], st.categorical: ef["categorical"],
+                             st.timestamp: ef["timestamp"]}, cols).to(DEV)
+    ei = torch.from_numpy(z["edge_index"]).to(DEV)
+    model.eval()
+    with torch.no_grad():
+        lg = model(node_tf, ei, edge_tf)
+    np.testing.assert_allclose(lg.cpu().numpy(), z["eval.logits"], rtol=1e-4, atol=1e-4)
+    model.train()
+    lg = model(node_tf, ei, edge_tf)
+    loss = T.ops.weighted_cross_entropy(lg, torch.from_numpy(z["y"]).to(DEV), torch.tensor([1.0, 9.23], device=DEV))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z["train.loss"]), rtol=2e-5)
+    np.testing.assert_allclose(lg.detach().cpu().numpy(), z["train.logits"], rtol=1e-4, atol=1e-4)
+    checked = 0
+    for k, p in model.named_parameters():
+        ref = float(z["gradnorm." + k])
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert abs(g.double().norm().item() - ref) <= 2e-3 * max(ref, 1e-3), (k, g.double().norm().item(), ref)
+        checked += 1
+        if ("grad." + k) in z.files:
+            np.testing.assert_allclose(g.cpu().numpy(), z["grad." + k], rtol=5e-3, atol=2e-6, err_msg=k)
+    assert checked >= 60
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), z["bn_after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
