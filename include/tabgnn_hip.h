@@ -18,7 +18,7 @@
 #define TABGNN_HIP_H_
 #include <stdint.h>
 
-#define TABGNN_HIP_ABI_VERSION 1
+#define TABGNN_HIP_ABI_VERSION 2
 
 #ifdef __cplusplus
 extern "C" {
@@ -215,6 +215,27 @@ int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void*
 int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bias, const void* res, const float* gamma,
                        const float* beta, void* Z, void* OUT, float* stats, int64_t R, int32_t K, int64_t ldx, float eps,
                        float p_drop, uint64_t seed, uint32_t rstream, void* stream);
+
+/* ---- the whole column-transformer layer in one kernel per direction (bf16, d_model = dim_feedforward = 128,
+ *      4 or 8 heads, S <= 32 tokens per table row): torch nn.TransformerEncoderLayer as configured at
+ *      src/nn/models/fused.py:83-92,187-196 (post-norm, ReLU, dropout p on attention probabilities / both
+ *      sub-layer outputs / the hidden activation) + the tab_norm LayerNorm and residual combine of its call sites
+ *      (fused.py:160,164,249; tabgnn.py:219):  out = alpha*x + beta_c*LN_t(enc(x))  (tail = 1)  |  out = enc(x).
+ *      tg_encoder_pack builds, once per call, the LDS weight images (wpack, tg_encoder_pack_bytes() bytes) and the
+ *      fp32 parameter block (prm, tg_encoder_prm_floats() floats) from the layer's parameters (weights bf16 [out,in]).
+ *      tg_encoder_fwd_bf16: x [R,S,128] -> out; z1 / z2 (optional) = the two pre-LayerNorm sums, all a recomputing
+ *      backward needs; qkv, scores, attention output, x1 and the hidden activation never reach memory.
+ *      rs[4]: dropout streams (attention, norm1, ffn, norm2), the same element indexing as the unfused kernels. ---- */
+int64_t tg_encoder_pack_bytes(void);
+int64_t tg_encoder_prm_floats(void);
+int32_t tg_encoder_fused_supported(int32_t S, int32_t C, int32_t H, int32_t FF);
+int tg_encoder_pack(const void* w_in, const void* w_o, const void* w1, const void* w2, const float* b_in,
+                    const float* b_o, const float* g1, const float* be1, const float* b1, const float* b2,
+                    const float* g2, const float* be2, const float* gt /*NULL: no tail*/, const float* bt, void* wpack,
+                    float* prm, void* stream);
+int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2, const void* wpack, const float* prm, int64_t R,
+                        int32_t S, int32_t H, int32_t tail, float alpha, float beta_c, float eps, float p_drop,
+                        uint64_t seed, const uint32_t* rs /*host [4]*/, void* stream);
 
 /* ---- weight gradient of every Linear on the path (autograd of torch.nn.Linear in the reference):
  *      out[M,N] (fp32) = G[R,M]^T X[R,N], bf16 operands, split over row slabs, deterministic slab sum ------- */

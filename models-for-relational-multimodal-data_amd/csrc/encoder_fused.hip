@@ -1,0 +1,582 @@
+// The column-transformer layer of the fused path as ONE kernel per direction (bf16, d_model = feed-forward = 128):
+//     torch nn.TransformerEncoderLayer(d_model=C, nhead, dim_feedforward=C, dropout, relu, batch_first), post-norm,
+//     as configured at src/nn/models/fused.py:83-92,187-196 and called at fused.py:160,164,249 / tabgnn.py:127-129,219,
+//     followed by the tab_norm LayerNorm + residual combine every call site applies:
+//         out = alpha * x + beta_c * LN_t(enc(x))                 (or out = enc(x))
+//
+// Design (MI355X, wave64, MFMA 32x32x16 bf16):
+//   * a WAVE owns 32 consecutive token slots = floor(32/S) whole table rows (S = columns + CLS: 6 for AML); nothing a
+//     wave computes depends on another wave's tokens, so the whole layer — QKV projection, S x S attention, output
+//     projection, LayerNorm, feed-forward, LayerNorm, tail LayerNorm — runs on that wave's REGISTERS:
+//       - every GEMM is out^T[n, t] = W[n, :] . act[t, :] with A := W tile (from LDS), B := activations of the wave's 32
+//         tokens; the result has the token on the LANE (column) and 64 channels of that token in the lane's registers;
+//       - an accumulator tile converted to bf16 IS the B operand of the next MFMA (k = accumulator row), so q/k/v, the
+//         softmax probabilities, the attention output, x1 and the feed-forward hidden state never leave registers; the
+//         k order inside a 16-deep MFMA step is the accumulator's row order (16s + 8(j>>2) + 4h + (j&3)), so the weight
+//         images are stored in LDS with their k axis permuted the same way (done once per call by k_encoder_pack) and
+//         x itself is loaded from HBM straight into that fragment order;
+//       - attention per head: S^T = K Q^T (keys on accumulator rows), softmax down the rows in registers (one xor-32
+//         exchange), P^T back in as the B operand of O^T = V^T P^T — the block-diagonal structure (a query only sees
+//         the keys of its own table row) is a mask on the 32 x 32 tile;
+//       - LayerNorm is a reduction over the lane's 64 registers plus one xor-32 exchange.
+//   * the only LDS traffic is weights: six 32 KiB stages per group of eight wave tiles (per 32-channel head block:
+//     Wq | Wk | Wv rows + the matching k slice of Wo; then W1; then W2), double-buffered, filled by LDS-DMA
+//     (global_load_lds 16 B) from a pre-swizzled image, one barrier per stage;
+//   * HBM: x is read once (fragment order, 8-byte pieces of whole rows), out / z1 / z2 are written once through a small
+//     wave-private LDS restage as whole 128-byte row segments.  qkv, scores, o, x1, h never exist in memory.
+// Dropout masks are the package's counter RNG on the same element indices the unfused kernels use (attention
+// probabilities: ((row*H + head)*S + q)*S + k; linear outputs: token*128 + channel), so either path can run the backward.
+#include "common.hpp"
+#include "../../include/tabgnn_hip.h"
+
+namespace tg {
+
+typedef __bf16 ef_v8bf __attribute__((ext_vector_type(8)));
+typedef float ef_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ef_f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int EF_C = 128;
+constexpr int EF_STAGE_BYTES = 32768;
+constexpr int EF_WAVES = 8;                  // waves per workgroup
+constexpr int EF_NSTAGE = 6;
+// fp32 parameter block (floats): b_in[384] | b_o | g1 | be1 | b1 | b2 | g2 | be2 | gt | bt  (128 each)
+enum { EF_P_BIN = 0, EF_P_BO = 384, EF_P_G1 = 512, EF_P_BE1 = 640, EF_P_B1 = 768, EF_P_B2 = 896, EF_P_G2 = 1024,
+       EF_P_BE2 = 1152, EF_P_GT = 1280, EF_P_BT = 1408, EF_P_FLOATS = 1536 };
+
+__device__ __forceinline__ int ef_off(int row, int ch) {      // 256-byte rows, 16-byte chunk ch (0..15)
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+__device__ __forceinline__ int ef_off_wo(int row, int ch) {   // 64-byte rows (k slice of 32 channels), chunk 0..3
+  return 64 * row + 16 * (ch ^ ((row >> 2) & 3));
+}
+
+// ---------------------------------------------------------------------------------------------- weight pack
+// wpack: [6 stages][32 KiB] bf16 LDS images, prm: EF_P_FLOATS floats.  Data chunk c = 2*ks + h of a row holds channels
+// {16ks + 4h + 0..3, 16ks + 8 + 4h + 0..3}: the accumulator row order of MFMA k-step ks, lane half h.
+// TRANSPOSED variant (backward): stage s holds W^T tiles laid out the same way (see k_encoder_pack_bwd below).
+__device__ __forceinline__ uint4 ef_perm_chunk(const unsigned short* wrow, int ks, int h) {
+  const uint2 a = *reinterpret_cast<const uint2*>(wrow + 16 * ks + 4 * h);
+  const uint2 b = *reinterpret_cast<const uint2*>(wrow + 16 * ks + 8 + 4 * h);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+__global__ void __launch_bounds__(256) k_encoder_pack(const unsigned short* __restrict__ w_in,   // [384,128]
+                                                       const unsigned short* __restrict__ w_o,    // [128,128]
+                                                       const unsigned short* __restrict__ w1,
+                                                       const unsigned short* __restrict__ w2,
+                                                       const float* __restrict__ b_in, const float* __restrict__ b_o,
+                                                       const float* __restrict__ g1, const float* __restrict__ be1,
+                                                       const float* __restrict__ b1, const float* __restrict__ b2,
+                                                       const float* __restrict__ g2, const float* __restrict__ be2,
+                                                       const float* __restrict__ gt, const float* __restrict__ bt,
+                                                       char* __restrict__ wpack, float* __restrict__ prm) {
+  const int stage = blockIdx.x;                // 0..5
+  char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
+  if (stage < 4) {
+    // rows 0..95: (Wq | Wk | Wv) rows 32*stage + r; 16 chunks each
+    for (int p = threadIdx.x; p < 96 * 16; p += blockDim.x) {
+      const int row = p >> 4, c = p & 15, part = row >> 5, r = row & 31;
+      const unsigned short* wrow = w_in + (size_t)(128 * part + 32 * stage + r) * EF_C;
+      *reinterpret_cast<uint4*>(dst + 8192 * part + ef_off(r, c)) = ef_perm_chunk(wrow, c >> 1, c & 1);
+    }
+    // Wo k slice: rows n = 0..127, channels 32*stage .. +31 -> 4 chunks (k-steps 2*stage, 2*stage+1)
+    for (int p = threadIdx.x; p < 128 * 4; p += blockDim.x) {
+      const int n = p >> 2, c = p & 3;
+      *reinterpret_cast<uint4*>(dst + 24576 + ef_off_wo(n, c)) = ef_perm_chunk(w_o + (size_t)n * EF_C, 2 * stage + (c >> 1), c & 1);
+    }
+  } else {
+    const unsigned short* w = stage == 4 ? w1 : w2;
+    for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
+      const int row = p >> 4, c = p & 15;
+      *reinterpret_cast<uint4*>(dst + ef_off(row, c)) = ef_perm_chunk(w + (size_t)row * EF_C, c >> 1, c & 1);
+    }
+  }
+  if (stage == 0) {
+    for (int i = threadIdx.x; i < EF_P_FLOATS; i += blockDim.x) {
+      float v;
+      if (i < 384) v = b_in[i];
+      else {
+        const int k = (i - 384) >> 7, j = i & 127;
+        const float* src = k == 0 ? b_o : k == 1 ? g1 : k == 2 ? be1 : k == 3 ? b1 : k == 4 ? b2 : k == 5 ? g2 : k == 6 ? be2
+                         : k == 7 ? gt : bt;
+        v = src ? src[j] : (k == 7 ? 1.f : 0.f);
+      }
+      prm[i] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- device helpers
+__device__ __forceinline__ ef_v8bf ef_frag(const char* tile, int off) {
+  return __builtin_bit_cast(ef_v8bf, *reinterpret_cast<const uint4*>(tile + off));
+}
+template <int S8> __device__ __forceinline__ ef_v8bf ef_pack(const ef_f32x16& a) {   // regs 8*S8 .. 8*S8+7 -> 8 bf16
+  ef_f32x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = a[8 * S8 + j];
+  return __builtin_convertvector(t, ef_v8bf);
+}
+__device__ __forceinline__ float ef_bf(ef_v8bf v, int j) { return (float)v[j]; }
+__device__ __forceinline__ float ef_xor32(float v) { return __shfl_xor(v, 32, 64); }
+__device__ __forceinline__ ef_f32x16 ef_zero16() {
+  ef_f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+#define EF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+
+// LDS-DMA of one 32 KiB stage by the 512 threads of the workgroup: 4 pieces of 16 bytes per thread, linear image.
+__device__ __forceinline__ void ef_stage_dma(const char* __restrict__ src, char* lds_dst, int tid) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int piece = p * 512 + (tid & ~63);          // wave-uniform first piece of this wave-instruction
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + (size_t)(piece + (tid & 63)) * 16),
+        (__attribute__((address_space(3))) void*)(lds_dst + piece * 16), 16, 0, 0);
+  }
+}
+
+// mean / rstd of a token's 128 channels held as 8 packed fragments (this lane's 64 + the xor-32 partner's 64)
+__device__ __forceinline__ void ef_row_stats(const ef_v8bf (&zp)[8], float eps, float& mu, float& rstd) {
+  float sum = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += (float)zp[f][j];
+  sum += ef_xor32(sum);
+  mu = sum * (1.f / 128.f);
+  float var = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = (float)zp[f][j] - mu; var += d * d; }
+  var += ef_xor32(var);
+  rstd = rsqrtf(var * (1.f / 128.f) + eps);
+}
+// (z - mu) * rstd * gamma + beta for one fragment; gp / bp point at the fragment's first float4 (channels 16f + 4h ..),
+// the second float4 sits 8 floats further (channels 16f + 8 + 4h ..)
+__device__ __forceinline__ ef_v8bf ef_ln_apply(ef_v8bf z, float mu, float rstd, const float* gp, const float* bp) {
+  const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 8);
+  const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 8);
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  ef_f32x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = ((float)z[j] - mu) * rstd * gg[j] + bb[j];
+  return __builtin_convertvector(t, ef_v8bf);
+}
+__device__ __forceinline__ ef_v8bf ef_ln_combine(ef_v8bf z, ef_v8bf x, float mu, float rstd, const float* gp,
+                                                 const float* bp, float alpha, float beta_c) {
+  const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 8);
+  const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 8);
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+  ef_f32x8 t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = ((float)z[j] - mu) * rstd * gg[j] + bb[j];
+    t[j] = beta_c * v + (alpha != 0.f ? alpha * (float)x[j] : 0.f);
+  }
+  return __builtin_convertvector(t, ef_v8bf);
+}
+// Rows of 128 channels held as 8 packed fragments -> memory, through the wave-private 4 KiB restage (64 channels at a
+// time): every lane then stores 16 bytes of a 128-byte row segment.  dst = first token of the wave tile.
+__device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], char* stg, unsigned short* dst, int lane, int tl, int h,
+                                              int nvalid) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ff = 0; ff < 4; ++ff) {
+      const uint4 v = __builtin_bit_cast(uint4, zp[4 * half + ff]);
+      // fragment f: channels 16f + 4h + 0..3 (.xy) and 16f + 8 + 4h + 0..3 (.zw) -> 16-byte chunks 2ff and 2ff + 1 of the half row
+      *reinterpret_cast<uint2*>(stg + 128 * tl + 16 * ((2 * ff) ^ (tl & 7)) + 8 * h) = make_uint2(v.x, v.y);
+      *reinterpret_cast<uint2*>(stg + 128 * tl + 16 * ((2 * ff + 1) ^ (tl & 7)) + 8 * h) = make_uint2(v.z, v.w);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int t = (lane >> 3) + 8 * p, c = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(stg + 128 * t + 16 * (c ^ (t & 7)));
+      if (t < nvalid) *reinterpret_cast<uint4*>(dst + (size_t)t * EF_C + 64 * half + 8 * c) = v;
+    }
+  }
+}
+
+struct EfArgs {
+  const unsigned short* x;        // [T,128]
+  unsigned short* out;            // [T,128]
+  unsigned short* z1;             // [T,128] or null
+  unsigned short* z2;             // [T,128] or null
+  const char* wpack;
+  const float* prm;
+  long long R;                    // table rows
+  int S;                          // tokens per row
+  int tail;                       // 1: out = alpha*x + beta_c*LN_t(x2)
+  float alpha, beta_c, eps;
+  unsigned thresh;                // dropout threshold (0 = off)
+  float inv_keep;
+  unsigned long long seed;
+  unsigned rs0, rs1, rs2, rs3;    // attention, norm1, ffn, norm2 dropout streams
+};
+
+// Forward.  HD = head dim (16 or 32).  One workgroup = 8 waves = 8 wave tiles of 32 token slots per iteration.
+template <int HD, bool DROP>
+__global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wbuf0 = smem;
+  char* wbuf1 = smem + EF_STAGE_BYTES;
+  float* prm = reinterpret_cast<float*>(smem + 2 * EF_STAGE_BYTES);                  // 6 KiB
+  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;                       // 8 x 4 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl0 = lane & 31, h0 = lane >> 5;
+  char* stg = stg_all + wave * 4096;
+  constexpr int NH = EF_C / HD;                 // heads
+  constexpr int HB = 32 / HD;                   // heads per 32-channel block
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.25f;
+  const int S = a.S;
+  const int RW = 32 / S;                        // table rows per wave tile
+  const long long n_wt = (a.R + RW - 1) / RW;   // wave tiles
+  const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
+
+  for (int i = tid; i < EF_P_FLOATS; i += 512) prm[i] = a.prm[i];
+  // stage pipeline: global stage counter g = it_local * 6 + s; buffer = g & 1
+  if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
+  __syncthreads();
+
+  // softmax geometry of this lane: query slot tl, its table row's token range [row_lo, row_lo + S)
+  const int q_row = tl0 / S;
+  const int row_lo = q_row * S;
+
+  for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
+    int tl = tl0, h = h0;
+    asm volatile("" : "+v"(tl), "+v"(h));     // opaque per iteration: see EF_OPAQUE below
+    const long long wt = it * EF_WAVES + wave;
+    const long long row0 = wt * RW;
+    long long rows_here = a.R - row0;
+    rows_here = rows_here < 0 ? 0 : (rows_here > RW ? RW : rows_here);
+    const int nvalid = (int)rows_here * S;                       // valid token slots of this wave tile
+    const long long tok0 = row0 * S;                             // first token of the wave tile
+    const bool tok_ok = tl < nvalid;
+    const long long tglob = tok0 + tl;
+
+    // ---- x in fragment order: xf[ks] element j = x[t][16ks + 8(j>>2) + 4h + (j&3)]
+    ef_v8bf xf[8];
+    const unsigned short* xp = a.x + (tok_ok ? tglob : 0) * EF_C + 4 * h;
+#define EF_LOAD_X()                                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
+      uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);                                         \
+      if (tok_ok) {                                                                                   \
+        lo = *reinterpret_cast<const uint2*>(xp + 16 * ks);                                           \
+        hi = *reinterpret_cast<const uint2*>(xp + 16 * ks + 8);                                       \
+      }                                                                                               \
+      xf[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                      \
+    }
+    EF_LOAD_X()
+
+    ef_f32x16 accy[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) accy[m] = ef_zero16();
+
+    // ================================================================ attention + output projection, per head block
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk) {
+      asm volatile("" : "+v"(tl), "+v"(h));
+      char* wb = (blk & 1) ? wbuf1 : wbuf0;
+      char* wn = (blk & 1) ? wbuf0 : wbuf1;
+      // next stage (blk+1: head block, or W1) -> other buffer
+      ef_stage_dma(a.wpack + (size_t)(blk + 1) * EF_STAGE_BYTES, wn, tid);
+
+      // K^T and Q^T blocks [32 d, 32 tokens]
+      ef_f32x16 acc = ef_zero16();
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wb + 8192, ef_off(tl, 2 * ks + h)), xf[ks], acc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BIN + 128 + 32 * blk + 8 * g + 4 * h);
+        acc[4 * g] += b.x; acc[4 * g + 1] += b.y; acc[4 * g + 2] += b.z; acc[4 * g + 3] += b.w;
+      }
+      const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = ef_zero16();
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wb, ef_off(tl, 2 * ks + h)), xf[ks], acc);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BIN + 32 * blk + 8 * g + 4 * h);
+        acc[4 * g] += b.x; acc[4 * g + 1] += b.y; acc[4 * g + 2] += b.z; acc[4 * g + 3] += b.w;
+      }
+      const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+      // V block in the transposed orientation [32 tokens (rows), 32 d (columns)]
+      acc = ef_zero16();
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(xf[ks], ef_frag(wb + 16384, ef_off(tl, 2 * ks + h)), acc);
+      {
+        const float bv = prm[EF_P_BIN + 256 + 32 * blk + tl];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += bv;
+      }
+      const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+
+      ef_v8bf of0, of1;
+#pragma unroll
+      for (int hh = 0; hh < HB; ++hh) {
+        // scores S^T[key (rows), query (columns)]
+        ef_f32x16 st = ef_zero16();
+        if constexpr (HB == 1) {
+          st = EF_MFMA(kf0, qf0, st);
+          st = EF_MFMA(kf1, qf1, st);
+        } else {
+          st = hh == 0 ? EF_MFMA(kf0, qf0, st) : EF_MFMA(kf1, qf1, st);
+        }
+        // softmax over the keys of the query's own table row
+        float mx = -INFINITY;
+        bool ok[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+          ok[i] = key >= row_lo && key < row_lo + S;
+          st[i] *= scale;
+          mx = ok[i] ? fmaxf(mx, st[i]) : mx;
+        }
+        mx = fmaxf(mx, ef_xor32(mx));
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          st[i] = ok[i] ? __expf(st[i] - mx) : 0.f;
+          l += st[i];
+        }
+        l += ef_xor32(l);
+        const float inv = 1.f / l;
+        if constexpr (DROP) {
+          const int head = blk * HB + hh;
+          const unsigned long long blk0 = ((unsigned long long)(row0 + q_row) * NH + head) * (unsigned long long)(S * S);
+          const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
+          const unsigned key0 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32));
+          const unsigned key1 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32) + 1u);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const unsigned lo = lo0 + (unsigned)(key - row_lo);
+            const unsigned kk = lo < (unsigned)blk0 ? key1 : key0;       // carry into the high word
+            st[i] *= inv * drop_scale_key(kk, lo, a.thresh, a.inv_keep);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) st[i] *= inv;
+        }
+        const ef_v8bf pf0 = ef_pack<0>(st), pf1 = ef_pack<1>(st);
+        // O^T[d (rows), query (columns)] = V^T P^T
+        ef_f32x16 ot = ef_zero16();
+        ot = EF_MFMA(vf0, pf0, ot);
+        ot = EF_MFMA(vf1, pf1, ot);
+        if constexpr (HB == 1) {
+          of0 = ef_pack<0>(ot); of1 = ef_pack<1>(ot);
+        } else {
+          if (hh == 0) of0 = ef_pack<0>(ot); else of1 = ef_pack<1>(ot);
+        }
+      }
+      // output projection: y^T[n, t] += Wo[n, 32 blk + ...] o^T
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        accy[m] = EF_MFMA(ef_frag(wb + 24576, ef_off_wo(32 * m + tl, h)), of0, accy[m]);
+        accy[m] = EF_MFMA(ef_frag(wb + 24576, ef_off_wo(32 * m + tl, 2 + h)), of1, accy[m]);
+      }
+      __syncthreads();          // stage blk consumed by every wave; the DMA of stage blk+1 has landed (vmcnt(0) + barrier)
+    }
+
+    // ================================================================ LayerNorm 1 (registers)
+    // z1 = x + drop(y + b_o), rounded to bf16 (what is stored and what the backward recomputes from);
+    // x1 = LN(z1) * g1 + be1, rounded to bf16: the feed-forward input and residual
+    asm volatile("" : "+v"(tl), "+v"(h));
+    const unsigned long long e_base = (unsigned long long)tglob * EF_C;
+    ef_v8bf x1f[8];
+    {
+      ef_v8bf zp[8];
+      const unsigned dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BO + 32 * m + 8 * g + 4 * h);
+          const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * g + j;
+            float u = accy[m][i] + bb[j];
+            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            accy[m][i] = u + ef_bf(xf[2 * m + (i >> 3)], i & 7);
+          }
+        }
+        zp[2 * m] = ef_pack<0>(accy[m]);
+        zp[2 * m + 1] = ef_pack<1>(accy[m]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (a.z1) ef_store_rows(zp, stg, a.z1 + tok0 * EF_C, lane, tl, h, nvalid);
+      float mu, rstd;
+      ef_row_stats(zp, a.eps, mu, rstd);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        x1f[f] = ef_ln_apply(zp[f], mu, rstd, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
+      }
+    }
+
+    // ================================================================ feed-forward 1: h = drop(relu(W1 x1 + b1))
+    ef_v8bf hf[8];
+    {
+      asm volatile("" : "+v"(tl), "+v"(h));
+      // stage 5 (W2) -> wbuf1 while W1 (wbuf0) is used
+      ef_stage_dma(a.wpack + (size_t)5 * EF_STAGE_BYTES, wbuf1, tid);
+      const unsigned dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        ef_f32x16 acc = ef_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wbuf0, ef_off(32 * m + tl, 2 * ks + h)), x1f[ks], acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
+          const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
+            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            acc[4 * g + j] = u;
+          }
+        }
+        hf[2 * m] = ef_pack<0>(acc);
+        hf[2 * m + 1] = ef_pack<1>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();          // W1 consumed; W2 landed
+    }
+
+    // ================================================================ feed-forward 2 + LayerNorm 2 (+ tail LayerNorm)
+    {
+      // stage 0 of the next iteration -> wbuf0 while W2 (wbuf1) is used
+      asm volatile("" : "+v"(tl), "+v"(h));
+      if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
+      ef_v8bf zp[8];
+      const unsigned dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        ef_f32x16 acc = ef_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wbuf1, ef_off(32 * m + tl, 2 * ks + h)), hf[ks], acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B2 + 32 * m + 8 * g + 4 * h);
+          const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * g + j;
+            float u = acc[i] + bb[j];
+            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            acc[i] = u + ef_bf(x1f[2 * m + (i >> 3)], i & 7);
+          }
+        }
+        zp[2 * m] = ef_pack<0>(acc);
+        zp[2 * m + 1] = ef_pack<1>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (a.z2) ef_store_rows(zp, stg, a.z2 + tok0 * EF_C, lane, tl, h, nvalid);
+      float mu, rstd;
+      ef_row_stats(zp, a.eps, mu, rstd);
+      // x2 = LN2(z2), rounded to bf16 as the unfused path stores it
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        zp[f] = ef_ln_apply(zp[f], mu, rstd, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
+      }
+      if (a.tail) {
+        ef_row_stats(zp, a.eps, mu, rstd);
+        if (a.alpha != 0.f) { EF_LOAD_X() }       // x again for the combine (L2-hot): its registers were free in between
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          __builtin_amdgcn_sched_barrier(0);
+          zp[f] = ef_ln_combine(zp[f], xf[f], mu, rstd, prm + EF_P_GT + 16 * f + 4 * h, prm + EF_P_BT + 16 * f + 4 * h,
+                                a.alpha, a.beta_c);
+        }
+      }
+      ef_store_rows(zp, stg, a.out + tok0 * EF_C, lane, tl, h, nvalid);
+      __syncthreads();          // W2 consumed; next iteration's stage 0 landed
+    }
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+extern "C" int64_t tg_encoder_pack_bytes(void) { return (int64_t)EF_NSTAGE * EF_STAGE_BYTES; }
+extern "C" int64_t tg_encoder_prm_floats(void) { return EF_P_FLOATS; }
+
+// Builds the LDS weight images + the fp32 parameter block of one ColumnTransformerLayer call (bf16 weights [out,in]
+// row-major; biases / LayerNorm parameters fp32; gt/bt may be NULL when there is no tail norm).
+extern "C" int tg_encoder_pack(const void* w_in, const void* w_o, const void* w1, const void* w2, const float* b_in,
+                               const float* b_o, const float* g1, const float* be1, const float* b1, const float* b2,
+                               const float* g2, const float* be2, const float* gt, const float* bt, void* wpack,
+                               float* prm, void* stream) {
+  TG_CHECK(w_in && w_o && w1 && w2 && b_in && b_o && g1 && be1 && b1 && b2 && g2 && be2 && wpack && prm,
+           "tg_encoder_pack: null operand");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(w_in) | reinterpret_cast<uintptr_t>(w_o) | reinterpret_cast<uintptr_t>(w1) |
+             reinterpret_cast<uintptr_t>(w2) | reinterpret_cast<uintptr_t>(wpack)) & 15) == 0,
+           "tg_encoder_pack: operands must be 16-byte aligned");
+  hipLaunchKernelGGL(k_encoder_pack, dim3(EF_NSTAGE), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)w_in,
+                     (const unsigned short*)w_o, (const unsigned short*)w1, (const unsigned short*)w2, b_in, b_o, g1, be1,
+                     b1, b2, g2, be2, gt, bt, (char*)wpack, prm);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int32_t tg_encoder_fused_supported(int32_t S, int32_t C, int32_t H, int32_t FF) {
+  return C == 128 && FF == 128 && (H == 4 || H == 8) && S >= 1 && S <= 32;
+}
+
+// out [R,S,128] = encoder layer (+ tail) of x [R,S,128], bf16; z1 / z2 (pre-LayerNorm sums, what a recomputing backward
+// needs) optional.  rs[4] = dropout streams (attention, norm1, ffn, norm2).
+extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2, const void* wpack, const float* prm,
+                                   int64_t R, int32_t S, int32_t H, int32_t tail, float alpha, float beta_c, float eps,
+                                   float p_drop, uint64_t seed, const uint32_t* rs, void* stream) {
+  TG_CHECK(tg_encoder_fused_supported(S, 128, H, 128), "tg_encoder_fwd_bf16: unsupported geometry S=%d H=%d", S, H);
+  TG_CHECK(x && out && wpack && prm && rs, "tg_encoder_fwd_bf16: null operand");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(z1) |
+             reinterpret_cast<uintptr_t>(z2) | reinterpret_cast<uintptr_t>(wpack)) & 15) == 0,
+           "tg_encoder_fwd_bf16: operands must be 16-byte aligned");
+  if (R <= 0) return 0;
+  EfArgs a;
+  a.x = (const unsigned short*)x; a.out = (unsigned short*)out; a.z1 = (unsigned short*)z1; a.z2 = (unsigned short*)z2;
+  a.wpack = (const char*)wpack; a.prm = prm; a.R = R; a.S = S; a.tail = tail; a.alpha = alpha; a.beta_c = beta_c; a.eps = eps;
+  a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1]; a.rs2 = rs[2]; a.rs3 = rs[3];
+  const int RW = 32 / S;
+  const long long n_wt = (R + RW - 1) / RW, n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  const unsigned grid = (unsigned)(n_it < n_cu ? n_it : n_cu);
+  const size_t lds = 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 4096;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const bool drop = a.thresh != 0u;
+  if (H == 4 && drop) hipLaunchKernelGGL((k_encoder_fwd<32, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  else if (H == 4) hipLaunchKernelGGL((k_encoder_fwd<32, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  else if (drop) hipLaunchKernelGGL((k_encoder_fwd<16, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_encoder_fwd<16, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  TG_LAUNCH_CHECK();
+  return 0;
+}

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtabgnn_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i32, _i64, _f32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
 
@@ -69,6 +69,11 @@ SIGNATURES = {
     "tg_gemm_nt_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _f32, _u64, _u32, _vp],
     "tg_gemm_nt_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _u64, _u32, _vp],
     "tg_gemm_tn_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
+    "tg_encoder_pack_bytes": [],
+    "tg_encoder_prm_floats": [],
+    "tg_encoder_fused_supported": [_i32, _i32, _i32, _i32],
+    "tg_encoder_pack": [_vp] * 17,
+    "tg_encoder_fwd_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _u64, _vp, _vp],
     "tg_weighted_ce_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "tg_weighted_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "tg_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],
@@ -76,7 +81,7 @@ SIGNATURES = {
     "tg_transpose_batched_bf16": [_vp, _vp, _vp, _i32, _vp],
 }
 _RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,
-             "tg_gemm_tn_workspace_floats": _i64}
+             "tg_gemm_tn_workspace_floats": _i64, "tg_encoder_pack_bytes": _i64, "tg_encoder_prm_floats": _i64}
 
 
 class EncCol(C.Structure):

@@ -22,6 +22,39 @@ from . import _lib as L
 from . import ops
 
 _FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B switch
+_FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B switch: the one-kernel layer (encoder_fused.hip)
+
+
+def fused_ok(x, nhead, w1):
+    """Shapes the one-kernel layer takes: bf16 rows of S <= 32 column tokens, d_model = feed-forward = 128, 4 or 8 heads."""
+    return (_FUSED_LAYER and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.shape[0] > 0
+            and bool(L.load().tg_encoder_fused_supported(x.shape[1], x.shape[2], nhead, w1.shape[0])))
+
+
+def pack_layer(lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, b1, b2, g2, be2, gt, bt):
+    """LDS weight images + fp32 parameter block of one call (tg_encoder_pack): bf16 weights, fp32 vectors."""
+    lib = L.load()
+    dev = lw_in.device
+    wpack = torch.empty(lib.tg_encoder_pack_bytes(), dtype=torch.uint8, device=dev)
+    prm = torch.empty(lib.tg_encoder_prm_floats(), dtype=torch.float32, device=dev)
+    f = lambda t: None if t is None else L.ptr(t.detach().float().contiguous() if t.dtype != torch.float32 else t.detach())
+    L.call("tg_encoder_pack", L.ptr(lw_in.contiguous()), L.ptr(lw_o.contiguous()), L.ptr(lw1.contiguous()),
+           L.ptr(lw2.contiguous()), f(b_in), f(b_o), f(g1), f(be1), f(b1), f(b2), f(g2), f(be2), f(gt), f(bt),
+           L.ptr(wpack), L.ptr(prm), L.stream())
+    return wpack, prm
+
+
+def fused_forward(x, nhead, p, tail, alpha, beta_c, wpack, prm, seed, rs, want_z):
+    """(out, z1, z2) of the one-kernel layer; z1 / z2 only when ``want_z`` (training)."""
+    R, S, C = x.shape
+    out = torch.empty_like(x)
+    z1 = torch.empty_like(x) if want_z else None
+    z2 = torch.empty_like(x) if want_z else None
+    rs_arr = (ctypes.c_uint32 * 4)(*rs)
+    ops._launch("tg_encoder_fwd_bf16", L.ptr(x), L.ptr(out), L.ptr(z1), L.ptr(z2), L.ptr(wpack), L.ptr(prm), R, S, nhead,
+                int(tail), float(alpha), float(beta_c), 1e-5, float(p), int(seed), ctypes.addressof(rs_arr), L.stream(),
+                nbytes=2 * x.numel() * (2 + 2 * int(want_z)))
+    return out, z1, z2
 
 
 def _ln_fwd(a, b, bias_b, gamma, beta, res, alpha, beta_c, p, seed, rs, eps=1e-5):
@@ -61,6 +94,13 @@ class _EncoderLayerFn(torch.autograd.Function):
         seed = ops.DropoutRNG.seed
         rs = [ops.DropoutRNG.next_stream() for _ in range(4)]          # attention, norm1, ffn, norm2
         x2d = x.view(T, C)
+        needs_grad = any(ctx.needs_input_grad)
+        if not needs_grad and fused_ok(x, nhead, w1):
+            # inference (main.py:104-155): the whole layer in one kernel, nothing saved
+            wpack, prm = pack_layer(lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None,
+                                    bt if tail else None)
+            out, _, _ = fused_forward(x, nhead, p, tail, alpha, beta_c, wpack, prm, seed, rs, False)
+            return out
         # projections on the hand-written MFMA kernel when the shapes allow (bf16, d_model = feed-forward = 128);
         # its epilogue applies bias and, for linear1, ReLU + dropout, so the pre-activation never exists
         nt = C == 128 and lw1.shape[0] == 128 and ops.nt_ok(x2d, 3 * C, C)     # every GEMM of the layer qualifies

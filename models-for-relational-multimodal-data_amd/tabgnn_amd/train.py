@@ -209,6 +209,7 @@ def train_step(model, flat, opt, batch, loss_weight, ddp=None, step_seed=None):
     """One supervised step (main.py:41-75).  batch = (node_tf, edge_index, edge_tf, y)."""
     node_tf, edge_index, edge_tf, y = batch
     IndexGuard.check()
+    ops.take_index_errors()               # flags of index structures built outside a step are not this step's business
     ops.DropoutRNG.new_step(step_seed)
     flat.zero_grad()
     logits = model(node_tf, edge_index, edge_tf)
