@@ -38,7 +38,7 @@ typedef float ef_f32x8 __attribute__((ext_vector_type(8)));
 constexpr int EF_C = 128;
 constexpr int EF_STAGE_BYTES = 32768;
 constexpr int EF_WAVES = 8;                  // waves per workgroup
-constexpr int EF_NSTAGE = 6;
+constexpr int EF_NSTAGE = 7;              // 4 head blocks (Wq|Wk|Wv rows), Wo, W1, W2
 // fp32 parameter block (floats): b_in[384] | b_o | g1 | be1 | b1 | b2 | g2 | be2 | gt | bt  (128 each)
 enum { EF_P_BIN = 0, EF_P_BO = 384, EF_P_G1 = 512, EF_P_BE1 = 640, EF_P_B1 = 768, EF_P_B2 = 896, EF_P_G2 = 1024,
        EF_P_BE2 = 1152, EF_P_GT = 1280, EF_P_BT = 1408, EF_P_FLOATS = 1536 };
@@ -70,22 +70,18 @@ __global__ void __launch_bounds__(256) k_encoder_pack(const unsigned short* __re
                                                        const float* __restrict__ g2, const float* __restrict__ be2,
                                                        const float* __restrict__ gt, const float* __restrict__ bt,
                                                        char* __restrict__ wpack, float* __restrict__ prm) {
-  const int stage = blockIdx.x;                // 0..5
+  const int stage = blockIdx.x;                // 0..6
   char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
   if (stage < 4) {
-    // rows 0..95: (Wq | Wk | Wv) rows 32*stage + r; 16 chunks each
+    // rows 0..95: (Wq | Wk | Wv) rows 32*stage + r; 16 chunks each (the last 8 KiB of the stage are unused)
     for (int p = threadIdx.x; p < 96 * 16; p += blockDim.x) {
       const int row = p >> 4, c = p & 15, part = row >> 5, r = row & 31;
       const unsigned short* wrow = w_in + (size_t)(128 * part + 32 * stage + r) * EF_C;
       *reinterpret_cast<uint4*>(dst + 8192 * part + ef_off(r, c)) = ef_perm_chunk(wrow, c >> 1, c & 1);
     }
-    // Wo k slice: rows n = 0..127, channels 32*stage .. +31 -> 4 chunks (k-steps 2*stage, 2*stage+1)
-    for (int p = threadIdx.x; p < 128 * 4; p += blockDim.x) {
-      const int n = p >> 2, c = p & 3;
-      *reinterpret_cast<uint4*>(dst + 24576 + ef_off_wo(n, c)) = ef_perm_chunk(w_o + (size_t)n * EF_C, 2 * stage + (c >> 1), c & 1);
-    }
+    for (int p = threadIdx.x; p < 512; p += blockDim.x) *reinterpret_cast<uint4*>(dst + 24576 + 16 * p) = make_uint4(0u, 0u, 0u, 0u);
   } else {
-    const unsigned short* w = stage == 4 ? w1 : w2;
+    const unsigned short* w = stage == 4 ? w_o : stage == 5 ? w1 : w2;
     for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
       const int row = p >> 4, c = p & 15;
       *reinterpret_cast<uint4*>(dst + ef_off(row, c)) = ef_perm_chunk(w + (size_t)row * EF_C, c >> 1, c & 1);
@@ -128,11 +124,14 @@ __device__ __forceinline__ ef_f32x16 ef_zero16() {
 
 // LDS-DMA of one 32 KiB stage by the 512 threads of the workgroup: 4 pieces of 16 bytes per thread, linear image.
 __device__ __forceinline__ void ef_stage_dma(const char* __restrict__ src, char* lds_dst, int tid) {
+  asm volatile("" : "+v"(tid));      // opaque: the per-lane source addresses are formed here, not hoisted out of the
+                                     // persistent loop as 28 64-bit register pairs (which then spill)
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int piece = p * 512 + (tid & ~63);          // wave-uniform first piece of this wave-instruction
+    // wave-uniform 64-bit base + 32-bit lane offset: the saddr form, no per-lane 64-bit address registers
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + (size_t)(piece + (tid & 63)) * 16),
+        (const __attribute__((address_space(1))) void*)(src + (unsigned)((p * 512 + tid) * 16)),
         (__attribute__((address_space(3))) void*)(lds_dst + piece * 16), 16, 0, 0);
   }
 }
@@ -148,15 +147,20 @@ __device__ __forceinline__ void ef_row_stats(const ef_v8bf (&zp)[8], float eps, 
   mu = sum * (1.f / 128.f);
   float var = 0.f;
 #pragma unroll
-  for (int f = 0; f < 8; ++f)
+  for (int f = 0; f < 8; ++f) {
+    // unpack again rather than keep 64 unpacked floats alive across the passes (they spill): opaque copy defeats CSE
+    ef_v8bf z = zp[f];
+    asm volatile("" : "+v"(z));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = (float)zp[f][j] - mu; var += d * d; }
+    for (int j = 0; j < 8; ++j) { const float d = (float)z[j] - mu; var += d * d; }
+  }
   var += ef_xor32(var);
   rstd = rsqrtf(var * (1.f / 128.f) + eps);
 }
 // (z - mu) * rstd * gamma + beta for one fragment; gp / bp point at the fragment's first float4 (channels 16f + 4h ..),
 // the second float4 sits 8 floats further (channels 16f + 8 + 4h ..)
 __device__ __forceinline__ ef_v8bf ef_ln_apply(ef_v8bf z, float mu, float rstd, const float* gp, const float* bp) {
+  asm volatile("" : "+v"(z));          // (see ef_row_stats)
   const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 8);
   const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 8);
   const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -168,6 +172,7 @@ __device__ __forceinline__ ef_v8bf ef_ln_apply(ef_v8bf z, float mu, float rstd, 
 }
 __device__ __forceinline__ ef_v8bf ef_ln_combine(ef_v8bf z, ef_v8bf x, float mu, float rstd, const float* gp,
                                                  const float* bp, float alpha, float beta_c) {
+  asm volatile("" : "+v"(z));
   const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 8);
   const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 8);
   const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -184,6 +189,7 @@ __device__ __forceinline__ ef_v8bf ef_ln_combine(ef_v8bf z, ef_v8bf x, float mu,
 // time): every lane then stores 16 bytes of a 128-byte row segment.  dst = first token of the wave tile.
 __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], char* stg, unsigned short* dst, int lane, int tl, int h,
                                               int nvalid) {
+  asm volatile("" : "+v"(lane), "+v"(tl), "+v"(h));          // (addresses formed here: see ef_stage_dma)
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -197,7 +203,7 @@ __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], char* stg,
     for (int p = 0; p < 4; ++p) {
       const int t = (lane >> 3) + 8 * p, c = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4*>(stg + 128 * t + 16 * (c ^ (t & 7)));
-      if (t < nvalid) *reinterpret_cast<uint4*>(dst + (size_t)t * EF_C + 64 * half + 8 * c) = v;
+      if (t < nvalid) *reinterpret_cast<uint4*>(dst + (unsigned)(t * EF_C + 64 * half + 8 * c)) = v;
     }
   }
 }
@@ -226,10 +232,10 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
   char* wbuf0 = smem;
   char* wbuf1 = smem + EF_STAGE_BYTES;
   float* prm = reinterpret_cast<float*>(smem + 2 * EF_STAGE_BYTES);                  // 6 KiB
-  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;                       // 8 x 4 KiB
+  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;                       // 8 x 8 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl0 = lane & 31, h0 = lane >> 5;
-  char* stg = stg_all + wave * 4096;
+  char* stg = stg_all + wave * 8192;          // wave-private: output restage (4 KiB) / parked x1 fragments (8 KiB)
   constexpr int NH = EF_C / HD;                 // heads
   constexpr int HB = 32 / HD;                   // heads per 32-channel block
   const float scale = HD == 32 ? 0.17677669529663687f : 0.25f;
@@ -247,6 +253,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
   const int q_row = tl0 / S;
   const int row_lo = q_row * S;
 
+  int gstage = 0;              // running stage counter: stage g lives in buffer g & 1 (7 stages per iteration)
   for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
     int tl = tl0, h = h0;
     asm volatile("" : "+v"(tl), "+v"(h));     // opaque per iteration: see EF_OPAQUE below
@@ -261,35 +268,36 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
 
     // ---- x in fragment order: xf[ks] element j = x[t][16ks + 8(j>>2) + 4h + (j&3)]
     ef_v8bf xf[8];
-    const unsigned short* xp = a.x + (tok_ok ? tglob : 0) * EF_C + 4 * h;
+    const unsigned short* xbase = a.x + tok0 * EF_C;                    // wave-uniform
+    const unsigned xoff = (unsigned)((tok_ok ? tl0 : 0) * EF_C + 4 * h0);
 #define EF_LOAD_X()                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
       uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);                                         \
       if (tok_ok) {                                                                                   \
-        lo = *reinterpret_cast<const uint2*>(xp + 16 * ks);                                           \
-        hi = *reinterpret_cast<const uint2*>(xp + 16 * ks + 8);                                       \
+        lo = *reinterpret_cast<const uint2*>(xbase + (xoff + 16 * ks));                               \
+        hi = *reinterpret_cast<const uint2*>(xbase + (xoff + 16 * ks + 8));                           \
       }                                                                                               \
       xf[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                      \
     }
     EF_LOAD_X()
 
-    ef_f32x16 accy[4];
+    // ================================================================ attention, per 32-channel head block
+    ef_v8bf of[8];               // attention output o^T, packed: the B operand of the output projection
 #pragma unroll
-    for (int m = 0; m < 4; ++m) accy[m] = ef_zero16();
-
-    // ================================================================ attention + output projection, per head block
-#pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = (blk & 1) ? wbuf1 : wbuf0;
-      char* wn = (blk & 1) ? wbuf0 : wbuf1;
-      // next stage (blk+1: head block, or W1) -> other buffer
+      char* wb = ((gstage + blk) & 1) ? wbuf1 : wbuf0;
+      char* wn = ((gstage + blk) & 1) ? wbuf0 : wbuf1;
+      // next stage (blk+1: head block, or Wo) -> other buffer
       ef_stage_dma(a.wpack + (size_t)(blk + 1) * EF_STAGE_BYTES, wn, tid);
 
       // K^T and Q^T blocks [32 d, 32 tokens]
       ef_f32x16 acc = ef_zero16();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wb + 8192, ef_off(tl, 2 * ks + h)), xf[ks], acc);
+      for (int ks = 0; ks < 8; ++ks) {
+        acc = EF_MFMA(ef_frag(wb + 8192, ef_off(tl, 2 * ks + h)), xf[ks], acc);
+        if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BIN + 128 + 32 * blk + 8 * g + 4 * h);
@@ -299,7 +307,10 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       acc = ef_zero16();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wb, ef_off(tl, 2 * ks + h)), xf[ks], acc);
+      for (int ks = 0; ks < 8; ++ks) {
+        acc = EF_MFMA(ef_frag(wb, ef_off(tl, 2 * ks + h)), xf[ks], acc);
+        if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BIN + 32 * blk + 8 * g + 4 * h);
@@ -310,7 +321,10 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
       // V block in the transposed orientation [32 tokens (rows), 32 d (columns)]
       acc = ef_zero16();
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(xf[ks], ef_frag(wb + 16384, ef_off(tl, 2 * ks + h)), acc);
+      for (int ks = 0; ks < 8; ++ks) {
+        acc = EF_MFMA(xf[ks], ef_frag(wb + 16384, ef_off(tl, 2 * ks + h)), acc);
+        if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+      }
       {
         const float bv = prm[EF_P_BIN + 256 + 32 * blk + tl];
 #pragma unroll
@@ -319,7 +333,6 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
       const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
       __builtin_amdgcn_sched_barrier(0);
 
-      ef_v8bf of0, of1;
 #pragma unroll
       for (int hh = 0; hh < HB; ++hh) {
         // scores S^T[key (rows), query (columns)]
@@ -372,32 +385,35 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         ot = EF_MFMA(vf0, pf0, ot);
         ot = EF_MFMA(vf1, pf1, ot);
         if constexpr (HB == 1) {
-          of0 = ef_pack<0>(ot); of1 = ef_pack<1>(ot);
+          of[2 * blk] = ef_pack<0>(ot); of[2 * blk + 1] = ef_pack<1>(ot);
         } else {
-          if (hh == 0) of0 = ef_pack<0>(ot); else of1 = ef_pack<1>(ot);
+          if (hh == 0) of[2 * blk] = ef_pack<0>(ot); else of[2 * blk + 1] = ef_pack<1>(ot);
         }
-      }
-      // output projection: y^T[n, t] += Wo[n, 32 blk + ...] o^T
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        accy[m] = EF_MFMA(ef_frag(wb + 24576, ef_off_wo(32 * m + tl, h)), of0, accy[m]);
-        accy[m] = EF_MFMA(ef_frag(wb + 24576, ef_off_wo(32 * m + tl, 2 + h)), of1, accy[m]);
       }
       __syncthreads();          // stage blk consumed by every wave; the DMA of stage blk+1 has landed (vmcnt(0) + barrier)
     }
+    gstage += 4;
 
-    // ================================================================ LayerNorm 1 (registers)
-    // z1 = x + drop(y + b_o), rounded to bf16 (what is stored and what the backward recomputes from);
+    // ================================================================ output projection + LayerNorm 1 (registers)
+    // z1 = x + drop(o Wo^T + b_o), rounded to bf16 (what is stored and what the backward recomputes from);
     // x1 = LN(z1) * g1 + be1, rounded to bf16: the feed-forward input and residual
     asm volatile("" : "+v"(tl), "+v"(h));
     const unsigned long long e_base = (unsigned long long)tglob * EF_C;
     ef_v8bf x1f[8];
     {
+      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
+      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
+      ef_stage_dma(a.wpack + (size_t)5 * EF_STAGE_BYTES, wn, tid);          // W1
       ef_v8bf zp[8];
       const unsigned dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        __builtin_amdgcn_sched_barrier(0);
+        ef_f32x16 acc = ef_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), of[ks], acc);
+          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BO + 32 * m + 8 * g + 4 * h);
@@ -405,15 +421,15 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * g + j;
-            float u = accy[m][i] + bb[j];
+            float u = acc[i] + bb[j];
             if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
-            accy[m][i] = u + ef_bf(xf[2 * m + (i >> 3)], i & 7);
+            acc[i] = u + ef_bf(xf[2 * m + (i >> 3)], i & 7);
           }
         }
-        zp[2 * m] = ef_pack<0>(accy[m]);
-        zp[2 * m + 1] = ef_pack<1>(accy[m]);
+        zp[2 * m] = ef_pack<0>(acc);
+        zp[2 * m + 1] = ef_pack<1>(acc);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
       if (a.z1) ef_store_rows(zp, stg, a.z1 + tok0 * EF_C, lane, tl, h, nvalid);
       float mu, rstd;
       ef_row_stats(zp, a.eps, mu, rstd);
@@ -421,21 +437,30 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
       for (int f = 0; f < 8; ++f) {
         __builtin_amdgcn_sched_barrier(0);
         x1f[f] = ef_ln_apply(zp[f], mu, rstd, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
+        // parked in LDS (lane-linear, read back by the same lane) for the residual of the second sub-layer: 32
+        // registers less across the feed-forward
+        *reinterpret_cast<uint4*>(stg + 1024 * f + 16 * lane) = __builtin_bit_cast(uint4, x1f[f]);
       }
+      __syncthreads();          // Wo consumed; W1 landed
+      gstage += 1;
     }
 
     // ================================================================ feed-forward 1: h = drop(relu(W1 x1 + b1))
     ef_v8bf hf[8];
     {
       asm volatile("" : "+v"(tl), "+v"(h));
-      // stage 5 (W2) -> wbuf1 while W1 (wbuf0) is used
-      ef_stage_dma(a.wpack + (size_t)5 * EF_STAGE_BYTES, wbuf1, tid);
+      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
+      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
+      ef_stage_dma(a.wpack + (size_t)6 * EF_STAGE_BYTES, wn, tid);          // W2
       const unsigned dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         ef_f32x16 acc = ef_zero16();
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wbuf0, ef_off(32 * m + tl, 2 * ks + h)), x1f[ks], acc);
+        for (int ks = 0; ks < 8; ++ks) {
+          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), x1f[ks], acc);
+          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
@@ -452,20 +477,28 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();          // W1 consumed; W2 landed
+      gstage += 1;
     }
 
     // ================================================================ feed-forward 2 + LayerNorm 2 (+ tail LayerNorm)
     {
-      // stage 0 of the next iteration -> wbuf0 while W2 (wbuf1) is used
       asm volatile("" : "+v"(tl), "+v"(h));
-      if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
+      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
+      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
+      // stage 0 of the next iteration -> other buffer while W2 is used
+      if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wn, tid);
       ef_v8bf zp[8];
       const unsigned dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         ef_f32x16 acc = ef_zero16();
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc = EF_MFMA(ef_frag(wbuf1, ef_off(32 * m + tl, 2 * ks + h)), hf[ks], acc);
+        for (int ks = 0; ks < 8; ++ks) {
+          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), hf[ks], acc);
+          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        const ef_v8bf r0 = __builtin_bit_cast(ef_v8bf, *reinterpret_cast<const uint4*>(stg + 1024 * (2 * m) + 16 * lane));
+        const ef_v8bf r1 = __builtin_bit_cast(ef_v8bf, *reinterpret_cast<const uint4*>(stg + 1024 * (2 * m + 1) + 16 * lane));
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B2 + 32 * m + 8 * g + 4 * h);
@@ -475,7 +508,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
             const int i = 4 * g + j;
             float u = acc[i] + bb[j];
             if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
-            acc[i] = u + ef_bf(x1f[2 * m + (i >> 3)], i & 7);
+            acc[i] = u + ef_bf(i < 8 ? r0 : r1, i & 7);
           }
         }
         zp[2 * m] = ef_pack<0>(acc);
@@ -503,6 +536,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
       }
       ef_store_rows(zp, stg, a.out + tok0 * EF_C, lane, tl, h, nvalid);
       __syncthreads();          // W2 consumed; next iteration's stage 0 landed
+      gstage += 1;
     }
   }
 }
@@ -563,7 +597,7 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
     n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
   const unsigned grid = (unsigned)(n_it < n_cu ? n_it : n_cu);
-  const size_t lds = 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 4096;
+  const size_t lds = 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

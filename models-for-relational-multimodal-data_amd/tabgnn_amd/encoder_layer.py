@@ -25,6 +25,9 @@ _FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B 
 _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B switch: the one-kernel layer (encoder_fused.hip)
 
 
+STATS = {"fused_fwd": 0, "fused_bwd": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
+
+
 def fused_ok(x, nhead, w1):
     """Shapes the one-kernel layer takes: bf16 rows of S <= 32 column tokens, d_model = feed-forward = 128, 4 or 8 heads."""
     return (_FUSED_LAYER and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.shape[0] > 0
@@ -84,7 +87,8 @@ def _ln_bwd(a, b, bias_b, gamma, stats, g, da, want_db, dres, alpha, beta_c, p, 
 
 class _EncoderLayerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, nhead, p, tail, alpha, beta_c, w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2, gt, bt):
+    def forward(ctx, x, nhead, p, tail, alpha, beta_c, w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2, gt, bt,
+                needs_grad=True):
         x = x.contiguous()
         R, S, C = x.shape
         T = R * S
@@ -94,12 +98,12 @@ class _EncoderLayerFn(torch.autograd.Function):
         seed = ops.DropoutRNG.seed
         rs = [ops.DropoutRNG.next_stream() for _ in range(4)]          # attention, norm1, ffn, norm2
         x2d = x.view(T, C)
-        needs_grad = any(ctx.needs_input_grad)
         if not needs_grad and fused_ok(x, nhead, w1):
             # inference (main.py:104-155): the whole layer in one kernel, nothing saved
             wpack, prm = pack_layer(lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None,
                                     bt if tail else None)
             out, _, _ = fused_forward(x, nhead, p, tail, alpha, beta_c, wpack, prm, seed, rs, False)
+            STATS["fused_fwd"] += 1
             return out
         # projections on the hand-written MFMA kernel when the shapes allow (bf16, d_model = feed-forward = 128);
         # its epilogue applies bias and, for linear1, ReLU + dropout, so the pre-activation never exists
@@ -230,7 +234,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         else:
             d_x.addmm_(d_qkv, lw_in)
         return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],
-                dp1[0], dp1[1], dp2[0], dp2[1], dgt, dbt)
+                dp1[0], dp1[1], dp2[0], dp2[1], dgt, dbt, None)
 
 
 def encoder_layer(x, layer, p, tail_norm=None, alpha=0.0, beta_c=1.0):
@@ -239,7 +243,9 @@ def encoder_layer(x, layer, p, tail_norm=None, alpha=0.0, beta_c=1.0):
     tail = tail_norm is not None
     gt = tail_norm.weight if tail else None
     bt = tail_norm.bias if tail else None
-    return _EncoderLayerFn.apply(x, layer.nhead, float(p), tail, float(alpha), float(beta_c), sa.in_proj_weight,
-                                 sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.linear1.weight,
-                                 layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight,
-                                 layer.norm1.bias, layer.norm2.weight, layer.norm2.bias, gt, bt)
+    params = (sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias, layer.linear1.weight,
+              layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm1.weight, layer.norm1.bias,
+              layer.norm2.weight, layer.norm2.bias, gt, bt)
+    # (inside Function.forward grad mode is always off and needs_input_grad ignores it: decide here)
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(t is not None and t.requires_grad for t in params))
+    return _EncoderLayerFn.apply(x, layer.nhead, float(p), tail, float(alpha), float(beta_c), *params, needs_grad)

@@ -45,8 +45,11 @@ def test_fused_forward_matches_torch_encoder_layer(S, H, R, use_tail, alpha, bet
     x = (torch.randn(R, S, 128) * 1.3).to(torch.bfloat16)
     want = _torch_reference(layer, tail, x, H, use_tail, alpha, beta_c)
     layer.to(DEV); tail.to(DEV)
+    import tabgnn_amd.encoder_layer as EL
+    n0 = EL.STATS["fused_fwd"]
     with torch.no_grad():
         got = encoder_layer(x.to(DEV), layer, 0.0, tail if use_tail else None, alpha, beta_c)
+    assert EL.STATS["fused_fwd"] == n0 + 1                       # the one-kernel layer ran, not the op-by-op kernels
     assert got.dtype == torch.bfloat16 and got.shape == x.shape
     err = (got.float().cpu() - want).abs().max().item()
     assert err <= BF16_TOL, err
@@ -64,12 +67,14 @@ def test_fused_forward_matches_op_by_op_kernels_same_dropout_masks(S, H, R, p):
     layer.to(DEV); tail.to(DEV)
     x = (torch.randn(R, S, 128, device=DEV) * 1.3).to(torch.bfloat16)
     outs = []
+    n0 = EL.STATS["fused_fwd"]
     for fused in (True, False):
         EL._FUSED_LAYER = fused
         ops.DropoutRNG.new_step(4242)
         with torch.no_grad():
             outs.append(EL.encoder_layer(x, layer, p, tail, 0.5, 0.5).float())
     EL._FUSED_LAYER = True
+    assert EL.STATS["fused_fwd"] == n0 + 1
     d = (outs[0] - outs[1]).abs()
     assert d.max().item() <= 0.08 and d.mean().item() <= 0.004, (d.max().item(), d.mean().item())
 
