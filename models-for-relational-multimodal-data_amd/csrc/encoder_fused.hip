@@ -541,6 +541,377 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- backward, feed-forward half
+// Everything between the layer output and x1, recomputed from (z1, z2) in the same register-chained form:
+//     g = d out -> (tail LayerNorm backward) -> LayerNorm-2 backward -> d_z2 ; d_y2 = mask3 . d_z2
+//     x1 = LN1(z1) ; h = drop(relu(W1 x1 + b1))                           (recomputed, one GEMM)
+//     d_h = d_y2 W2 ; d_hpre = d_h . [h > 0] / keep ; d_x1 = d_z2 + d_hpre W1
+// Written: d_x1 (the gradient the attention half continues from) and the four operands of the two weight-gradient
+// GEMMs (d_y2, h) and (d_hpre, x1) — tg_gemm_tn_bf16 also sums the bias gradients from d_y2 / d_hpre.  LayerNorm
+// parameter gradients are a separate streaming pass (tg_encoder_ln_grads).
+// Stages (LDS weight images, k-permuted like the forward's): W1 [f][n] | W2^T [f][n] | W1^T [n][f].
+struct EbArgs {
+  const unsigned short *g, *z1, *z2;
+  unsigned short *dx1, *dy2, *hout, *dhpre, *x1out;
+  const char* wpack;
+  const float* prm;
+  long long R;
+  int S, tail;
+  float beta_c, eps;
+  unsigned thresh;
+  float inv_keep;
+  unsigned long long seed;
+  unsigned rs2, rs3;
+};
+
+// sums over a token's 128 channels of (a) dy*gamma and (b) dy*gamma*xhat, with xhat = (z - mu) * rstd; dy, z packed
+__device__ __forceinline__ void ef_ln_bwd_sums(const ef_v8bf (&dy)[8], const ef_v8bf (&z)[8], float dy_scale, float mu,
+                                               float rstd, const float* gamma, int h, float& s1, float& s2) {
+  s1 = 0.f; s2 = 0.f;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    ef_v8bf d = dy[f], zz = z[f];
+    asm volatile("" : "+v"(d), "+v"(zz));
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + 16 * f + 4 * h), g1 = *reinterpret_cast<const float4*>(gamma + 16 * f + 8 + 4 * h);
+    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float dg = (float)d[j] * dy_scale * gg[j];
+      s1 += dg;
+      s2 += dg * (((float)zz[j] - mu) * rstd);
+    }
+  }
+  s1 += ef_xor32(s1);
+  s2 += ef_xor32(s2);
+  s1 *= (1.f / 128.f);
+  s2 *= (1.f / 128.f);
+}
+// d_z = rstd * (dy*gamma - s1 - xhat * s2) for one fragment
+__device__ __forceinline__ ef_f32x8 ef_ln_bwd_apply(ef_v8bf d, ef_v8bf zz, float dy_scale, float mu, float rstd, float s1,
+                                                     float s2, const float* gamma_f) {
+  asm volatile("" : "+v"(d), "+v"(zz));
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma_f), g1 = *reinterpret_cast<const float4*>(gamma_f + 8);
+  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  ef_f32x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float dg = (float)d[j] * dy_scale * gg[j];
+    o[j] = rstd * (dg - s1 - (((float)zz[j] - mu) * rstd) * s2);
+  }
+  return o;
+}
+
+template <bool DROP>
+__global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wbuf0 = smem;
+  char* wbuf1 = smem + EF_STAGE_BYTES;
+  float* prm = reinterpret_cast<float*>(smem + 2 * EF_STAGE_BYTES);
+  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl0 = lane & 31, h0 = lane >> 5;
+  char* stg = stg_all + wave * 8192;
+  const int S = a.S;
+  const int RW = 32 / S;
+  const long long n_wt = (a.R + RW - 1) / RW;
+  const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
+  for (int i = tid; i < EF_P_FLOATS; i += 512) prm[i] = a.prm[i];
+  if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
+  __syncthreads();
+
+  int gstage = 0;
+  for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
+    int tl = tl0, h = h0;
+    asm volatile("" : "+v"(tl), "+v"(h));
+    const long long wt = it * EF_WAVES + wave;
+    const long long row0 = wt * RW;
+    long long rows_here = a.R - row0;
+    rows_here = rows_here < 0 ? 0 : (rows_here > RW ? RW : rows_here);
+    const int nvalid = (int)rows_here * S;
+    const long long tok0 = row0 * S;
+    const bool tok_ok = tl0 < nvalid;
+    const long long tglob = tok0 + tl0;
+    const unsigned long long e_base = (unsigned long long)tglob * EF_C;
+    const unsigned xoff = (unsigned)((tok_ok ? tl0 : 0) * EF_C + 4 * h0);
+#define EB_LOAD(DST, SRC)                                                                             \
+    {                                                                                                 \
+      const unsigned short* base_ = (SRC) + tok0 * EF_C;                                              \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
+        uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);                                       \
+        if (tok_ok) {                                                                                 \
+          lo = *reinterpret_cast<const uint2*>(base_ + (xoff + 16 * ks));                             \
+          hi = *reinterpret_cast<const uint2*>(base_ + (xoff + 16 * ks + 8));                         \
+        }                                                                                             \
+        DST[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                    \
+      }                                                                                               \
+    }
+    ef_v8bf gf[8], zf[8];
+    EB_LOAD(gf, a.g)
+    EB_LOAD(zf, a.z2)
+
+    // ---- tail LayerNorm backward and LayerNorm-2 backward (registers); gf becomes d_x2, then d_y2; dzf = d_z2
+    float mu2, rstd2;
+    ef_row_stats(zf, a.eps, mu2, rstd2);
+    if (a.tail) {
+      ef_v8bf x2f[8];
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        x2f[f] = ef_ln_apply(zf[f], mu2, rstd2, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
+      }
+      float mut, rstdt, s1, s2;
+      ef_row_stats(x2f, a.eps, mut, rstdt);
+      ef_ln_bwd_sums(gf, x2f, a.beta_c, mut, rstdt, prm + EF_P_GT, h, s1, s2);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        gf[f] = __builtin_convertvector(ef_ln_bwd_apply(gf[f], x2f[f], a.beta_c, mut, rstdt, s1, s2, prm + EF_P_GT + 16 * f + 4 * h), ef_v8bf);
+      }
+    }
+    ef_v8bf dzf[8];
+    {
+      float s1, s2;
+      ef_ln_bwd_sums(gf, zf, 1.f, mu2, rstd2, prm + EF_P_G2, h, s1, s2);
+      const unsigned dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        ef_f32x8 dz = ef_ln_bwd_apply(gf[f], zf[f], 1.f, mu2, rstd2, s1, s2, prm + EF_P_G2 + 16 * f + 4 * h);
+        dzf[f] = __builtin_convertvector(dz, ef_v8bf);
+        if constexpr (DROP) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            dz[j] *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 * (j >> 2) + 4 * h + (j & 3)), a.thresh, a.inv_keep);
+          gf[f] = __builtin_convertvector(dz, ef_v8bf);
+        } else {
+          gf[f] = dzf[f];
+        }
+      }
+    }
+    ef_store_rows(gf, stg, a.dy2 + tok0 * EF_C, lane, tl, h, nvalid);            // d_y2: operand of dW2 (and db2)
+
+    // ---- x1 = LN1(z1) (recomputed), written as the X operand of dW1
+    ef_v8bf x1f[8];
+    {
+      EB_LOAD(zf, a.z1)
+      float mu1, rstd1;
+      ef_row_stats(zf, a.eps, mu1, rstd1);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        x1f[f] = ef_ln_apply(zf[f], mu1, rstd1, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
+      }
+      ef_store_rows(x1f, stg, a.x1out + tok0 * EF_C, lane, tl, h, nvalid);
+    }
+
+    // ---- stage W1: h = drop(relu(W1 x1 + b1)) (recomputed), written as the X operand of dW2
+    ef_v8bf hf[8];
+    {
+      asm volatile("" : "+v"(tl), "+v"(h));
+      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
+      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
+      ef_stage_dma(a.wpack + (size_t)1 * EF_STAGE_BYTES, wn, tid);          // W2^T
+      const unsigned dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        ef_f32x16 acc = ef_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), x1f[ks], acc);
+          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
+          const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
+            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            acc[4 * g + j] = u;
+          }
+        }
+        hf[2 * m] = ef_pack<0>(acc);
+        hf[2 * m + 1] = ef_pack<1>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ef_store_rows(hf, stg, a.hout + tok0 * EF_C, lane, tl, h, nvalid);
+      __syncthreads();
+      gstage += 1;
+    }
+
+    // ---- stage W2^T: d_h = d_y2 W2, gated by the recomputed h: d_hpre (G operand of dW1, and db1)
+    {
+      asm volatile("" : "+v"(tl), "+v"(h));
+      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
+      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
+      ef_stage_dma(a.wpack + (size_t)2 * EF_STAGE_BYTES, wn, tid);          // W1^T
+      const float keep = DROP ? a.inv_keep : 1.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        ef_f32x16 acc = ef_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), gf[ks], acc);
+          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = ef_bf(hf[2 * m + (i >> 3)], i & 7) > 0.f ? acc[i] * keep : 0.f;
+        hf[2 * m] = ef_pack<0>(acc);            // hf now holds d_hpre for the blocks done
+        hf[2 * m + 1] = ef_pack<1>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ef_store_rows(hf, stg, a.dhpre + tok0 * EF_C, lane, tl, h, nvalid);
+      __syncthreads();
+      gstage += 1;
+    }
+
+    // ---- stage W1^T: d_x1 = d_z2 + d_hpre W1
+    {
+      asm volatile("" : "+v"(tl), "+v"(h));
+      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
+      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
+      if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wn, tid);            // next iteration's W1
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        ef_f32x16 acc = ef_zero16();
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), hf[ks], acc);
+          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += ef_bf(dzf[2 * m + (i >> 3)], i & 7);
+        dzf[2 * m] = ef_pack<0>(acc);
+        dzf[2 * m + 1] = ef_pack<1>(acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      ef_store_rows(dzf, stg, a.dx1 + tok0 * EF_C, lane, tl, h, nvalid);
+      __syncthreads();
+      gstage += 1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- LayerNorm parameter gradients
+// The chained kernels keep a token on a lane, so sums over TOKENS (the LayerNorm weight / bias gradients) are taken by
+// this streaming pass instead: 16 lanes per token row (8 channels each), per-thread column accumulators, per-block
+// partial vectors summed in block order by k_ef_reduce (deterministic, no float atomics).
+//   MODE 0 (tail + norm2): reads g = d out and z2:  d_gt, d_bt (tail) and d_g2, d_be2
+//   MODE 1 (norm1):        reads d_x1 and z1:       d_g1, d_be1
+constexpr int EG_BLOCK = 256, EG_MAXBLK = 1024;
+struct EgArgs {
+  const unsigned short *dy, *z;
+  const float *g_inner, *b_inner, *g_tail;      // MODE 0: gamma2, beta2, gamma_t;  MODE 1: unused
+  float* partials;                              // [grid][4][128]
+  long long T;
+  int tail;
+  float beta_c, eps;
+};
+template <int MODE>
+__global__ void __launch_bounds__(EG_BLOCK) k_encoder_ln_grads(const EgArgs a) {
+  __shared__ float red[16][4][128];
+  const int gl = threadIdx.x & 15, gi = threadIdx.x >> 4;
+  float acc[4][8];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[v][j] = 0.f;
+  float g2[8], b2[8], gt[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    g2[j] = MODE == 0 ? a.g_inner[8 * gl + j] : 1.f;
+    b2[j] = MODE == 0 ? a.b_inner[8 * gl + j] : 0.f;
+    gt[j] = (MODE == 0 && a.tail) ? a.g_tail[8 * gl + j] : 1.f;
+  }
+  for (long long row = (long long)blockIdx.x * 16 + gi; row < a.T; row += (long long)gridDim.x * 16) {
+    float dy[8], z[8];
+    loadv<bf16_t, 8>(reinterpret_cast<const bf16_t*>(a.dy) + row * EF_C + 8 * gl, dy);
+    loadv<bf16_t, 8>(reinterpret_cast<const bf16_t*>(a.z) + row * EF_C + 8 * gl, z);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += z[j];
+    const float mu = group_sum<16>(s) * (1.f / 128.f);
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
+    const float rstd = rsqrtf(group_sum<16>(v) * (1.f / 128.f) + a.eps);
+    float zh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zh[j] = (z[j] - mu) * rstd;
+    if (MODE == 0 && a.tail) {
+      // x2 = bf16(LN2(z2)); tail statistics; d_x2 = tail LayerNorm backward of beta_c * g
+      float x2[8], s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { x2[j] = bf2f(f2bf(zh[j] * g2[j] + b2[j])); s2 += x2[j]; }
+      const float mut = group_sum<16>(s2) * (1.f / 128.f);
+      float vt = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = x2[j] - mut; vt += d * d; }
+      const float rstdt = rsqrtf(group_sum<16>(vt) * (1.f / 128.f) + a.eps);
+      float t1 = 0.f, t2 = 0.f, xh[8], dg[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float go = dy[j] * a.beta_c;
+        xh[j] = (x2[j] - mut) * rstdt;
+        acc[2][j] += go * xh[j];            // d gamma_t
+        acc[3][j] += go;                    // d beta_t
+        dg[j] = go * gt[j];
+        t1 += dg[j];
+        t2 += dg[j] * xh[j];
+      }
+      t1 = group_sum<16>(t1) * (1.f / 128.f);
+      t2 = group_sum<16>(t2) * (1.f / 128.f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dy[j] = bf2f(f2bf(rstdt * (dg[j] - t1 - xh[j] * t2)));     // d_x2, rounded as the chain rounds it
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[0][j] += dy[j] * zh[j];           // d gamma (norm2 / norm1)
+      acc[1][j] += dy[j];                   // d beta
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[gi][v][8 * gl + j] = acc[v][j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * 128; i += EG_BLOCK) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][i >> 7][i & 127];
+    a.partials[(size_t)blockIdx.x * 512 + i] = t;
+  }
+}
+struct EgOut { float* dst[4]; };
+__global__ void __launch_bounds__(128) k_ef_reduce(const float* __restrict__ partials, int nblk, const EgOut o, int accumulate) {
+  const int v = blockIdx.x, c = threadIdx.x;
+  if (!o.dst[v]) return;
+  float t = 0.f;
+  for (int b = 0; b < nblk; ++b) t += partials[(size_t)b * 512 + v * 128 + c];
+  o.dst[v][c] = accumulate ? o.dst[v][c] + t : t;
+}
+
+// ---------------------------------------------------------------------------------------------- generic tile pack
+struct EfTileList {
+  const unsigned short* src[8];    // [128 rows][128] bf16 row-major tiles (row stride ld[i])
+  int ld[8];
+  int n;
+};
+// wpack stage i = k-permuted, swizzled LDS image of tile i (see k_encoder_pack)
+__global__ void __launch_bounds__(256) k_encoder_pack_tiles(const EfTileList t, char* __restrict__ wpack) {
+  const int stage = blockIdx.x;
+  if (stage >= t.n) return;
+  char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
+  const unsigned short* w = t.src[stage];
+  const int ld = t.ld[stage];
+  for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
+    const int row = p >> 4, c = p & 15;
+    *reinterpret_cast<uint4*>(dst + ef_off(row, c)) = ef_perm_chunk(w + (size_t)row * ld, c >> 1, c & 1);
+  }
+}
+
 }  // namespace tg
 
 using namespace tg;
@@ -611,6 +982,93 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
   else if (H == 4) hipLaunchKernelGGL((k_encoder_fwd<32, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
   else if (drop) hipLaunchKernelGGL((k_encoder_fwd<16, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((k_encoder_fwd<16, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Backward weight images: stage i = tile i ([128,128] bf16 row-major, row stride ld[i]); the feed-forward half takes
+// (W1, W2^T, W1^T) in this order.  wpack: n * 32 KiB.
+extern "C" int tg_encoder_pack_tiles(const void* const* tiles, const int32_t* ld, int32_t n, void* wpack, void* stream) {
+  TG_CHECK(tiles && ld && wpack && n >= 1 && n <= 8, "tg_encoder_pack_tiles: bad arguments (n=%d)", n);
+  EfTileList t;
+  t.n = n;
+  for (int i = 0; i < 8; ++i) { t.src[i] = i < n ? (const unsigned short*)tiles[i] : nullptr; t.ld[i] = i < n ? ld[i] : 0; }
+  for (int i = 0; i < n; ++i)
+    TG_CHECK(t.src[i] && (reinterpret_cast<uintptr_t>(t.src[i]) & 7) == 0 && t.ld[i] >= 128 && t.ld[i] % 4 == 0,
+             "tg_encoder_pack_tiles: tile %d must be 8-byte aligned with a row stride >= 128", i);
+  hipLaunchKernelGGL(k_encoder_pack_tiles, dim3(n), dim3(256), 0, (hipStream_t)stream, t, (char*)wpack);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+static size_t ef_lds_bytes() { return 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192; }
+static unsigned ef_grid(long long R, int S) {
+  const int RW = 32 / S;
+  const long long n_wt = (R + RW - 1) / RW, n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return (unsigned)(n_it < n_cu ? n_it : n_cu);
+}
+
+// Feed-forward half of the layer backward (see k_encoder_bwd_ffn).  g = d out [R,S,128]; z1, z2 from the forward;
+// wpack = tg_encoder_pack_tiles(W1, W2^T, W1^T); prm = the forward's parameter block.  Writes d_x1 and the weight-gradient
+// operands d_y2, h, d_hpre, x1 (all [R,S,128] bf16).  rs: the forward's dropout streams.
+extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void* z2, void* dx1, void* dy2, void* hout,
+                                       void* dhpre, void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S,
+                                       int32_t tail, float beta_c, float eps, float p_drop, uint64_t seed,
+                                       const uint32_t* rs, void* stream) {
+  TG_CHECK(S >= 1 && S <= 32, "tg_encoder_bwd_ffn_bf16: unsupported S=%d", S);
+  TG_CHECK(g && z1 && z2 && dx1 && dy2 && hout && dhpre && x1out && wpack && prm && rs, "tg_encoder_bwd_ffn_bf16: null operand");
+  if (R <= 0) return 0;
+  EbArgs a;
+  a.g = (const unsigned short*)g; a.z1 = (const unsigned short*)z1; a.z2 = (const unsigned short*)z2;
+  a.dx1 = (unsigned short*)dx1; a.dy2 = (unsigned short*)dy2; a.hout = (unsigned short*)hout; a.dhpre = (unsigned short*)dhpre;
+  a.x1out = (unsigned short*)x1out; a.wpack = (const char*)wpack; a.prm = prm; a.R = R; a.S = S; a.tail = tail;
+  a.beta_c = beta_c; a.eps = eps;
+  a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  a.seed = seed; a.rs2 = rs[2]; a.rs3 = rs[3];
+  const size_t lds = ef_lds_bytes();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_ffn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_ffn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const unsigned grid = ef_grid(R, S);
+  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_ffn<true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_encoder_bwd_ffn<false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int64_t tg_encoder_ln_grads_partials_floats(void) { return (int64_t)EG_MAXBLK * 512; }
+// LayerNorm parameter gradients of the fused layer backward (k_encoder_ln_grads).
+//   mode 0: dy = d out, z = z2, gamma/beta = norm2's, gamma_t = tail norm's (NULL without tail):
+//           out[0] = d gamma2, out[1] = d beta2, out[2] = d gamma_t, out[3] = d beta_t
+//   mode 1: dy = d_x1, z = z1: out[0] = d gamma1, out[1] = d beta1
+// out[i] fp32 [128] or NULL; accumulate = 1 adds into them (.grad semantics).  partials: tg_encoder_ln_grads_partials_floats().
+extern "C" int tg_encoder_ln_grads(int32_t mode, const void* dy, const void* z, const float* gamma, const float* beta,
+                                   const float* gamma_t, float beta_c, float eps, int64_t T, float* const* out,
+                                   int32_t accumulate, float* partials, void* stream) {
+  TG_CHECK((mode == 0 || mode == 1) && dy && z && out && partials, "tg_encoder_ln_grads: bad arguments");
+  TG_CHECK(mode == 1 || (gamma && beta), "tg_encoder_ln_grads: mode 0 needs norm2's gamma / beta");
+  EgOut o;
+  for (int i = 0; i < 4; ++i) o.dst[i] = (mode == 0 || i < 2) ? out[i] : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (T <= 0) return 0;
+  EgArgs a;
+  a.dy = (const unsigned short*)dy; a.z = (const unsigned short*)z; a.g_inner = gamma; a.b_inner = beta; a.g_tail = gamma_t;
+  a.partials = partials; a.T = T; a.tail = gamma_t != nullptr; a.beta_c = beta_c; a.eps = eps;
+  const int grid = grid_cap(ceil_div(T, 16 * 8), EG_MAXBLK);
+  if (mode == 0) hipLaunchKernelGGL(k_encoder_ln_grads<0>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
+  else hipLaunchKernelGGL(k_encoder_ln_grads<1>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
+  hipLaunchKernelGGL(k_ef_reduce, dim3(4), dim3(128), 0, st, partials, grid, o, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }

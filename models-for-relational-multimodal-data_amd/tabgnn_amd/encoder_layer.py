@@ -23,6 +23,7 @@ from . import ops
 
 _FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B switch
 _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B switch: the one-kernel layer (encoder_fused.hip)
+_FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
 
 
 STATS = {"fused_fwd": 0, "fused_bwd": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
@@ -105,6 +106,20 @@ class _EncoderLayerFn(torch.autograd.Function):
             out, _, _ = fused_forward(x, nhead, p, tail, alpha, beta_c, wpack, prm, seed, rs, False)
             STATS["fused_fwd"] += 1
             return out
+        if needs_grad and _FUSED_TRAIN and fused_ok(x, nhead, w1):
+            # training: one kernel, only the two pre-LayerNorm sums are kept; the backward recomputes the rest
+            wpack, prm = pack_layer(lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None,
+                                    bt if tail else None)
+            out, z1, z2 = fused_forward(x, nhead, p, tail, alpha, beta_c, wpack, prm, seed, rs, True)
+            STATS["fused_fwd"] += 1
+            ctx.save_for_backward(x2d, z1, z2, prm, lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, g2, be2, gt)
+            ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
+            ctx.fused = True
+            isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
+            ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2))
+            ctx.ln_params = ((g1, be1, b_o), (g2, be2, b2), (gt, bt, None))
+            return out.view(R, S, C)
+        ctx.fused = False
         # projections on the hand-written MFMA kernel when the shapes allow (bf16, d_model = feed-forward = 128);
         # its epilogue applies bias and, for linear1, ReLU + dropout, so the pre-activation never exists
         nt = C == 128 and lw1.shape[0] == 128 and ops.nt_ok(x2d, 3 * C, C)     # every GEMM of the layer qualifies
@@ -144,6 +159,8 @@ class _EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.fused:
+            return _fused_backward(ctx, g)
         (x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2, g1, g2,
          gt) = ctx.saved_tensors
         R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
@@ -235,6 +252,91 @@ class _EncoderLayerFn(torch.autograd.Function):
             d_x.addmm_(d_qkv, lw_in)
         return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],
                 dp1[0], dp1[1], dp2[0], dp2[1], dgt, dbt, None)
+
+
+def _grad_ptrs(params):
+    """ctypes array of the parameters' gradient-buffer pointers (FlatParams views) or None when one has none."""
+    tg = [ops._grad_target(p) if isinstance(p, torch.nn.Parameter) else None for p in params]
+    return tg if all(t is not None for t in tg) else None
+
+
+def _ln_grads(mode, dy, z, gamma, beta, gamma_t, beta_c, params):
+    """LayerNorm weight / bias gradients by the streaming pass (tg_encoder_ln_grads); ``params`` = the parameters whose
+    gradients come out, in the kernel's order.  Adds into their gradient buffers when every one has one (returns Nones),
+    else returns fp32 tensors."""
+    lib = L.load()
+    T = dy.numel() // 128
+    dev = dy.device
+    partials = torch.empty(lib.tg_encoder_ln_grads_partials_floats(), dtype=torch.float32, device=dev)
+    live = [p for p in params if p is not None]
+    tg = _grad_ptrs(live)
+    outs = tg if tg is not None else [torch.empty(128, dtype=torch.float32, device=dev) for _ in live]
+    arr = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in outs] + [None] * (4 - len(outs))))
+    f = lambda t: None if t is None else L.ptr(t.detach())
+    L.call("tg_encoder_ln_grads", mode, L.ptr(dy), L.ptr(z), f(gamma), f(beta), f(gamma_t), float(beta_c), 1e-5, T,
+           ctypes.addressof(arr), int(tg is not None), L.ptr(partials), L.stream())
+    return [None] * len(live) if tg is not None else outs
+
+
+def _fused_backward(ctx, g):
+    """Backward of the one-kernel layer: everything is recomputed from (x, z1, z2).  Feed-forward half: one chained
+    kernel (tg_encoder_bwd_ffn_bf16) + the two weight-gradient GEMMs + the LayerNorm-parameter pass."""
+    (x2d, z1, z2, prm, lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, g2, be2, gt) = ctx.saved_tensors
+    R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
+    p_in, pb_in, p_o, p_1, pb_1, p_2, pb_2 = ctx.params
+    T = R * S
+    dev = g.device
+    g = g.contiguous().view(T, C)
+    rs_arr = (ctypes.c_uint32 * 4)(*rs)
+    # ---- feed-forward half
+    tiles = [lw1.contiguous(), ops.wt(lw2, p_2).contiguous(), ops.wt(lw1, p_1).contiguous()]      # W1, W2^T, W1^T
+    wpack_b = torch.empty(3 * 32768, dtype=torch.uint8, device=dev)
+    tp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tiles])
+    ld = (ctypes.c_int32 * 3)(*[t.stride(0) for t in tiles])
+    L.call("tg_encoder_pack_tiles", ctypes.addressof(tp), ctypes.addressof(ld), 3, L.ptr(wpack_b), L.stream())
+    d_x1, d_y2, h, d_hpre, x1 = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(5))
+    ops._launch("tg_encoder_bwd_ffn_bf16", L.ptr(g), L.ptr(z1), L.ptr(z2), L.ptr(d_x1), L.ptr(d_y2), L.ptr(h), L.ptr(d_hpre),
+                L.ptr(x1), L.ptr(wpack_b), L.ptr(prm), R, S, int(tail), float(beta_c), 1e-5, float(p), int(seed),
+                ctypes.addressof(rs_arr), L.stream(), nbytes=2 * T * C * 8)
+    STATS["fused_bwd"] += 1
+    gg2, gb2, ggt, gbt = ctx.ln_params[1][0], ctx.ln_params[1][1], ctx.ln_params[2][0], ctx.ln_params[2][1]
+    if tail:
+        dg2, dbe2, dgt, dbt = _ln_grads(0, g, z2, g2, be2, gt, beta_c, (gg2, gb2, ggt, gbt))
+    else:
+        dg2, dbe2 = _ln_grads(0, g, z2, g2, be2, None, beta_c, (gg2, gb2))
+        dgt = dbt = None
+    dw2, db2 = ops.weight_grad(d_y2, h, True, p_2, pb_2)
+    if db2 is None and dw2 is not None:
+        db2 = d_y2.sum(0, dtype=torch.float32)
+    del d_y2, h
+    dw1, db1 = ops.weight_grad(d_hpre, x1, True, p_1, pb_1)
+    if db1 is None and dw1 is not None:
+        db1 = d_hpre.sum(0, dtype=torch.float32)
+    del d_hpre, x1
+    # ---- attention half: the op-by-op kernels on recomputed qkv / o (until the chained kernel for it lands)
+    qkv = ops.gemm_nt(x2d, lw_in, b_in.detach())
+    o = torch.empty(T, C, dtype=g.dtype, device=dev)
+    lse = torch.empty(R, H, S, dtype=torch.float32, device=dev)
+    L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, H, p, seed, rs[0], L.dt(qkv), L.stream())
+    _, st1 = _ln_fwd(z1, None, None, g1, be1, None, 0.0, 1.0, 0.0, 0, 0)
+    tg1 = ops.ln_grad_targets(*ctx.ln_params[0])
+    acc_dx = tail and alpha != 0.0
+    d_x = g * alpha if acc_dx else torch.empty_like(g)
+    d_y, dp1 = _ln_bwd(z1, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
+    del d_x1
+    dwo, _ = ops.weight_grad(d_y, o, False, p_o)
+    d_o = ops.gemm_nt(d_y, ops.wt(lw_o, p_o))
+    del d_y
+    d_qkv = torch.empty_like(qkv)
+    L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
+           L.dt(qkv), L.stream())
+    del d_o
+    dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
+    if dbin is None and dwin is not None:
+        dbin = d_qkv.sum(0, dtype=torch.float32)
+    ops.gemm_nt(d_qkv, ops.wt(lw_in, p_in), None, ops.NT_ACCUM, out=d_x)
+    return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, db2,
+            dp1[0], dp1[1], dg2, dbe2, dgt, dbt, None)
 
 
 def encoder_layer(x, layer, p, tail_norm=None, alpha=0.0, beta_c=1.0):

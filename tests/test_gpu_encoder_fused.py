@@ -95,3 +95,81 @@ def test_fused_forward_full_size_rows_are_independent():
     assert torch.isfinite(big.float()).all()
     # (not bit-equal: a row's position inside its wave tile changes the order of the softmax / LayerNorm partial sums)
     assert (big[idx].float() - small.float()).abs().max().item() <= 0.04
+
+
+def _grads(layer, tail, x, p, use_tail, alpha, beta_c, co, seed=99):
+    """d(sum(out * co)) wrt x and every parameter through the package's layer (current switches)."""
+    import tabgnn_amd.encoder_layer as EL
+    from tabgnn_amd import ops
+    for q in list(layer.parameters()) + list(tail.parameters()):
+        q.grad = None
+    xx = x.clone().requires_grad_(True)
+    ops.DropoutRNG.new_step(seed)
+    out = EL.encoder_layer(xx, layer, p, tail if use_tail else None, alpha, beta_c)
+    (out.float() * co).sum().backward()
+    names = [n for n, _ in layer.named_parameters()] + ["tail." + n for n, _ in tail.named_parameters()]
+    params = list(layer.parameters()) + list(tail.parameters())
+    gr = {"x": xx.grad.float()}
+    for n, q in zip(names, params):
+        gr[n] = None if q.grad is None else q.grad.float().clone()
+    return out.detach().float(), gr
+
+
+def _relerr(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("p", [0.0, 0.5])
+@pytest.mark.parametrize("S,H,R,use_tail,alpha,beta_c", [(6, 4, 4001, True, 0.5, 0.5), (6, 8, 700, True, 0.0, 1.0),
+                                                         (8, 4, 257, False, 0.0, 1.0), (3, 4, 1000, True, 1.0, 0.5)])
+def test_fused_training_gradients_match_op_by_op_kernels(S, H, R, use_tail, alpha, beta_c, p):
+    """Fused forward + chained backward kernels against the op-by-op kernels of the same package on the same dropout
+    streams: output, input gradient and every parameter gradient in relative Frobenius norm (bf16 rounding points
+    differ between the two paths; a wrong mask or a wrong term would show as O(1))."""
+    import tabgnn_amd.encoder_layer as EL
+    layer, tail = _layer(H, seed=11)
+    layer.to(DEV); tail.to(DEV)
+    x = (torch.randn(R, S, 128, device=DEV) * 1.2).to(torch.bfloat16)
+    co = torch.randn(R, S, 128, device=DEV)
+    n0 = dict(EL.STATS)
+    EL._FUSED_TRAIN = True
+    out_f, g_f = _grads(layer, tail, x, p, use_tail, alpha, beta_c, co)
+    assert EL.STATS["fused_fwd"] == n0["fused_fwd"] + 1 and EL.STATS["fused_bwd"] == n0["fused_bwd"] + 1
+    EL._FUSED_TRAIN = False
+    try:
+        out_u, g_u = _grads(layer, tail, x, p, use_tail, alpha, beta_c, co)
+    finally:
+        EL._FUSED_TRAIN = True
+    assert _relerr(out_f, out_u) <= 0.01
+    worst = []
+    for k in g_u:
+        if g_u[k] is None or (not use_tail and k.startswith("tail.")):
+            continue
+        assert g_f[k] is not None, k
+        worst.append((_relerr(g_f[k], g_u[k]), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 0.03, worst[:4]
+
+
+def test_fused_training_gradients_match_torch_fp32_autograd():
+    """p = 0: against torch.nn.TransformerEncoderLayer + LayerNorm tail in fp32 autograd (the module the reference builds)."""
+    S, H, R = 6, 4, 2000
+    layer, tail = _layer(H, seed=5)
+    x = (torch.randn(R, S, 128) * 1.2).to(torch.bfloat16)
+    co = torch.randn(R, S, 128)
+    ref = torch.nn.TransformerEncoderLayer(128, H, 128, 0.0, "relu", batch_first=True)
+    ref.load_state_dict(layer.state_dict())
+    rt = torch.nn.LayerNorm(128)
+    rt.load_state_dict(tail.state_dict())
+    xr = x.float().requires_grad_(True)
+    y = 0.5 * xr + 0.5 * rt(ref(xr))
+    (y * co).sum().backward()
+    want = {"x": xr.grad}
+    want.update({n: q.grad for n, q in ref.named_parameters()})
+    want.update({"tail." + n: q.grad for n, q in rt.named_parameters()})
+    layer.to(DEV); tail.to(DEV)
+    out, got = _grads(layer, tail, x.to(DEV), 0.0, True, 0.5, 0.5, co.to(DEV))
+    assert (out.cpu() - y.detach()).abs().max().item() <= BF16_TOL
+    worst = sorted(((_relerr(got[k].cpu(), want[k]), k) for k in want), reverse=True)
+    print("fused layer vs fp32 autograd, worst:", worst[:4])
+    assert worst[0][0] <= 0.05, worst[:4]
