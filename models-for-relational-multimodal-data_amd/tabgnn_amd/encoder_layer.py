@@ -112,7 +112,7 @@ class _EncoderLayerFn(torch.autograd.Function):
                                     bt if tail else None)
             out, z1, z2 = fused_forward(x, nhead, p, tail, alpha, beta_c, wpack, prm, seed, rs, True)
             STATS["fused_fwd"] += 1
-            ctx.save_for_backward(x2d, z1, z2, prm, lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, g2, be2, gt)
+            ctx.save_for_backward(x2d, z1.view(T, C), z2.view(T, C), prm, lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, g2, be2, gt)
             ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
             ctx.fused = True
             isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None

@@ -148,7 +148,9 @@ def test_fused_training_gradients_match_op_by_op_kernels(S, H, R, use_tail, alph
         assert g_f[k] is not None, k
         worst.append((_relerr(g_f[k], g_u[k]), k))
     worst.sort(reverse=True)
-    assert worst[0][0] <= 0.03, worst[:4]
+    # linear1's gradients carry the ReLU gate: hidden units within bf16 rounding of zero flip between the two paths
+    # (both are 3-4 % from the fp32 gradient there, ~1 % elsewhere: tools/dbg_grad.py)
+    assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
 
 
 def test_fused_training_gradients_match_torch_fp32_autograd():
@@ -172,4 +174,4 @@ def test_fused_training_gradients_match_torch_fp32_autograd():
     assert (out.cpu() - y.detach()).abs().max().item() <= BF16_TOL
     worst = sorted(((_relerr(got[k].cpu(), want[k]), k) for k in want), reverse=True)
     print("fused layer vs fp32 autograd, worst:", worst[:4])
-    assert worst[0][0] <= 0.05, worst[:4]
+    assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
