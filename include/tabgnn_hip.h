@@ -245,6 +245,14 @@ int tg_encoder_pack_tiles(const void* const* tiles /*host [n]*/, const int32_t* 
 int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void* z2, void* dx1, void* dy2, void* hout, void* dhpre,
                             void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S, int32_t tail,
                             float beta_c, float eps, float p_drop, uint64_t seed, const uint32_t* rs, void* stream);
+/* backward of the fused layer, attention half (4 heads): d_x1 -> LayerNorm-1 backward -> output projection backward
+ * -> attention backward with q / k / v / probabilities recomputed from x.  Writes dx (partial: tg_gemm_nt_bf16 then adds
+ * d_qkv W_in), and the operands of the weight-gradient GEMMs: dy, o [R,S,128] and dqkv [R,S,384]. */
+int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const void* x, const void* g /*d out; NULL if alpha == 0*/,
+                             void* dx, void* dy, void* o, void* dqkv, const void* w_in /*[384,128]*/,
+                             const void* w_o_t /*Wo^T [128, ld_ot]*/, int32_t ld_ot, void* wpack /*4 x 32 KiB*/,
+                             const float* prm, int64_t R, int32_t S, int32_t H, float alpha, float eps, float p_drop,
+                             uint64_t seed, const uint32_t* rs, void* stream);
 /* LayerNorm weight / bias gradients of the fused layer (sums over tokens; a streaming pass of its own):
  * mode 0: dy = d out, z = z2 -> out = (d gamma2, d beta2, d gamma_t, d beta_t);  mode 1: dy = d_x1, z = z1 -> (d gamma1,
  * d beta1).  out[i] fp32 [128] or NULL; accumulate = 1: += . */

@@ -794,6 +794,356 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- backward, attention half
+// From d_x1 (gradient wrt x1, written by the feed-forward half) back to the layer input, everything recomputed from
+// (x, z1) in registers, per wave tile of 32 tokens:
+//     LayerNorm-1 backward -> d_z1 ;  d_y = mask1 . d_z1 ;  d_x(partial) = d_z1 (+ alpha * g)
+//     per head: recompute K, Q, V (BOTH MFMA orientations: a product that contracts over tokens needs its operand with
+//     tokens on the accumulator rows), S^T -> P^T (softmax, same statistics as the forward), O^T (written: dWo operand);
+//     d_o = d_y Wo (both orientations);  dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dV^T = dO^T-contracted with P ;
+//     dQ^T = K-contracted with dS^T ; dK^T = Q-contracted with dS  — every one of them one or two 32x32x16 MFMAs on
+//     packed accumulator tiles, no LDS round trip (a 32-entry per-query table in LDS carries max / 1/sum / delta to the
+//     orientation that has queries on rows).
+// Written: d_x (partial: the QKV projection's input gradient is accumulated into it by the next GEMM), d_y, o, d_qkv
+// (operands of the weight-gradient GEMMs for Wo and W_in).  Head dim 32 (4 heads).
+// Stages: per 32-channel head block  Wq rows | Wk rows | Wv rows | Wo^T rows  (8 KiB each).
+struct EaArgs {
+  const unsigned short *dx1, *z1, *x, *g;
+  unsigned short *dx, *dy, *o, *dqkv;
+  const char* wpack;
+  const float* prm;
+  long long R;
+  int S;
+  float alpha, eps;
+  unsigned thresh;
+  float inv_keep;
+  unsigned long long seed;
+  unsigned rs0, rs1;
+};
+
+// a [32 token][32 channel] block held as two packed fragments -> memory (row stride ld elements), via the restage
+__device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* stg, unsigned short* dst, int ld, int lane,
+                                                 int tl, int h, int nvalid) {
+  asm volatile("" : "+v"(lane), "+v"(tl), "+v"(h));
+  const uint4 v0 = __builtin_bit_cast(uint4, f0), v1 = __builtin_bit_cast(uint4, f1);
+  // fragment s: channels 16s + 4h + 0..3 (.xy), 16s + 8 + 4h + 0..3 (.zw) -> 16-byte chunks 2s, 2s+1 of the 64-byte row
+  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (0 ^ (tl & 3)) + 8 * h) = make_uint2(v0.x, v0.y);
+  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (1 ^ (tl & 3)) + 8 * h) = make_uint2(v0.z, v0.w);
+  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (2 ^ (tl & 3)) + 8 * h) = make_uint2(v1.x, v1.y);
+  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (3 ^ (tl & 3)) + 8 * h) = make_uint2(v1.z, v1.w);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int t = (lane >> 2) + 16 * p, c = lane & 3;
+    const uint4 v = *reinterpret_cast<const uint4*>(stg + 64 * t + 16 * (c ^ (t & 3)));
+    if (t < nvalid) *reinterpret_cast<uint4*>(dst + (unsigned)(t * ld + 8 * c)) = v;
+  }
+}
+
+template <bool DROP>
+__global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wbuf0 = smem;
+  char* wbuf1 = smem + EF_STAGE_BYTES;
+  float* prm = reinterpret_cast<float*>(smem + 2 * EF_STAGE_BYTES);
+  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl0 = lane & 31, h0 = lane >> 5;
+  char* stg = stg_all + wave * 8192;
+  float* tab = reinterpret_cast<float*>(stg + 4096);            // [3][32]: max, 1/sum, delta per query slot
+  constexpr int NH = 4;
+  const float scale = 0.17677669529663687f;
+  const int S = a.S;
+  const int RW = 32 / S;
+  const long long n_wt = (a.R + RW - 1) / RW;
+  const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
+  for (int i = tid; i < EF_P_FLOATS; i += 512) prm[i] = a.prm[i];
+  if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
+  __syncthreads();
+  const int q_row = tl0 / S;
+  const int row_lo = q_row * S;
+
+  int gstage = 0;
+  for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
+    int tl = tl0, h = h0;
+    asm volatile("" : "+v"(tl), "+v"(h));
+    const long long wt = it * EF_WAVES + wave;
+    const long long row0 = wt * RW;
+    long long rows_here = a.R - row0;
+    rows_here = rows_here < 0 ? 0 : (rows_here > RW ? RW : rows_here);
+    const int nvalid = (int)rows_here * S;
+    const long long tok0 = row0 * S;
+    const bool tok_ok = tl0 < nvalid;
+    const long long tglob = tok0 + tl0;
+    const unsigned long long e_base = (unsigned long long)tglob * EF_C;
+    const unsigned xoff = (unsigned)((tok_ok ? tl0 : 0) * EF_C + 4 * h0);
+
+    // ---- LayerNorm-1 backward: d_z1 -> d_x (partial) and d_y
+    ef_v8bf dyf[8], xf[8];
+    {
+      ef_v8bf zf[8];
+      EB_LOAD(dyf, a.dx1)
+      EB_LOAD(zf, a.z1)
+      float mu, rstd, s1, s2;
+      ef_row_stats(zf, a.eps, mu, rstd);
+      ef_ln_bwd_sums(dyf, zf, 1.f, mu, rstd, prm + EF_P_G1, h, s1, s2);
+      const bool with_g = a.alpha != 0.f;
+      if (with_g) { EB_LOAD(xf, a.g) }
+      const unsigned dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        __builtin_amdgcn_sched_barrier(0);
+        ef_f32x8 dz = ef_ln_bwd_apply(dyf[f], zf[f], 1.f, mu, rstd, s1, s2, prm + EF_P_G1 + 16 * f + 4 * h);
+        ef_f32x8 dxp = dz;
+        if (with_g) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dxp[j] += a.alpha * (float)xf[f][j];
+        }
+        zf[f] = __builtin_convertvector(dxp, ef_v8bf);
+        if constexpr (DROP) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            dz[j] *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 * (j >> 2) + 4 * h + (j & 3)), a.thresh, a.inv_keep);
+        }
+        dyf[f] = __builtin_convertvector(dz, ef_v8bf);
+      }
+      ef_store_rows(zf, stg, a.dx + tok0 * EF_C, lane, tl, h, nvalid);
+      ef_store_rows(dyf, stg, a.dy + tok0 * EF_C, lane, tl, h, nvalid);
+    }
+    EB_LOAD(xf, a.x)
+
+#pragma unroll 1
+    for (int blk = 0; blk < 4; ++blk) {
+      asm volatile("" : "+v"(tl), "+v"(h));
+      char* wb = ((gstage + blk) & 1) ? wbuf1 : wbuf0;
+      char* wn = ((gstage + blk) & 1) ? wbuf0 : wbuf1;
+      if (blk < 3) ef_stage_dma(a.wpack + (size_t)(blk + 1) * EF_STAGE_BYTES, wn, tid);
+      else if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wn, tid);
+      const int fo = ef_off(tl, h);                 // chunk (2ks + h) = ef_off(tl, 2ks + h): computed per use below
+      (void)fo;
+#define EA_CHAIN_STD(ACC, WOFF, BOP)                                                                  \
+      ACC = ef_zero16();                                                                              \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
+        ACC = EF_MFMA(ef_frag(wb + (WOFF), ef_off(tl, 2 * ks + h)), BOP[ks], ACC);                    \
+        if (ks == 3) __builtin_amdgcn_sched_barrier(0);                                               \
+      }
+#define EA_CHAIN_TR(ACC, WOFF, AOP)                                                                   \
+      ACC = ef_zero16();                                                                              \
+      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
+        ACC = EF_MFMA(AOP[ks], ef_frag(wb + (WOFF), ef_off(tl, 2 * ks + h)), ACC);                    \
+        if (ks == 3) __builtin_amdgcn_sched_barrier(0);                                               \
+      }
+#define EA_ROWBIAS(ACC, POFF)                                                                         \
+      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+        const float4 b = *reinterpret_cast<const float4*>(prm + (POFF) + 8 * g + 4 * h);              \
+        ACC[4 * g] += b.x; ACC[4 * g + 1] += b.y; ACC[4 * g + 2] += b.z; ACC[4 * g + 3] += b.w;       \
+      }
+      ef_f32x16 acc;
+      // 1. K^T, Q^T [32 d (rows), 32 tokens]
+      EA_CHAIN_STD(acc, 8192, xf)
+      EA_ROWBIAS(acc, EF_P_BIN + 128 + 32 * blk)
+      const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+      EA_CHAIN_STD(acc, 0, xf)
+      EA_ROWBIAS(acc, EF_P_BIN + 32 * blk)
+      const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+
+      // dropout geometry of this (table row, head)
+      const unsigned long long blk0 = ((unsigned long long)(row0 + q_row) * NH + blk) * (unsigned long long)(S * S);
+      const unsigned key0 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32));
+      const unsigned key1 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32) + 1u);
+
+      // 2. S^T[key, q] and the softmax down the keys of the query's table row: P^T (fp32)
+      ef_f32x16 pt = ef_zero16();
+      pt = EF_MFMA(kf0, qf0, pt);
+      pt = EF_MFMA(kf1, qf1, pt);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+        pt[i] *= scale;
+        mx = (key >= row_lo && key < row_lo + S) ? fmaxf(mx, pt[i]) : mx;
+      }
+      mx = fmaxf(mx, ef_xor32(mx));
+      float l = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+        pt[i] = (key >= row_lo && key < row_lo + S) ? __expf(pt[i] - mx) : 0.f;
+        l += pt[i];
+      }
+      l += ef_xor32(l);
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pt[i] *= inv;
+      tab[tl] = mx;
+      tab[32 + tl] = inv;
+
+      // 3. V [tokens (rows), d]; O^T = V^T Pd^T, written (operand of dWo)
+      EA_CHAIN_TR(acc, 16384, xf)
+      {
+        const float bv = prm[EF_P_BIN + 256 + 32 * blk + tl];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += bv;
+      }
+      {
+        const ef_v8bf vt0 = ef_pack<0>(acc), vt1 = ef_pack<1>(acc);
+        ef_f32x16 pd = pt;
+        if constexpr (DROP) {
+          const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const unsigned lo = lo0 + (unsigned)(key - row_lo);
+            pd[i] *= drop_scale_key(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
+          }
+        }
+        const ef_v8bf pd0 = ef_pack<0>(pd), pd1 = ef_pack<1>(pd);
+        ef_f32x16 ot = ef_zero16();
+        ot = EF_MFMA(vt0, pd0, ot);
+        ot = EF_MFMA(vt1, pd1, ot);
+        ef_store_block32(ef_pack<0>(ot), ef_pack<1>(ot), stg, a.o + tok0 * EF_C + 32 * blk, EF_C, lane, tl, h, nvalid);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // 4. dO^T [d, q] = Wo^T rows . d_y ; V^T [d, key] ; dPd^T = V dO^T ; dS^T
+      EA_CHAIN_STD(acc, 24576, dyf)
+      const ef_v8bf dof0 = ef_pack<0>(acc), dof1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+      EA_CHAIN_STD(acc, 16384, xf)
+      EA_ROWBIAS(acc, EF_P_BIN + 256 + 32 * blk)
+      const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+      ef_v8bf dstf0, dstf1;
+      {
+        ef_f32x16 dp = ef_zero16();
+        dp = EF_MFMA(vf0, dof0, dp);
+        dp = EF_MFMA(vf1, dof1, dp);
+        if constexpr (DROP) {
+          const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const unsigned lo = lo0 + (unsigned)(key - row_lo);
+            dp[i] *= drop_scale_key(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
+          }
+        }
+        float delta = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) delta += pt[i] * dp[i];
+        delta += ef_xor32(delta);
+        tab[64 + tl] = delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dp[i] = pt[i] * (dp[i] - delta);
+        dstf0 = ef_pack<0>(dp); dstf1 = ef_pack<1>(dp);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // 5. dO [q (rows), d] ; P, Pd with queries on rows ; dV^T [d, key]
+      EA_CHAIN_TR(acc, 24576, dyf)
+      const ef_v8bf dotf0 = ef_pack<0>(acc), dotf1 = ef_pack<1>(acc);
+      __builtin_amdgcn_sched_barrier(0);
+      ef_f32x16 p2 = ef_zero16();
+      p2 = EF_MFMA(qf0, kf0, p2);
+      p2 = EF_MFMA(qf1, kf1, p2);
+      ef_f32x16 m2;                                   // dropout factor of (query row i, key tl)
+      float dl2[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 mx4 = *reinterpret_cast<const float4*>(tab + 8 * g + 4 * h);
+        const float4 iv4 = *reinterpret_cast<const float4*>(tab + 32 + 8 * g + 4 * h);
+        const float4 dl4 = *reinterpret_cast<const float4*>(tab + 64 + 8 * g + 4 * h);
+        const float mxs[4] = {mx4.x, mx4.y, mx4.z, mx4.w}, ivs[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
+        const float dls[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * g + j;
+          const int q = 8 * g + 4 * h + j;
+          const bool okq = q >= row_lo && q < row_lo + S;
+          p2[i] = okq ? __expf(p2[i] * scale - mxs[j]) * ivs[j] : 0.f;
+          dl2[i] = dls[j];
+          if constexpr (DROP) {
+            const unsigned lo = (unsigned)blk0 + (unsigned)((q - row_lo) * S + (tl - row_lo));
+            m2[i] = drop_scale_key(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
+          } else {
+            m2[i] = 1.f;
+          }
+        }
+      }
+      ef_v8bf dvf0, dvf1;
+      {
+        ef_f32x16 pd2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pd2[i] = p2[i] * m2[i];
+        const ef_v8bf pd20 = ef_pack<0>(pd2), pd21 = ef_pack<1>(pd2);
+        ef_f32x16 dv = ef_zero16();
+        dv = EF_MFMA(dotf0, pd20, dv);
+        dv = EF_MFMA(dotf1, pd21, dv);
+        dvf0 = ef_pack<0>(dv); dvf1 = ef_pack<1>(dv);
+      }
+      ef_store_block32(dvf0, dvf1, stg, a.dqkv + tok0 * (3 * EF_C) + 256 + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
+      __builtin_amdgcn_sched_barrier(0);
+
+      // 6. K [key (rows), d] ; dQ^T [d, q] = K-contracted with dS^T
+      EA_CHAIN_TR(acc, 8192, xf)
+      {
+        const float bk = prm[EF_P_BIN + 128 + 32 * blk + tl];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += bk;
+      }
+      {
+        const ef_v8bf kt0 = ef_pack<0>(acc), kt1 = ef_pack<1>(acc);
+        ef_f32x16 dq = ef_zero16();
+        dq = EF_MFMA(kt0, dstf0, dq);
+        dq = EF_MFMA(kt1, dstf1, dq);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[i] *= scale;
+        ef_store_block32(ef_pack<0>(dq), ef_pack<1>(dq), stg, a.dqkv + tok0 * (3 * EF_C) + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // 7. Q [q (rows), d] ; dPd, dS with queries on rows ; dK^T [d, key] = Q-contracted with dS
+      EA_CHAIN_TR(acc, 0, xf)
+      {
+        const float bq = prm[EF_P_BIN + 32 * blk + tl];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += bq;
+      }
+      {
+        const ef_v8bf qt0 = ef_pack<0>(acc), qt1 = ef_pack<1>(acc);
+        ef_f32x16 ds = ef_zero16();
+        ds = EF_MFMA(dof0, vf0, ds);                  // dPd[q, key] = sum_d dO^T[d, q] V^T[d, key]
+        ds = EF_MFMA(dof1, vf1, ds);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ds[i] = p2[i] * (ds[i] * m2[i] - dl2[i]);
+        const ef_v8bf ds0 = ef_pack<0>(ds), ds1 = ef_pack<1>(ds);
+        ef_f32x16 dk = ef_zero16();
+        dk = EF_MFMA(qt0, ds0, dk);
+        dk = EF_MFMA(qt1, ds1, dk);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dk[i] *= scale;
+        ef_store_block32(ef_pack<0>(dk), ef_pack<1>(dk), stg, a.dqkv + tok0 * (3 * EF_C) + 128 + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
+      }
+      __syncthreads();          // stage consumed; next one landed
+    }
+    gstage += 4;
+  }
+}
+
+// wpack stage blk (0..3) = Wq rows | Wk rows | Wv rows | Wo^T rows (32 rows each, rows 32 blk ..), k-permuted images
+__global__ void __launch_bounds__(256) k_encoder_pack_attn_bwd(const unsigned short* __restrict__ w_in,
+                                                                const unsigned short* __restrict__ w_o_t, int ld_ot,
+                                                                char* __restrict__ wpack) {
+  const int stage = blockIdx.x;
+  char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
+  for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
+    const int row = p >> 4, c = p & 15, part = row >> 5, r = row & 31;
+    const unsigned short* wrow = part < 3 ? w_in + (size_t)(128 * part + 32 * stage + r) * EF_C
+                                          : w_o_t + (size_t)(32 * stage + r) * ld_ot;
+    *reinterpret_cast<uint4*>(dst + 8192 * part + ef_off(r, c)) = ef_perm_chunk(wrow, c >> 1, c & 1);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- LayerNorm parameter gradients
 // The chained kernels keep a token on a lane, so sums over TOKENS (the LayerNorm weight / bias gradients) are taken by
 // this streaming pass instead: 16 lanes per token row (8 channels each), per-thread column accumulators, per-block
@@ -1069,6 +1419,41 @@ extern "C" int tg_encoder_ln_grads(int32_t mode, const void* dy, const void* z, 
   if (mode == 0) hipLaunchKernelGGL(k_encoder_ln_grads<0>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
   else hipLaunchKernelGGL(k_encoder_ln_grads<1>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
   hipLaunchKernelGGL(k_ef_reduce, dim3(4), dim3(128), 0, st, partials, grid, o, accumulate);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Attention half of the layer backward (see k_encoder_bwd_attn; 4 heads).  wpack (4 x 32 KiB) is built here from W_in
+// [384,128] and Wo^T [128,128] (row stride ld_ot).  d_x1 from tg_encoder_bwd_ffn_bf16; g = d out (read when alpha != 0).
+// Writes dx (partial: add d_qkv W_in to it), dy, o ([R,S,128]) and dqkv ([R,S,384]).
+extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const void* x, const void* g, void* dx, void* dy,
+                                        void* o, void* dqkv, const void* w_in, const void* w_o_t, int32_t ld_ot,
+                                        void* wpack, const float* prm, int64_t R, int32_t S, int32_t H, float alpha,
+                                        float eps, float p_drop, uint64_t seed, const uint32_t* rs, void* stream) {
+  TG_CHECK(S >= 1 && S <= 32 && H == 4, "tg_encoder_bwd_attn_bf16: unsupported geometry S=%d H=%d (4 heads only)", S, H);
+  TG_CHECK(dx1 && z1 && x && dx && dy && o && dqkv && w_in && w_o_t && wpack && prm && rs && (g || alpha == 0.f),
+           "tg_encoder_bwd_attn_bf16: null operand");
+  if (R <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_encoder_pack_attn_bwd, dim3(4), dim3(256), 0, st, (const unsigned short*)w_in,
+                     (const unsigned short*)w_o_t, ld_ot, (char*)wpack);
+  EaArgs a;
+  a.dx1 = (const unsigned short*)dx1; a.z1 = (const unsigned short*)z1; a.x = (const unsigned short*)x;
+  a.g = (const unsigned short*)g; a.dx = (unsigned short*)dx; a.dy = (unsigned short*)dy; a.o = (unsigned short*)o;
+  a.dqkv = (unsigned short*)dqkv; a.wpack = (const char*)wpack; a.prm = prm; a.R = R; a.S = S; a.alpha = alpha; a.eps = eps;
+  a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1];
+  const size_t lds = ef_lds_bytes();
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  const unsigned grid = ef_grid(R, S);
+  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_attn<true>), dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((k_encoder_bwd_attn<false>), dim3(grid), dim3(512), lds, st, a);
   TG_LAUNCH_CHECK();
   return 0;
 }

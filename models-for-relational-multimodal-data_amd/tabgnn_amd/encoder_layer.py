@@ -24,9 +24,10 @@ from . import ops
 _FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B switch
 _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B switch: the one-kernel layer (encoder_fused.hip)
 _FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
+_FUSED_ATTN_BWD = os.environ.get("TABGNN_NO_FUSED_ATTN_BWD") != "1"     # ... its attention-half backward kernel
 
 
-STATS = {"fused_fwd": 0, "fused_bwd": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
+STATS = {"fused_fwd": 0, "fused_bwd": 0, "fused_bwd_attn": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
 
 
 def fused_ok(x, nhead, w1):
@@ -116,7 +117,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
             ctx.fused = True
             isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
-            ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2))
+            ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2), isp(b_o))
             ctx.ln_params = ((g1, be1, b_o), (g2, be2, b2), (gt, bt, None))
             return out.view(R, S, C)
         ctx.fused = False
@@ -283,7 +284,7 @@ def _fused_backward(ctx, g):
     kernel (tg_encoder_bwd_ffn_bf16) + the two weight-gradient GEMMs + the LayerNorm-parameter pass."""
     (x2d, z1, z2, prm, lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, g2, be2, gt) = ctx.saved_tensors
     R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
-    p_in, pb_in, p_o, p_1, pb_1, p_2, pb_2 = ctx.params
+    p_in, pb_in, p_o, p_1, pb_1, p_2, pb_2 = ctx.params[:7]
     T = R * S
     dev = g.device
     g = g.contiguous().view(T, C)
@@ -313,30 +314,54 @@ def _fused_backward(ctx, g):
     if db1 is None and dw1 is not None:
         db1 = d_hpre.sum(0, dtype=torch.float32)
     del d_hpre, x1
-    # ---- attention half: the op-by-op kernels on recomputed qkv / o (until the chained kernel for it lands)
-    qkv = ops.gemm_nt(x2d, lw_in, b_in.detach())
-    o = torch.empty(T, C, dtype=g.dtype, device=dev)
-    lse = torch.empty(R, H, S, dtype=torch.float32, device=dev)
-    L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, H, p, seed, rs[0], L.dt(qkv), L.stream())
-    _, st1 = _ln_fwd(z1, None, None, g1, be1, None, 0.0, 1.0, 0.0, 0, 0)
-    tg1 = ops.ln_grad_targets(*ctx.ln_params[0])
-    acc_dx = tail and alpha != 0.0
-    d_x = g * alpha if acc_dx else torch.empty_like(g)
-    d_y, dp1 = _ln_bwd(z1, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
-    del d_x1
-    dwo, _ = ops.weight_grad(d_y, o, False, p_o)
-    d_o = ops.gemm_nt(d_y, ops.wt(lw_o, p_o))
-    del d_y
-    d_qkv = torch.empty_like(qkv)
-    L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
-           L.dt(qkv), L.stream())
-    del d_o
+    # ---- attention half
+    p_bo = ctx.params[7]
+    if H == 4 and _FUSED_ATTN_BWD:
+        # one chained kernel: LayerNorm-1 backward, output-projection backward, attention backward on recomputed q/k/v/P
+        wo_t = ops.wt(lw_o, p_o)
+        if not wo_t.is_contiguous():
+            wo_t = wo_t.contiguous()
+        wpack_a = torch.empty(4 * 32768, dtype=torch.uint8, device=dev)
+        d_x, d_y, o = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(3))
+        d_qkv = torch.empty(T, 3 * C, dtype=g.dtype, device=dev)
+        with_g = tail and alpha != 0.0
+        ops._launch("tg_encoder_bwd_attn_bf16", L.ptr(d_x1), L.ptr(z1), L.ptr(x2d), L.ptr(g) if with_g else None, L.ptr(d_x),
+                    L.ptr(d_y), L.ptr(o), L.ptr(d_qkv), L.ptr(lw_in.contiguous()), L.ptr(wo_t), wo_t.stride(0),
+                    L.ptr(wpack_a), L.ptr(prm), R, S, H, float(alpha) if with_g else 0.0, 1e-5, float(p), int(seed),
+                    ctypes.addressof(rs_arr), L.stream(), nbytes=2 * T * C * (9 + int(with_g)))
+        STATS["fused_bwd_attn"] += 1
+        dg1, dbe1 = _ln_grads(1, d_x1, z1, None, None, None, 1.0, (ctx.ln_params[0][0], ctx.ln_params[0][1]))
+        del d_x1
+        dwo, dbo = ops.weight_grad(d_y, o, True, p_o, p_bo)
+        if dbo is None and dwo is not None:
+            dbo = d_y.sum(0, dtype=torch.float32)
+        del d_y, o
+    else:
+        # the op-by-op kernels on recomputed qkv / o (8 heads)
+        qkv = ops.gemm_nt(x2d, lw_in, b_in.detach())
+        o = torch.empty(T, C, dtype=g.dtype, device=dev)
+        lse = torch.empty(R, H, S, dtype=torch.float32, device=dev)
+        L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, H, p, seed, rs[0], L.dt(qkv), L.stream())
+        _, st1 = _ln_fwd(z1, None, None, g1, be1, None, 0.0, 1.0, 0.0, 0, 0)
+        tg1 = ops.ln_grad_targets(*ctx.ln_params[0])
+        acc_dx = tail and alpha != 0.0
+        d_x = g * alpha if acc_dx else torch.empty_like(g)
+        d_y, dp1 = _ln_bwd(z1, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
+        dg1, dbe1, dbo = dp1[0], dp1[1], dp1[2]
+        del d_x1
+        dwo, _ = ops.weight_grad(d_y, o, False, p_o)
+        d_o = ops.gemm_nt(d_y, ops.wt(lw_o, p_o))
+        del d_y
+        d_qkv = torch.empty_like(qkv)
+        L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
+               L.dt(qkv), L.stream())
+        del d_o, qkv, o
     dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
     if dbin is None and dwin is not None:
         dbin = d_qkv.sum(0, dtype=torch.float32)
     ops.gemm_nt(d_qkv, ops.wt(lw_in, p_in), None, ops.NT_ACCUM, out=d_x)
-    return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, db2,
-            dp1[0], dp1[1], dg2, dbe2, dgt, dbt, None)
+    return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dbo, dw1, db1, dw2, db2,
+            dg1, dbe1, dg2, dbe2, dgt, dbt, None)
 
 
 def encoder_layer(x, layer, p, tail_norm=None, alpha=0.0, beta_c=1.0):
