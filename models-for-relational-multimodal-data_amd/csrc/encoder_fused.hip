@@ -37,7 +37,18 @@ typedef float ef_f32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int EF_C = 128;
 constexpr int EF_STAGE_BYTES = 32768;
-constexpr int EF_WAVES = 8;                  // waves per workgroup
+#ifndef EF_WAVES_N
+#define EF_WAVES_N 4
+#endif
+#ifndef EF_DBUF
+#define EF_DBUF 0
+#endif
+// Geometry: EF_WAVES_N waves per workgroup.  4 waves + ONE 32 KiB weight buffer (70 KiB of LDS) lets two workgroups share
+// a CU: their barriers, stage DMAs and input loads overlap each other (measured against 8 waves + two buffers, one
+// workgroup per CU, whose waves all stall together).  EF_DBUF = 1: double-buffered stages (needs EF_WAVES_N = 8 to pay).
+constexpr int EF_WAVES = EF_WAVES_N;         // waves per workgroup
+constexpr int EF_THREADS = 64 * EF_WAVES;
+constexpr int EF_NBUF = EF_DBUF ? 2 : 1;
 constexpr int EF_NSTAGE = 7;              // 4 head blocks (Wq|Wk|Wv rows), Wo, W1, W2
 // fp32 parameter block (floats): b_in[384] | b_o | g1 | be1 | b1 | b2 | g2 | be2 | gt | bt  (128 each)
 enum { EF_P_BIN = 0, EF_P_BO = 384, EF_P_G1 = 512, EF_P_BE1 = 640, EF_P_B1 = 768, EF_P_B2 = 896, EF_P_G2 = 1024,
@@ -70,10 +81,10 @@ __global__ void __launch_bounds__(256) k_encoder_pack(const unsigned short* __re
                                                        const float* __restrict__ g2, const float* __restrict__ be2,
                                                        const float* __restrict__ gt, const float* __restrict__ bt,
                                                        char* __restrict__ wpack, float* __restrict__ prm) {
-  const int stage = blockIdx.x;                // 0..6
+  const int stage = blockIdx.x;                // 0..6: four head blocks, Wo, W1, W2 -> two 16 KiB units each
   char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
   if (stage < 4) {
-    // rows 0..95: (Wq | Wk | Wv) rows 32*stage + r; 16 chunks each (the last 8 KiB of the stage are unused)
+    // unit 2*stage: Wq rows | Wk rows (8 KiB each); unit 2*stage + 1: Wv rows (+ 8 KiB unused)
     for (int p = threadIdx.x; p < 96 * 16; p += blockDim.x) {
       const int row = p >> 4, c = p & 15, part = row >> 5, r = row & 31;
       const unsigned short* wrow = w_in + (size_t)(128 * part + 32 * stage + r) * EF_C;
@@ -81,6 +92,7 @@ __global__ void __launch_bounds__(256) k_encoder_pack(const unsigned short* __re
     }
     for (int p = threadIdx.x; p < 512; p += blockDim.x) *reinterpret_cast<uint4*>(dst + 24576 + 16 * p) = make_uint4(0u, 0u, 0u, 0u);
   } else {
+    // rows 0..63 -> first unit, 64..127 -> second (ef_off of a row is 256 * row + a swizzle of its low bits)
     const unsigned short* w = stage == 4 ? w_o : stage == 5 ? w1 : w2;
     for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
       const int row = p >> 4, c = p & 15;
@@ -120,24 +132,79 @@ __device__ __forceinline__ ef_f32x16 ef_zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+#ifndef EF_ABL
+#define EF_ABL 0
+#endif
+// (A/B switches for tools/encoder_ablate.sh; 0 = the shipped kernel)
+#define EF_FENCE() do { if (!(EF_ABL & 64)) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define EF_MID_FENCE() do { if (!(EF_ABL & 1)) EF_FENCE(); } while (0)
 #define EF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
 
-// LDS-DMA of one 32 KiB stage by the 512 threads of the workgroup: 4 pieces of 16 bytes per thread, linear image.
+// LDS-DMA of one 32 KiB stage by the workgroup: 2048 / EF_THREADS pieces of 16 bytes per thread, linear image.
 __device__ __forceinline__ void ef_stage_dma(const char* __restrict__ src, char* lds_dst, int tid) {
   asm volatile("" : "+v"(tid));      // opaque: the per-lane source addresses are formed here, not hoisted out of the
-                                     // persistent loop as 28 64-bit register pairs (which then spill)
+                                     // persistent loop as 64-bit register pairs (which then spill)
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int piece = p * 512 + (tid & ~63);          // wave-uniform first piece of this wave-instruction
+  for (int p = 0; p < 2048 / EF_THREADS; ++p) {
+    const int piece = p * EF_THREADS + (tid & ~63);          // wave-uniform first piece of this wave-instruction
     // wave-uniform 64-bit base + 32-bit lane offset: the saddr form, no per-lane 64-bit address registers
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + (unsigned)((p * 512 + tid) * 16)),
+        (const __attribute__((address_space(1))) void*)(src + (unsigned)((p * EF_THREADS + tid) * 16)),
         (__attribute__((address_space(3))) void*)(lds_dst + piece * 16), 16, 0, 0);
   }
 }
+// Stage pipeline.  Double-buffered: stage g sits in buffer g & 1, the next stage's DMA is issued on entry, one barrier
+// on leaving.  Single-buffered: barrier (buffer free) -> DMA -> barrier (landed); nothing on leaving.
+#if EF_DBUF
+#define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
+  char* wb = (gstage & 1) ? wbuf1 : wbuf0;                                                            \
+  if (NEXT_VALID) ef_stage_dma(a.wpack + (size_t)(NEXT) * EF_STAGE_BYTES, (gstage & 1) ? wbuf0 : wbuf1, tid);
+#define EF_STAGE_LEAVE() __syncthreads(); gstage += 1;
+#define EF_PIPE_PROLOGUE() if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid); __syncthreads();
+#else
+#define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
+  if (!(EF_ABL & 32)) {                                                                               \
+    __syncthreads();                                                                                  \
+    ef_stage_dma(a.wpack + (size_t)(CUR) * EF_STAGE_BYTES, wbuf0, tid);                               \
+    __syncthreads();                                                                                  \
+  }                                                                                                   \
+  char* wb = wbuf0;
+#define EF_STAGE_LEAVE()
+#define EF_PIPE_PROLOGUE() __syncthreads();
+#endif
+
+// Unit pipeline (forward and feed-forward-half backward): the weights stream through TWO 16 KiB buffers in units of
+// half a stage (64 rows of a 128 x 128 tile; Wq|Wk rows or Wv rows of a head block).  Invariant: unit u sits in buffer
+// gu & 1 and the DMA of unit u+1 is in flight into the other one.  EF_UNIT_NEXT at the end of unit u: barrier (every
+// wave done with u, every wave's pieces of u+1 landed), then the DMA of u+2 goes into u's buffer at once, so it has the
+// whole of unit u+1 to land.  One barrier per unit, no exposed DMA wait.
+constexpr int EF_UNIT_BYTES = 16384;
+__device__ __forceinline__ void ef_unit_dma(const char* __restrict__ src, char* lds_dst, int tid) {
+  asm volatile("" : "+v"(tid));
+#pragma unroll
+  for (int p = 0; p < 1024 / EF_THREADS; ++p) {
+    const int piece = p * EF_THREADS + (tid & ~63);
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + (unsigned)((p * EF_THREADS + tid) * 16)),
+        (__attribute__((address_space(3))) void*)(lds_dst + piece * 16), 16, 0, 0);
+  }
+}
+#define EF_UNIT_CUR() (smem + (gu & 1) * EF_UNIT_BYTES)
+#define EF_UNIT_NEXT(VALID, U2)                                                                       \
+  {                                                                                                   \
+    if (!(EF_ABL & 128)) __syncthreads();                                                             \
+    gu += 1;                                                                                          \
+    if (!(EF_ABL & 32) && (VALID)) ef_unit_dma(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, smem + ((gu + 1) & 1) * EF_UNIT_BYTES, tid); \
+  }
+#define EF_UNIT_PROLOGUE(NU)                                                                          \
+  int gu = 0;                                                                                         \
+  if (blockIdx.x < n_it) ef_unit_dma(a.wpack, smem, tid);                                             \
+  __syncthreads();                                                                                    \
+  if (blockIdx.x < n_it) ef_unit_dma(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, tid);
 
 // mean / rstd of a token's 128 channels held as 8 packed fragments (this lane's 64 + the xor-32 partner's 64)
 __device__ __forceinline__ void ef_row_stats(const ef_v8bf (&zp)[8], float eps, float& mu, float& rstd) {
+  if (EF_ABL & 4) { mu = (float)zp[0][0]; rstd = 1.f + eps; return; }
   float sum = 0.f;
 #pragma unroll
   for (int f = 0; f < 8; ++f)
@@ -203,7 +270,7 @@ __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], char* stg,
     for (int p = 0; p < 4; ++p) {
       const int t = (lane >> 3) + 8 * p, c = lane & 7;
       const uint4 v = *reinterpret_cast<const uint4*>(stg + 128 * t + 16 * (c ^ (t & 7)));
-      if (t < nvalid) *reinterpret_cast<uint4*>(dst + (unsigned)(t * EF_C + 64 * half + 8 * c)) = v;
+      if ((EF_ABL & 2) ? (t < nvalid - 1000) : (t < nvalid)) *reinterpret_cast<uint4*>(dst + (unsigned)(t * EF_C + 64 * half + 8 * c)) = v;
     }
   }
 }
@@ -227,12 +294,12 @@ struct EfArgs {
 
 // Forward.  HD = head dim (16 or 32).  One workgroup = 8 waves = 8 wave tiles of 32 token slots per iteration.
 template <int HD, bool DROP>
-__global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
+__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf0 = smem;
-  char* wbuf1 = smem + EF_STAGE_BYTES;
-  float* prm = reinterpret_cast<float*>(smem + 2 * EF_STAGE_BYTES);                  // 6 KiB
-  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;                       // 8 x 8 KiB
+  char* wbuf1 = smem + (EF_NBUF - 1) * EF_STAGE_BYTES;
+  float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);                  // 6 KiB
+  char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;                       // 8 x 8 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl0 = lane & 31, h0 = lane >> 5;
   char* stg = stg_all + wave * 8192;          // wave-private: output restage (4 KiB) / parked x1 fragments (8 KiB)
@@ -244,16 +311,13 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
   const long long n_wt = (a.R + RW - 1) / RW;   // wave tiles
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
 
-  for (int i = tid; i < EF_P_FLOATS; i += 512) prm[i] = a.prm[i];
-  // stage pipeline: global stage counter g = it_local * 6 + s; buffer = g & 1
-  if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
-  __syncthreads();
+  for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
+  EF_UNIT_PROLOGUE(14)
 
   // softmax geometry of this lane: query slot tl, its table row's token range [row_lo, row_lo + S)
   const int q_row = tl0 / S;
   const int row_lo = q_row * S;
 
-  int gstage = 0;              // running stage counter: stage g lives in buffer g & 1 (7 stages per iteration)
   for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
     int tl = tl0, h = h0;
     asm volatile("" : "+v"(tl), "+v"(h));     // opaque per iteration: see EF_OPAQUE below
@@ -286,17 +350,14 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = ((gstage + blk) & 1) ? wbuf1 : wbuf0;
-      char* wn = ((gstage + blk) & 1) ? wbuf0 : wbuf1;
-      // next stage (blk+1: head block, or Wo) -> other buffer
-      ef_stage_dma(a.wpack + (size_t)(blk + 1) * EF_STAGE_BYTES, wn, tid);
+      char* wb = EF_UNIT_CUR();                     // unit 2 blk: Wq rows | Wk rows
 
       // K^T and Q^T blocks [32 d, 32 tokens]
       ef_f32x16 acc = ef_zero16();
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         acc = EF_MFMA(ef_frag(wb + 8192, ef_off(tl, 2 * ks + h)), xf[ks], acc);
-        if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        if (ks == 3) EF_MID_FENCE();
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -304,12 +365,12 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         acc[4 * g] += b.x; acc[4 * g + 1] += b.y; acc[4 * g + 2] += b.z; acc[4 * g + 3] += b.w;
       }
       const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
       acc = ef_zero16();
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         acc = EF_MFMA(ef_frag(wb, ef_off(tl, 2 * ks + h)), xf[ks], acc);
-        if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        if (ks == 3) EF_MID_FENCE();
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -317,13 +378,14 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         acc[4 * g] += b.x; acc[4 * g + 1] += b.y; acc[4 * g + 2] += b.z; acc[4 * g + 3] += b.w;
       }
       const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_UNIT_NEXT(true, 2 * blk + 2)
+      wb = EF_UNIT_CUR();                           // unit 2 blk + 1: Wv rows
       // V block in the transposed orientation [32 tokens (rows), 32 d (columns)]
       acc = ef_zero16();
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        acc = EF_MFMA(xf[ks], ef_frag(wb + 16384, ef_off(tl, 2 * ks + h)), acc);
-        if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+        acc = EF_MFMA(xf[ks], ef_frag(wb, ef_off(tl, 2 * ks + h)), acc);
+        if (ks == 3) EF_MID_FENCE();
       }
       {
         const float bv = prm[EF_P_BIN + 256 + 32 * blk + tl];
@@ -331,7 +393,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         for (int i = 0; i < 16; ++i) acc[i] += bv;
       }
       const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_UNIT_NEXT(true, 2 * blk + 3)               // (units 8, 9: Wo)
 
 #pragma unroll
       for (int hh = 0; hh < HB; ++hh) {
@@ -346,6 +408,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         // softmax over the keys of the query's own table row
         float mx = -INFINITY;
         bool ok[16];
+        if (!(EF_ABL & 8)) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -379,6 +442,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) st[i] *= inv;
         }
+        }
         const ef_v8bf pf0 = ef_pack<0>(st), pf1 = ef_pack<1>(st);
         // O^T[d (rows), query (columns)] = V^T P^T
         ef_f32x16 ot = ef_zero16();
@@ -390,9 +454,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
           if (hh == 0) of[2 * blk] = ef_pack<0>(ot); else of[2 * blk + 1] = ef_pack<1>(ot);
         }
       }
-      __syncthreads();          // stage blk consumed by every wave; the DMA of stage blk+1 has landed (vmcnt(0) + barrier)
     }
-    gstage += 4;
 
     // ================================================================ output projection + LayerNorm 1 (registers)
     // z1 = x + drop(o Wo^T + b_o), rounded to bf16 (what is stored and what the backward recomputes from);
@@ -401,19 +463,18 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
     const unsigned long long e_base = (unsigned long long)tglob * EF_C;
     ef_v8bf x1f[8];
     {
-      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
-      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
-      ef_stage_dma(a.wpack + (size_t)5 * EF_STAGE_BYTES, wn, tid);          // W1
       ef_v8bf zp[8];
       const unsigned dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        char* wu = EF_UNIT_CUR();
         ef_f32x16 acc = ef_zero16();
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), of[ks], acc);
-          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+          acc = EF_MFMA(ef_frag(wu, ef_off(32 * (m & 1) + tl, 2 * ks + h)), of[ks], acc);
+          if (ks == 3) EF_MID_FENCE();
         }
+        if (m & 1) EF_UNIT_NEXT(true, 10 + (m >> 1))      // Wo unit done -> W1 units
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BO + 32 * m + 8 * g + 4 * h);
@@ -428,39 +489,36 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         }
         zp[2 * m] = ef_pack<0>(acc);
         zp[2 * m + 1] = ef_pack<1>(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
       }
       if (a.z1) ef_store_rows(zp, stg, a.z1 + tok0 * EF_C, lane, tl, h, nvalid);
       float mu, rstd;
       ef_row_stats(zp, a.eps, mu, rstd);
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
         x1f[f] = ef_ln_apply(zp[f], mu, rstd, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
         // parked in LDS (lane-linear, read back by the same lane) for the residual of the second sub-layer: 32
         // registers less across the feed-forward
         *reinterpret_cast<uint4*>(stg + 1024 * f + 16 * lane) = __builtin_bit_cast(uint4, x1f[f]);
       }
-      __syncthreads();          // Wo consumed; W1 landed
-      gstage += 1;
     }
 
     // ================================================================ feed-forward 1: h = drop(relu(W1 x1 + b1))
     ef_v8bf hf[8];
     {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
-      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
-      ef_stage_dma(a.wpack + (size_t)6 * EF_STAGE_BYTES, wn, tid);          // W2
       const unsigned dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        char* wu = EF_UNIT_CUR();
         ef_f32x16 acc = ef_zero16();
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), x1f[ks], acc);
-          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+          acc = EF_MFMA(ef_frag(wu, ef_off(32 * (m & 1) + tl, 2 * ks + h)), x1f[ks], acc);
+          if (ks == 3) EF_MID_FENCE();
         }
+        if (m & 1) EF_UNIT_NEXT(true, 12 + (m >> 1))      // W1 unit done -> W2 units
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
@@ -474,29 +532,26 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         }
         hf[2 * m] = ef_pack<0>(acc);
         hf[2 * m + 1] = ef_pack<1>(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
       }
-      __syncthreads();          // W1 consumed; W2 landed
-      gstage += 1;
     }
 
     // ================================================================ feed-forward 2 + LayerNorm 2 (+ tail LayerNorm)
     {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
-      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
-      // stage 0 of the next iteration -> other buffer while W2 is used
-      if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wn, tid);
+      const bool has_next = it + gridDim.x < n_it;
       ef_v8bf zp[8];
       const unsigned dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        char* wu = EF_UNIT_CUR();
         ef_f32x16 acc = ef_zero16();
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), hf[ks], acc);
-          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+          acc = EF_MFMA(ef_frag(wu, ef_off(32 * (m & 1) + tl, 2 * ks + h)), hf[ks], acc);
+          if (ks == 3) EF_MID_FENCE();
         }
+        if (m & 1) EF_UNIT_NEXT(has_next, m >> 1)         // W2 unit done -> the next iteration's first units
         const ef_v8bf r0 = __builtin_bit_cast(ef_v8bf, *reinterpret_cast<const uint4*>(stg + 1024 * (2 * m) + 16 * lane));
         const ef_v8bf r1 = __builtin_bit_cast(ef_v8bf, *reinterpret_cast<const uint4*>(stg + 1024 * (2 * m + 1) + 16 * lane));
 #pragma unroll
@@ -513,7 +568,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         }
         zp[2 * m] = ef_pack<0>(acc);
         zp[2 * m + 1] = ef_pack<1>(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
       }
       if (a.z2) ef_store_rows(zp, stg, a.z2 + tok0 * EF_C, lane, tl, h, nvalid);
       float mu, rstd;
@@ -521,7 +576,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
       // x2 = LN2(z2), rounded to bf16 as the unfused path stores it
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
         zp[f] = ef_ln_apply(zp[f], mu, rstd, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
       }
       if (a.tail) {
@@ -529,14 +584,12 @@ __global__ void __launch_bounds__(512, 1) k_encoder_fwd(const EfArgs a) {
         if (a.alpha != 0.f) { EF_LOAD_X() }       // x again for the combine (L2-hot): its registers were free in between
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
-          __builtin_amdgcn_sched_barrier(0);
+          EF_FENCE();
           zp[f] = ef_ln_combine(zp[f], xf[f], mu, rstd, prm + EF_P_GT + 16 * f + 4 * h, prm + EF_P_BT + 16 * f + 4 * h,
                                 a.alpha, a.beta_c);
         }
       }
       ef_store_rows(zp, stg, a.out + tok0 * EF_C, lane, tl, h, nvalid);
-      __syncthreads();          // W2 consumed; next iteration's stage 0 landed
-      gstage += 1;
     }
   }
 }
@@ -603,12 +656,12 @@ __device__ __forceinline__ ef_f32x8 ef_ln_bwd_apply(ef_v8bf d, ef_v8bf zz, float
 }
 
 template <bool DROP>
-__global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
+__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf0 = smem;
-  char* wbuf1 = smem + EF_STAGE_BYTES;
-  float* prm = reinterpret_cast<float*>(smem + 2 * EF_STAGE_BYTES);
-  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;
+  char* wbuf1 = smem + (EF_NBUF - 1) * EF_STAGE_BYTES;
+  float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);
+  char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl0 = lane & 31, h0 = lane >> 5;
   char* stg = stg_all + wave * 8192;
@@ -616,9 +669,8 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
   const int RW = 32 / S;
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
-  for (int i = tid; i < EF_P_FLOATS; i += 512) prm[i] = a.prm[i];
-  if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
-  __syncthreads();
+  for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
+  EF_PIPE_PROLOGUE()
 
   int gstage = 0;
   for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
@@ -657,7 +709,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
       ef_v8bf x2f[8];
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
         x2f[f] = ef_ln_apply(zf[f], mu2, rstd2, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
       }
       float mut, rstdt, s1, s2;
@@ -665,7 +717,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
       ef_ln_bwd_sums(gf, x2f, a.beta_c, mut, rstdt, prm + EF_P_GT, h, s1, s2);
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
         gf[f] = __builtin_convertvector(ef_ln_bwd_apply(gf[f], x2f[f], a.beta_c, mut, rstdt, s1, s2, prm + EF_P_GT + 16 * f + 4 * h), ef_v8bf);
       }
     }
@@ -676,7 +728,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
       const unsigned dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
         ef_f32x8 dz = ef_ln_bwd_apply(gf[f], zf[f], 1.f, mu2, rstd2, s1, s2, prm + EF_P_G2 + 16 * f + 4 * h);
         dzf[f] = __builtin_convertvector(dz, ef_v8bf);
         if constexpr (DROP) {
@@ -699,7 +751,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
       ef_row_stats(zf, a.eps, mu1, rstd1);
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
         x1f[f] = ef_ln_apply(zf[f], mu1, rstd1, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
       }
       ef_store_rows(x1f, stg, a.x1out + tok0 * EF_C, lane, tl, h, nvalid);
@@ -709,9 +761,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
     ef_v8bf hf[8];
     {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
-      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
-      ef_stage_dma(a.wpack + (size_t)1 * EF_STAGE_BYTES, wn, tid);          // W2^T
+      EF_STAGE_ENTER(0, true, 1)                    // W1 (next: W2^T)
       const unsigned dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -719,7 +769,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), x1f[ks], acc);
-          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+          if (ks == 3) EF_MID_FENCE();
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -734,19 +784,16 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
         }
         hf[2 * m] = ef_pack<0>(acc);
         hf[2 * m + 1] = ef_pack<1>(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
       }
       ef_store_rows(hf, stg, a.hout + tok0 * EF_C, lane, tl, h, nvalid);
-      __syncthreads();
-      gstage += 1;
+      EF_STAGE_LEAVE()
     }
 
     // ---- stage W2^T: d_h = d_y2 W2, gated by the recomputed h: d_hpre (G operand of dW1, and db1)
     {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
-      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
-      ef_stage_dma(a.wpack + (size_t)2 * EF_STAGE_BYTES, wn, tid);          // W1^T
+      EF_STAGE_ENTER(1, true, 2)                    // W2^T (next: W1^T)
       const float keep = DROP ? a.inv_keep : 1.f;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
@@ -754,42 +801,38 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_ffn(const EbArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), gf[ks], acc);
-          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+          if (ks == 3) EF_MID_FENCE();
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = ef_bf(hf[2 * m + (i >> 3)], i & 7) > 0.f ? acc[i] * keep : 0.f;
         hf[2 * m] = ef_pack<0>(acc);            // hf now holds d_hpre for the blocks done
         hf[2 * m + 1] = ef_pack<1>(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
       }
       ef_store_rows(hf, stg, a.dhpre + tok0 * EF_C, lane, tl, h, nvalid);
-      __syncthreads();
-      gstage += 1;
+      EF_STAGE_LEAVE()
     }
 
     // ---- stage W1^T: d_x1 = d_z2 + d_hpre W1
     {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = (gstage & 1) ? wbuf1 : wbuf0;
-      char* wn = (gstage & 1) ? wbuf0 : wbuf1;
-      if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wn, tid);            // next iteration's W1
+      EF_STAGE_ENTER(2, it + gridDim.x < n_it, 0)   // W1^T (next: the next iteration's W1)
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
         ef_f32x16 acc = ef_zero16();
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
           acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), hf[ks], acc);
-          if (ks == 3) __builtin_amdgcn_sched_barrier(0);
+          if (ks == 3) EF_MID_FENCE();
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] += ef_bf(dzf[2 * m + (i >> 3)], i & 7);
         dzf[2 * m] = ef_pack<0>(acc);
         dzf[2 * m + 1] = ef_pack<1>(acc);
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
       }
       ef_store_rows(dzf, stg, a.dx1 + tok0 * EF_C, lane, tl, h, nvalid);
-      __syncthreads();
-      gstage += 1;
+      EF_STAGE_LEAVE()
     }
   }
 }
@@ -840,12 +883,12 @@ __device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* s
 }
 
 template <bool DROP>
-__global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
+__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf0 = smem;
-  char* wbuf1 = smem + EF_STAGE_BYTES;
-  float* prm = reinterpret_cast<float*>(smem + 2 * EF_STAGE_BYTES);
-  char* stg_all = smem + 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4;
+  char* wbuf1 = smem + (EF_NBUF - 1) * EF_STAGE_BYTES;
+  float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);
+  char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl0 = lane & 31, h0 = lane >> 5;
   char* stg = stg_all + wave * 8192;
@@ -856,9 +899,8 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
   const int RW = 32 / S;
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
-  for (int i = tid; i < EF_P_FLOATS; i += 512) prm[i] = a.prm[i];
-  if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid);
-  __syncthreads();
+  for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
+  EF_PIPE_PROLOGUE()
   const int q_row = tl0 / S;
   const int row_lo = q_row * S;
 
@@ -891,7 +933,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
       const unsigned dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
-        __builtin_amdgcn_sched_barrier(0);
+        EF_FENCE();
         ef_f32x8 dz = ef_ln_bwd_apply(dyf[f], zf[f], 1.f, mu, rstd, s1, s2, prm + EF_P_G1 + 16 * f + 4 * h);
         ef_f32x8 dxp = dz;
         if (with_g) {
@@ -914,23 +956,20 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
       asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = ((gstage + blk) & 1) ? wbuf1 : wbuf0;
-      char* wn = ((gstage + blk) & 1) ? wbuf0 : wbuf1;
-      if (blk < 3) ef_stage_dma(a.wpack + (size_t)(blk + 1) * EF_STAGE_BYTES, wn, tid);
-      else if (it + gridDim.x < n_it) ef_stage_dma(a.wpack, wn, tid);
+      EF_STAGE_ENTER(blk, blk < 3 || it + gridDim.x < n_it, (blk + 1) & 3)
       const int fo = ef_off(tl, h);                 // chunk (2ks + h) = ef_off(tl, 2ks + h): computed per use below
       (void)fo;
 #define EA_CHAIN_STD(ACC, WOFF, BOP)                                                                  \
       ACC = ef_zero16();                                                                              \
       _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
         ACC = EF_MFMA(ef_frag(wb + (WOFF), ef_off(tl, 2 * ks + h)), BOP[ks], ACC);                    \
-        if (ks == 3) __builtin_amdgcn_sched_barrier(0);                                               \
+        if (ks == 3) EF_MID_FENCE();                                               \
       }
 #define EA_CHAIN_TR(ACC, WOFF, AOP)                                                                   \
       ACC = ef_zero16();                                                                              \
       _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
         ACC = EF_MFMA(AOP[ks], ef_frag(wb + (WOFF), ef_off(tl, 2 * ks + h)), ACC);                    \
-        if (ks == 3) __builtin_amdgcn_sched_barrier(0);                                               \
+        if (ks == 3) EF_MID_FENCE();                                               \
       }
 #define EA_ROWBIAS(ACC, POFF)                                                                         \
       _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
@@ -942,11 +981,11 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
       EA_CHAIN_STD(acc, 8192, xf)
       EA_ROWBIAS(acc, EF_P_BIN + 128 + 32 * blk)
       const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
       EA_CHAIN_STD(acc, 0, xf)
       EA_ROWBIAS(acc, EF_P_BIN + 32 * blk)
       const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
 
       // dropout geometry of this (table row, head)
       const unsigned long long blk0 = ((unsigned long long)(row0 + q_row) * NH + blk) * (unsigned long long)(S * S);
@@ -1004,16 +1043,16 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
         ot = EF_MFMA(vt1, pd1, ot);
         ef_store_block32(ef_pack<0>(ot), ef_pack<1>(ot), stg, a.o + tok0 * EF_C + 32 * blk, EF_C, lane, tl, h, nvalid);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
 
       // 4. dO^T [d, q] = Wo^T rows . d_y ; V^T [d, key] ; dPd^T = V dO^T ; dS^T
       EA_CHAIN_STD(acc, 24576, dyf)
       const ef_v8bf dof0 = ef_pack<0>(acc), dof1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
       EA_CHAIN_STD(acc, 16384, xf)
       EA_ROWBIAS(acc, EF_P_BIN + 256 + 32 * blk)
       const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
       ef_v8bf dstf0, dstf1;
       {
         ef_f32x16 dp = ef_zero16();
@@ -1037,12 +1076,12 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
         for (int i = 0; i < 16; ++i) dp[i] = pt[i] * (dp[i] - delta);
         dstf0 = ef_pack<0>(dp); dstf1 = ef_pack<1>(dp);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
 
       // 5. dO [q (rows), d] ; P, Pd with queries on rows ; dV^T [d, key]
       EA_CHAIN_TR(acc, 24576, dyf)
       const ef_v8bf dotf0 = ef_pack<0>(acc), dotf1 = ef_pack<1>(acc);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
       ef_f32x16 p2 = ef_zero16();
       p2 = EF_MFMA(qf0, kf0, p2);
       p2 = EF_MFMA(qf1, kf1, p2);
@@ -1082,7 +1121,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
         dvf0 = ef_pack<0>(dv); dvf1 = ef_pack<1>(dv);
       }
       ef_store_block32(dvf0, dvf1, stg, a.dqkv + tok0 * (3 * EF_C) + 256 + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
 
       // 6. K [key (rows), d] ; dQ^T [d, q] = K-contracted with dS^T
       EA_CHAIN_TR(acc, 8192, xf)
@@ -1100,7 +1139,7 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
         for (int i = 0; i < 16; ++i) dq[i] *= scale;
         ef_store_block32(ef_pack<0>(dq), ef_pack<1>(dq), stg, a.dqkv + tok0 * (3 * EF_C) + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      EF_FENCE();
 
       // 7. Q [q (rows), d] ; dPd, dS with queries on rows ; dK^T [d, key] = Q-contracted with dS
       EA_CHAIN_TR(acc, 0, xf)
@@ -1124,9 +1163,8 @@ __global__ void __launch_bounds__(512, 1) k_encoder_bwd_attn(const EaArgs a) {
         for (int i = 0; i < 16; ++i) dk[i] *= scale;
         ef_store_block32(ef_pack<0>(dk), ef_pack<1>(dk), stg, a.dqkv + tok0 * (3 * EF_C) + 128 + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
       }
-      __syncthreads();          // stage consumed; next one landed
+      EF_STAGE_LEAVE()
     }
-    gstage += 4;
   }
 }
 
@@ -1235,12 +1273,20 @@ __global__ void __launch_bounds__(EG_BLOCK) k_encoder_ln_grads(const EgArgs a) {
   }
 }
 struct EgOut { float* dst[4]; };
-__global__ void __launch_bounds__(128) k_ef_reduce(const float* __restrict__ partials, int nblk, const EgOut o, int accumulate) {
-  const int v = blockIdx.x, c = threadIdx.x;
-  if (!o.dst[v]) return;
+__global__ void __launch_bounds__(1024) k_ef_reduce(const float* __restrict__ partials, int nblk, const EgOut o, int accumulate) {
+  __shared__ float red[8][128];
+  const int v = blockIdx.x, c = threadIdx.x & 127, grp = threadIdx.x >> 7;
   float t = 0.f;
-  for (int b = 0; b < nblk; ++b) t += partials[(size_t)b * 512 + v * 128 + c];
-  o.dst[v][c] = accumulate ? o.dst[v][c] + t : t;
+  if (o.dst[v])
+    for (int b = grp; b < nblk; b += 8) t += partials[(size_t)b * 512 + v * 128 + c];     // fixed order: deterministic
+  red[grp][c] = t;
+  __syncthreads();
+  if (grp == 0 && o.dst[v]) {
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r += red[k][c];
+    o.dst[v][c] = accumulate ? o.dst[v][c] + r : r;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- generic tile pack
@@ -1317,8 +1363,9 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  const unsigned grid = (unsigned)(n_it < n_cu ? n_it : n_cu);
-  const size_t lds = 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
+  const long long slots = (long long)n_cu * (EF_DBUF ? 1 : 2);
+  const unsigned grid = (unsigned)(n_it < slots ? n_it : slots);
+  const size_t lds = EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1328,10 +1375,10 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
     attr_done = true;
   }
   const bool drop = a.thresh != 0u;
-  if (H == 4 && drop) hipLaunchKernelGGL((k_encoder_fwd<32, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-  else if (H == 4) hipLaunchKernelGGL((k_encoder_fwd<32, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-  else if (drop) hipLaunchKernelGGL((k_encoder_fwd<16, true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_encoder_fwd<16, false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  if (H == 4 && drop) hipLaunchKernelGGL((k_encoder_fwd<32, true>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
+  else if (H == 4) hipLaunchKernelGGL((k_encoder_fwd<32, false>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
+  else if (drop) hipLaunchKernelGGL((k_encoder_fwd<16, true>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_encoder_fwd<16, false>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -1351,7 +1398,7 @@ extern "C" int tg_encoder_pack_tiles(const void* const* tiles, const int32_t* ld
   return 0;
 }
 
-static size_t ef_lds_bytes() { return 2 * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192; }
+static size_t ef_lds_bytes() { return EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192; }
 static unsigned ef_grid(long long R, int S) {
   const int RW = 32 / S;
   const long long n_wt = (R + RW - 1) / RW, n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
@@ -1362,7 +1409,8 @@ static unsigned ef_grid(long long R, int S) {
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  return (unsigned)(n_it < n_cu ? n_it : n_cu);
+  const long long slots = (long long)n_cu * (EF_DBUF ? 1 : 2);
+  return (unsigned)(n_it < slots ? n_it : slots);
 }
 
 // Feed-forward half of the layer backward (see k_encoder_bwd_ffn).  g = d out [R,S,128]; z1, z2 from the forward;
@@ -1391,8 +1439,8 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
     attr_done = true;
   }
   const unsigned grid = ef_grid(R, S);
-  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_ffn<true>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_encoder_bwd_ffn<false>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_ffn<true>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((k_encoder_bwd_ffn<false>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -1418,7 +1466,7 @@ extern "C" int tg_encoder_ln_grads(int32_t mode, const void* dy, const void* z, 
   const int grid = grid_cap(ceil_div(T, 16 * 8), EG_MAXBLK);
   if (mode == 0) hipLaunchKernelGGL(k_encoder_ln_grads<0>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
   else hipLaunchKernelGGL(k_encoder_ln_grads<1>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
-  hipLaunchKernelGGL(k_ef_reduce, dim3(4), dim3(128), 0, st, partials, grid, o, accumulate);
+  hipLaunchKernelGGL(k_ef_reduce, dim3(4), dim3(1024), 0, st, partials, grid, o, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -1452,8 +1500,8 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
     attr_done = true;
   }
   const unsigned grid = ef_grid(R, S);
-  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_attn<true>), dim3(grid), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((k_encoder_bwd_attn<false>), dim3(grid), dim3(512), lds, st, a);
+  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_attn<true>), dim3(grid), dim3(EF_THREADS), lds, st, a);
+  else hipLaunchKernelGGL((k_encoder_bwd_attn<false>), dim3(grid), dim3(EF_THREADS), lds, st, a);
   TG_LAUNCH_CHECK();
   return 0;
 }

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtabgnn_hip.so")
+LIB_PATH = os.environ.get("TABGNN_LIB_PATH") or os.path.join(_HERE, "libtabgnn_hip.so")     # (override: kernel A/B builds)
 ABI_VERSION = 2
 
 _vp, _i32, _i64, _f32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
