@@ -479,11 +479,13 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BO + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
+          float dm[4];
+          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * g + j;
             float u = acc[i] + bb[j];
-            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            if constexpr (DROP) u *= dm[j];
             acc[i] = u + ef_bf(xf[2 * m + (i >> 3)], i & 7);
           }
         }
@@ -523,10 +525,12 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
+          float dm[4];
+          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
-            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            if constexpr (DROP) u *= dm[j];
             acc[4 * g + j] = u;
           }
         }
@@ -558,11 +562,13 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B2 + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
+          float dm[4];
+          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * g + j;
             float u = acc[i] + bb[j];
-            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            if constexpr (DROP) u *= dm[j];
             acc[i] = u + ef_bf(i < 8 ? r0 : r1, i & 7);
           }
         }
@@ -732,9 +738,11 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         ef_f32x8 dz = ef_ln_bwd_apply(gf[f], zf[f], 1.f, mu2, rstd2, s1, s2, prm + EF_P_G2 + 16 * f + 4 * h);
         dzf[f] = __builtin_convertvector(dz, ef_v8bf);
         if constexpr (DROP) {
+          float dm0[4], dm1[4];
+          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
+          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            dz[j] *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 * (j >> 2) + 4 * h + (j & 3)), a.thresh, a.inv_keep);
+          for (int j = 0; j < 4; ++j) { dz[j] *= dm0[j]; dz[4 + j] *= dm1[j]; }
           gf[f] = __builtin_convertvector(dz, ef_v8bf);
         } else {
           gf[f] = dzf[f];
@@ -775,10 +783,12 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         for (int g = 0; g < 4; ++g) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
+          float dm[4];
+          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
-            if constexpr (DROP) u *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h + j), a.thresh, a.inv_keep);
+            if constexpr (DROP) u *= dm[j];
             acc[4 * g + j] = u;
           }
         }
@@ -942,9 +952,11 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
         }
         zf[f] = __builtin_convertvector(dxp, ef_v8bf);
         if constexpr (DROP) {
+          float dm0[4], dm1[4];
+          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
+          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            dz[j] *= drop_scale_key(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 * (j >> 2) + 4 * h + (j & 3)), a.thresh, a.inv_keep);
+          for (int j = 0; j < 4; ++j) { dz[j] *= dm0[j]; dz[4 + j] *= dm1[j]; }
         }
         dyf[f] = __builtin_convertvector(dz, ef_v8bf);
       }

@@ -266,8 +266,12 @@ def test_gnn_wrapper_routes_match_oracle(name):
 
 # relative Frobenius tolerance of bf16 gradients against the fp32 oracle: activations and GEMM operands are rounded to
 # 8 significant bits (2^-9 relative per rounding) along a chain of ~40 operators per direction, master weights /
-# accumulators / statistics are fp32.  Measured worst case over the 100 parameters at B=1024 is recorded in DESIGN.md.
-BF16_GRAD_REL_FRO = 0.06
+# accumulators / statistics are fp32.  Measured at B=1024 (tools/dbg_e2e_grad.py): median 0.02, worst 0.118 on the
+# first PNA layer's weights — every node enters that layer with the SAME embedding (node_attr == 1), so its BatchNorm
+# normalises a small variance and amplifies the rounding of the convolution output; the same kernels in fp32 are within
+# 1e-4 of the oracle at this size (next test), and the op-by-op and the fused encoder paths give the same figures.
+BF16_GRAD_REL_FRO = 0.15
+BF16_GRAD_REL_FRO_MEDIAN = 0.04
 BF16_LOGIT_ABS = 0.06
 
 
@@ -304,6 +308,7 @@ def test_bf16_train_step_every_gradient_against_fp32_oracle():
     assert (out.detach().float().cpu() - logits.detach()).abs().max().item() <= BF16_LOGIT_ABS
     assert abs(dl.item() - loss.item()) <= 2e-2 * abs(loss.item())
     worst = []
+    gscale = max(v.double().norm().item() for v in want.values())
     for k, p in model.named_parameters():
         g = p.grad.detach().float().cpu()
         assert p.grad.data_ptr() >= flat.grad.data_ptr() and p.grad.data_ptr() < flat.grad.data_ptr() + 4 * flat.grad.numel(), k
@@ -311,14 +316,16 @@ def test_bf16_train_step_every_gradient_against_fp32_oracle():
         den = ref.double().norm().item()
         err = (g.double() - ref.double()).norm().item()
         rel = err / max(den, 1e-12)
-        if den < 1e-7:                        # structurally zero gradients (e.g. padding rows) must stay ~zero
-            assert err <= 1e-6, (k, err)
+        if den < 1e-7:      # structurally zero gradients (padding rows; biases in front of a BatchNorm, whose mean
+            # subtraction cancels them exactly in exact arithmetic) must stay at rounding-noise level
+            assert err <= 1e-3 * gscale, (k, err, gscale)
             continue
         worst.append((rel, k))
     worst.sort(reverse=True)
     print("bf16 gradient rel. Frobenius error, worst 5:", [(round(r, 4), k) for r, k in worst[:5]])
     assert len(worst) >= 90
     assert worst[0][0] <= BF16_GRAD_REL_FRO, worst[:5]
+    assert worst[len(worst) // 2][0] <= BF16_GRAD_REL_FRO_MEDIAN, worst[len(worst) // 2]
     # 3-step trajectory: the oracle's Adam against FusedAdam on the flat buffer
     sd2 = {k: v.detach().cpu().clone() for k, v in T.TABGNNFusedS(cfg).state_dict().items()}
     for k in sd2:
@@ -330,6 +337,43 @@ def test_bf16_train_step_every_gradient_against_fp32_oracle():
     opt = T.FusedAdam(flat, lr=cfg["lr"])
     got = [T.train_step(model, flat, opt, dbatch, lw.to(DEV))[0].item() for _ in range(3)]
     np.testing.assert_allclose(got, traj, rtol=3e-2)
+
+
+def test_fp32_train_step_at_hub_size_every_gradient_within_1e3_of_oracle():
+    """The fp32 path of the same kernels at B=1024 (hub sources, multi-block reductions, the 55 k-edge CSR): logits within
+    1e-4, every parameter gradient within 1e-3 (relative Frobenius) of oracle/step.py — what pins the kernels' logic at
+    the size where the bf16 test above can only state a rounding tolerance."""
+    from oracle import step as ostep
+    B = 1024
+    T, cfg, model, batch = _setup(B, 128, 2, 4, dtype=torch.float32, seed=21)
+    model.train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    node_tf, ei, edge_tf, y = batch
+    nf = {k.value: v for k, v in node_tf.feat_dict.items()}
+    ef = {k.value: v for k, v in edge_tf.feat_dict.items()}
+    lw = torch.tensor(cfg["loss_weights"])
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    keys = ostep.trainable_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    logits = ostep.wrapper_forward(sd, cfg["nhead"], B, nf, ei, ef, training=True)
+    loss = ostep.weighted_ce(logits[:B], y.view(-1), lw)
+    loss.backward()
+    model.to(DEV)
+    flat = T.FlatParams(model)
+    flat.zero_grad()
+    out = model(node_tf.to(DEV), ei.to(DEV), edge_tf.to(DEV))
+    T.ops.weighted_cross_entropy(out[:B], y.to(DEV), lw.to(DEV)).backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), logits.detach().numpy(), rtol=1e-4, atol=1e-4)
+    gscale = max(sd[k].grad.double().norm().item() for k in keys if sd[k].grad is not None)
+    n = 0
+    for k, p in model.named_parameters():
+        ref = sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])
+        err = (p.grad.detach().cpu().double() - ref.double()).norm().item()
+        den = ref.double().norm().item()
+        assert err <= 1e-3 * den + 1e-6 * gscale, (k, err, den)
+        n += 1
+    assert n >= 90
 
 
 def test_load_state_dict_after_flatparams_refreshes_the_bf16_shadows():
@@ -345,7 +389,7 @@ def test_load_state_dict_after_flatparams_refreshes_the_bf16_shadows():
                  for k, v in model.state_dict().items()}
         model.load_state_dict(other)
         b = model(*dbatch)
-        fresh = T.TABGNNFusedS(cfg)
+        _, _, fresh, _ = _setup(64, 128, 1, 4, dtype=torch.bfloat16, seed=5)      # its own encoder modules
         fresh.load_state_dict({k: v.cpu() for k, v in other.items()})
         fresh.to(DEV).eval()
         T.FlatParams(fresh, shadow_dtype=torch.bfloat16)
