@@ -58,7 +58,7 @@ __device__ __forceinline__ v8bf frag_tr(const char* tile, int ks, int cb, int la
 // [R,2] (amp, att); the G pieces of blocks 1 and 2 are multiplied in registers on their way into LDS (re-rounded to
 // bf16, exactly what the materialised [g | amp*g | att*g] operand of the unfused path held).
 template <bool SCALED>
-__global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __restrict__ G,
+__global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16(const unsigned short* __restrict__ G,
                                                        const unsigned short* __restrict__ X,
                                                        float* __restrict__ partial, float* __restrict__ colsum_part,
                                                        long long R, int M, int N, long long ldg, long long ldx,
@@ -92,9 +92,14 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
   // staging map: piece = tid + 256*p -> row = piece >> 4 (0..63), chunk = piece & 15
+  // TWO staging register sets (A: rg/rx/sg, B: rh/ry/sh): the tile two steps ahead is already in flight while the tile
+  // one step ahead waits for its LDS slot, so every HBM read has two steps of MFMA work to land (one set left each
+  // read ~0.5 us of cover against a > 1 us loaded latency: the slab loop ran at 4.0 TB/s)
   uint4 rg0, rg1, rg2, rg3, rx0, rx1, rx2, rx3;
+  uint4 rh0, rh1, rh2, rh3, ry0, ry1, ry2, ry3;
   float sg0 = 1.f, sg1 = 1.f, sg2 = 1.f, sg3 = 1.f;
-#define TG_LOAD_PIECE(P, RG, RX)                                                                              \
+  float sh0 = 1.f, sh1 = 1.f, sh2 = 1.f, sh3 = 1.f;
+#define TG_LOAD_PIECE(P, RG, RX, SG)                                                                          \
   {                                                                                                           \
     int piece = tid + 256 * P, row = piece >> 4, ch = piece & 15;                                             \
     long long r = r0_ + row;                                                                                  \
@@ -106,7 +111,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
     uint4 vg_ = *reinterpret_cast<const uint4*>(G + rc_ * ldg + mc_);                                         \
     uint4 vx_ = *reinterpret_cast<const uint4*>(X + rc_ * ldx + nc_);                                         \
     if constexpr (SCALED) {                                                                                   \
-      if (gset > 0) sg##P = scales[2 * rc_ + gset - 1];   /* applied at store time: no wait on the loads here */ \
+      if (gset > 0) SG = scales[2 * rc_ + gset - 1];      /* applied at store time: no wait on the loads here */ \
     }                                                                                                         \
     bool okg_ = okr && m0 + ch * 8 < M, okx_ = okr && n0 + ch * 8 < N;                                        \
     RG = make_uint4(okg_ ? vg_.x : 0u, okg_ ? vg_.y : 0u, okg_ ? vg_.z : 0u, okg_ ? vg_.w : 0u);              \
@@ -115,13 +120,18 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
 #define load_tile(R0)                                                                                         \
   {                                                                                                           \
     long long r0_ = (R0);                                                                                     \
-    TG_LOAD_PIECE(0, rg0, rx0) TG_LOAD_PIECE(1, rg1, rx1) TG_LOAD_PIECE(2, rg2, rx2) TG_LOAD_PIECE(3, rg3, rx3) \
+    TG_LOAD_PIECE(0, rg0, rx0, sg0) TG_LOAD_PIECE(1, rg1, rx1, sg1) TG_LOAD_PIECE(2, rg2, rx2, sg2) TG_LOAD_PIECE(3, rg3, rx3, sg3) \
   }
-#define TG_STORE_PIECE(P, RG, RX)                                                                             \
+#define load_tile_b(R0)                                                                                       \
+  {                                                                                                           \
+    long long r0_ = (R0);                                                                                     \
+    TG_LOAD_PIECE(0, rh0, ry0, sh0) TG_LOAD_PIECE(1, rh1, ry1, sh1) TG_LOAD_PIECE(2, rh2, ry2, sh2) TG_LOAD_PIECE(3, rh3, ry3, sh3) \
+  }
+#define TG_STORE_PIECE(P, RG, RX, SG)                                                                         \
   {                                                                                                           \
     int piece = tid + 256 * P, off = lds_off(piece >> 4, piece & 15);                                         \
     if constexpr (SCALED) {                                                                                   \
-      if (gset > 0) RG = tn_scale8(RG, sg##P);                                                                \
+      if (gset > 0) RG = tn_scale8(RG, SG);                                                                   \
     }                                                                                                         \
     *reinterpret_cast<uint4*>(tg_w + off) = RG;                                                               \
     *reinterpret_cast<uint4*>(tg_w + TILE_BYTES + off) = RX;                                                  \
@@ -129,7 +139,12 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
 #define store_tile(BUF)                                                                                       \
   {                                                                                                           \
     char* tg_w = lds + (BUF) * 2 * TILE_BYTES;                                                                \
-    TG_STORE_PIECE(0, rg0, rx0) TG_STORE_PIECE(1, rg1, rx1) TG_STORE_PIECE(2, rg2, rx2) TG_STORE_PIECE(3, rg3, rx3) \
+    TG_STORE_PIECE(0, rg0, rx0, sg0) TG_STORE_PIECE(1, rg1, rx1, sg1) TG_STORE_PIECE(2, rg2, rx2, sg2) TG_STORE_PIECE(3, rg3, rx3, sg3) \
+  }
+#define store_tile_b(BUF)                                                                                     \
+  {                                                                                                           \
+    char* tg_w = lds + (BUF) * 2 * TILE_BYTES;                                                                \
+    TG_STORE_PIECE(0, rh0, ry0, sh0) TG_STORE_PIECE(1, rh1, ry1, sh1) TG_STORE_PIECE(2, rh2, ry2, sh2) TG_STORE_PIECE(3, rh3, ry3, sh3) \
   }
 
   // bias gradient: thread t sums column (t & 127) over rows (t >> 7)*32 .. +31 of every G tile
@@ -137,35 +152,48 @@ __global__ void __launch_bounds__(256) k_gemm_tn_bf16(const unsigned short* __re
   float cs = 0.f;
   const int cs_col = tid & 127, cs_r0 = (tid >> 7) * 32;
 
+  // software pipeline, two tiles deep: at the top of step s the LDS buffer `buf` holds tile s, set A holds tile s+1
+  // (loads issued one step ago) and set B's loads of tile s+2 have just been issued; after the MFMAs tile s+1 goes to
+  // the other LDS buffer and the sets swap roles (the loop is unrolled by two so that each set keeps its names).
+#define TG_COMPUTE_TILE()                                                                                     \
+  {                                                                                                           \
+    const char* tg_ = lds + buf * 2 * TILE_BYTES;                                                             \
+    const char* tx_ = tg_ + TILE_BYTES;                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < GK / 16; ++ks) {                                                  \
+      v8bf a0 = frag_tr(tg_, ks, wm * 2 + 0, lane), a1 = frag_tr(tg_, ks, wm * 2 + 1, lane);                 \
+      v8bf b0 = frag_tr(tx_, ks, wn * 2 + 0, lane), b1 = frag_tr(tx_, ks, wn * 2 + 1, lane);                 \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);                        \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);                        \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);                        \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);                        \
+    }                                                                                                         \
+    if (do_cs) {                                                                                              \
+      _Pragma("unroll 8") for (int rr = 0; rr < 32; ++rr) {                                                   \
+        int row = cs_r0 + rr;                                                                                 \
+        unsigned short hv = *reinterpret_cast<const unsigned short*>(tg_ + lds_off(row, cs_col >> 3) + 2 * (cs_col & 7)); \
+        cs += bf2f(hv);                                                                                       \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
   if (r_begin < r_end) {
     load_tile(r_begin)
     store_tile(0)
+    if (r_begin + GK < r_end) load_tile(r_begin + GK)              // tile 1 -> set A
   }
   __syncthreads();
   int buf = 0;
-  for (long long r0 = r_begin; r0 < r_end; r0 += GK) {
-    const bool more = r0 + GK < r_end;
-    if (more) load_tile(r0 + GK)                   // next tile's HBM reads fly under this tile's MFMAs
-    const char* tg_ = lds + buf * 2 * TILE_BYTES;
-    const char* tx_ = tg_ + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < GK / 16; ++ks) {
-      v8bf a0 = frag_tr(tg_, ks, wm * 2 + 0, lane), a1 = frag_tr(tg_, ks, wm * 2 + 1, lane);
-      v8bf b0 = frag_tr(tx_, ks, wn * 2 + 0, lane), b1 = frag_tr(tx_, ks, wn * 2 + 1, lane);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (do_cs) {
-#pragma unroll 8
-      for (int rr = 0; rr < 32; ++rr) {
-        int row = cs_r0 + rr;
-        unsigned short hv = *reinterpret_cast<const unsigned short*>(tg_ + lds_off(row, cs_col >> 3) + 2 * (cs_col & 7));
-        cs += bf2f(hv);
-      }
-    }
-    if (more) store_tile(buf ^ 1)
+  for (long long r0 = r_begin; r0 < r_end; r0 += 2 * GK) {
+    // ---- step s (even): set A holds tile s+1
+    if (r0 + 2 * GK < r_end) load_tile_b(r0 + 2 * GK)              // tile s+2 -> set B
+    TG_COMPUTE_TILE()
+    if (r0 + GK < r_end) store_tile(buf ^ 1)
+    __syncthreads();
+    buf ^= 1;
+    if (r0 + GK >= r_end) break;
+    // ---- step s+1 (odd): set B holds tile s+2
+    if (r0 + 3 * GK < r_end) load_tile(r0 + 3 * GK)                // tile s+3 -> set A
+    TG_COMPUTE_TILE()
+    if (r0 + 2 * GK < r_end) store_tile_b(buf ^ 1)
     __syncthreads();
     buf ^= 1;
   }
@@ -262,7 +290,10 @@ static void tn_geometry(long long R, int M, int N, int& tm, int& tn, int& nslab,
   tm = ceil_div(M, GM);
   tn = ceil_div(N, GN);
   long long steps = ceil_div(R, GK);
-  long long want = ceil_div(768, (long long)tm * tn);
+  // 64 KiB of LDS per workgroup: two are resident per CU, so for a single output tile 512 workgroups fill the chip in
+  // ONE round (768 ran as a full round plus a half-empty one: 337 -> 291 us on the 2.58 M-row 128 x 128 problem);
+  // several output tiles per slab measured faster with the finer split (W_in, 3 tiles: 824 us at 768, 1045 us at 512)
+  long long want = ceil_div(tm * tn == 1 ? 512 : 768, (long long)tm * tn);
   nslab = (int)(want < 1 ? 1 : (want > steps ? steps : want));
   rows_per_slab = ceil_div(steps, nslab) * (long long)GK;
   nslab = (int)ceil_div(R, rows_per_slab);
