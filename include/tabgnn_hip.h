@@ -62,6 +62,9 @@ typedef struct {
   const float* cat_table;              /* [sum rows, C] */
   const float *ts_min_year, *ts_w, *ts_b; /* [nt] [nt,7,8,C] [nt,C] */
   const float *rel_w, *rel_b;          /* [nr,C] */
+  const int64_t* row_ids;              /* [R] or NULL.  Non-NULL: num / cat / ts / rel are the WHOLE HBM-resident raw table and
+                                        * output row r encodes table row row_ids[r] (the batch is a list of edge / node ids:
+                                        * TensorFrame.__getitem__ of ibm_transactions_for_aml.py:163,168 without the row copy) */
 } tg_enc_ptrs; /* HOST struct of device pointers */
 int tg_encode_max_cols(void);
 int tg_encode_small_table_rows(void);

@@ -22,6 +22,11 @@ int tg_sampler_sample(void* handle, const int64_t* seed_src, const int64_t* seed
                       const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
                       int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, int64_t* n_edges,
                       int64_t* n_nodes);
+/* Stable counting sort of M keys in [0, N) on the host: rowptr int32 [N+1], perm int32 [M] = input positions, ascending
+ * inside a segment — identical to the device's tg_csr_build (tabgnn_hip.h).  With it the sampler hands the batch's
+ * CSR-by-destination / by-source to the aggregation kernels directly (get_graph_inputs + the scatter indices of
+ * PNAConv.aggregate, ibm_transactions_for_aml.py:159-180; src/datasets/util/graph.py:38-53). */
+int tg_host_csr(const int64_t* key, int64_t M, int64_t N, int32_t* rowptr, int32_t* perm);
 /* Negative edges for link-prediction pre-training: replaces generate_negative_samples
  * (src/primitives/negative_sampling/negative_sampling.cpp:10-81; pybind11 binding :78-81; caller
  * src/utils/batch_processing.py:145).  edge_index (src,dst)[E] and the B positive edges use the same compact local

@@ -49,7 +49,13 @@ struct EncPtrs {
   const float* cat_table;                       // [sum rows, C]
   const float *ts_min_year, *ts_w, *ts_b;       // [nt], [nt,56,C], [nt,C]
   const float *rel_w, *rel_b;                   // [nr,C]
+  const long long* row_ids;                     // [R] or NULL: output row r reads raw-table row row_ids[r] (batch = ids into the
+                                                // HBM-resident table; tg_enc_ptrs.row_ids)
 };
+// raw-table row of output row r
+__device__ __forceinline__ long long enc_src_row(const long long* __restrict__ row_ids, long long r) {
+  return row_ids ? row_ids[r] : r;
+}
 
 __device__ __forceinline__ void ts_features(const long long* t7, float min_year, float* f /*[56]*/, int field) {
   // field 0: year -> sinusoidal positional encoding; fields 1..6: value / {12,31,7,24,60,60} -> cyclic encoding
@@ -89,17 +95,18 @@ __global__ void __launch_bounds__(256) k_encode_fwd(EncDesc d, EncPtrs p, T* __r
       const EncCol& c = d.col[ci];
       if (c.kind == ENC_TS) continue;
       long long r = r0 + rr;
+      const long long sr = enc_src_row(p.row_ids, r);
       float o[VEC];
       if (c.kind == ENC_NUM) {
-        float z = (p.num[r * p.nn + c.src_col] - p.num_mean[c.src_col]) / p.num_std[c.src_col];
+        float z = (p.num[sr * p.nn + c.src_col] - p.num_mean[c.src_col]) / p.num_std[c.src_col];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = z * p.num_w[c.src_col * C + cv + j] + p.num_b[c.src_col * C + cv + j];
       } else if (c.kind == ENC_REL) {
-        float z = p.rel[r * p.nr + c.src_col];
+        float z = p.rel[sr * p.nr + c.src_col];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o[j] = z * p.rel_w[c.src_col * C + cv + j] + p.rel_b[c.src_col * C + cv + j];
       } else {
-        long long idx = p.cat[r * p.nc + c.src_col] + 1;   // NaN index -1 -> padding row 0
+        long long idx = p.cat[sr * p.nc + c.src_col] + 1;  // NaN index -1 -> padding row 0
         idx = idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx);
         const float* row = p.cat_table + ((long long)c.tab_off + idx) * C + cv;
 #pragma unroll
@@ -153,11 +160,12 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
       if (c.kind == ENC_NUM || c.kind == ENC_REL) {
         // all 16 raw values are fetched before any arithmetic (no branch between the loads: they fly together)
         const bool isnum = c.kind == ENC_NUM;
-        const float* src = isnum ? p.num + r0 * p.nn + c.src_col : p.rel + r0 * p.nr + c.src_col;
+        const float* src = isnum ? p.num + c.src_col : p.rel + c.src_col;
         const int sstride = isnum ? p.nn : p.nr;
         float zv[ENC_RCH];
 #pragma unroll
-        for (int rr = 0; rr < ENC_RCH; ++rr) zv[rr] = src[(rr < nrows ? rr : nrows - 1) * sstride];   // gv is 0 past nrows
+        for (int rr = 0; rr < ENC_RCH; ++rr)                                                         // gv is 0 past nrows
+          zv[rr] = src[enc_src_row(p.row_ids, r0 + (rr < nrows ? rr : nrows - 1)) * sstride];
         const float mu = isnum ? p.num_mean[c.src_col] : 0.f, sd = isnum ? p.num_std[c.src_col] : 1.f;
         float aw[V], ab[V];
 #pragma unroll
@@ -178,11 +186,11 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
           acc[c.acc_off + C + ch + j] += ab[j];
         }
       } else {
-        const long long* src = p.cat + r0 * p.nc + c.src_col;
+        const long long* src = p.cat + c.src_col;
         int rowi[ENC_RCH];
 #pragma unroll
         for (int rr = 0; rr < ENC_RCH; ++rr) {
-          long long idx = src[(rr < nrows ? rr : nrows - 1) * p.nc] + 1;                             // gv is 0 past nrows
+          long long idx = src[enc_src_row(p.row_ids, r0 + (rr < nrows ? rr : nrows - 1)) * p.nc] + 1;   // gv is 0 past nrows
           rowi[rr] = (int)(idx < 0 ? 0 : (idx >= c.rows ? c.rows - 1 : idx));
         }
         if (c.acc_off >= 0) {
@@ -220,7 +228,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) k_encode_ts_fwd(const long long* __restrict__ ts, int nt, int src_col,
                                                         const float* __restrict__ min_year_p, const float* __restrict__ w /*[56,C]*/,
                                                         const float* __restrict__ bias /*[C]*/, T* __restrict__ out,
-                                                        long long R, int ncols, int out_col, int C) {
+                                                        long long R, int ncols, int out_col, int C,
+                                                        const long long* __restrict__ row_ids) {
   __shared__ __attribute__((aligned(16))) float feats[TS_RCH * TS_K];
   const int ngrp = C / 2, cg = threadIdx.x % ngrp, rl = threadIdx.x / ngrp, RL = 256 / ngrp;
   const int c0 = cg * 2;
@@ -234,7 +243,7 @@ __global__ void __launch_bounds__(256) k_encode_ts_fwd(const long long* __restri
     __syncthreads();
     if (threadIdx.x < nrows * TS_F) {
       int rr = threadIdx.x / TS_F, field = threadIdx.x % TS_F;
-      ts_features(ts + ((r0 + rr) * nt + src_col) * TS_F, min_year, feats + rr * TS_K, field);
+      ts_features(ts + (enc_src_row(row_ids, r0 + rr) * nt + src_col) * TS_F, min_year, feats + rr * TS_K, field);
     }
     __syncthreads();
     for (int rr = rl; rr < nrows; rr += RL) {
@@ -259,7 +268,8 @@ __global__ void __launch_bounds__(256) k_encode_ts_fwd(const long long* __restri
 template <typename T>
 __global__ void __launch_bounds__(256) k_encode_ts_bwd(const long long* __restrict__ ts, int nt, int src_col,
                                                         const float* __restrict__ min_year_p, const T* __restrict__ g, long long R, int ncols,
-                                                        int out_col, int C, float* __restrict__ partials) {
+                                                        int out_col, int C, float* __restrict__ partials,
+                                                        const long long* __restrict__ row_ids) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // feats [TS_RCH*56] | acc [57*C]
   float* feats = sm;
   float* acc = sm + TS_RCH * TS_K;
@@ -274,7 +284,7 @@ __global__ void __launch_bounds__(256) k_encode_ts_bwd(const long long* __restri
     __syncthreads();
     if (threadIdx.x < nrows * TS_F) {
       int rr = threadIdx.x / TS_F, field = threadIdx.x % TS_F;
-      ts_features(ts + ((r0 + rr) * nt + src_col) * TS_F, min_year, feats + rr * TS_K, field);
+      ts_features(ts + (enc_src_row(row_ids, r0 + rr) * nt + src_col) * TS_F, min_year, feats + rr * TS_K, field);
     }
     __syncthreads();
     for (int rr = rl; rr < nrows; rr += RL) {
@@ -391,10 +401,10 @@ extern "C" int tg_encode_fwd(const void* desc, const void* ptrs, void* out, int6
     const float* min_year_host = p->ts_min_year + c.src_col;   // device pointer
     if (dt == F32)
       hipLaunchKernelGGL((k_encode_ts_fwd<float>), dim3(grid), dim3(256), 0, st, (const long long*)p->ts, p->nt,
-                         c.src_col, min_year_host, w, b, (float*)out, (long long)R, ncols, c.out_col, C);
+                         c.src_col, min_year_host, w, b, (float*)out, (long long)R, ncols, c.out_col, C, p->row_ids);
     else
       hipLaunchKernelGGL((k_encode_ts_fwd<bf16_t>), dim3(grid), dim3(256), 0, st, (const long long*)p->ts, p->nt,
-                         c.src_col, min_year_host, w, b, (bf16_t*)out, (long long)R, ncols, c.out_col, C);
+                         c.src_col, min_year_host, w, b, (bf16_t*)out, (long long)R, ncols, c.out_col, C, p->row_ids);
   }
   TG_LAUNCH_CHECK();
   return 0;
@@ -441,11 +451,11 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
     if (dt == F32) {
       (void)hipFuncSetAttribute((const void*)k_encode_ts_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       hipLaunchKernelGGL((k_encode_ts_bwd<float>), dim3(grid), dim3(256), shm, st, (const long long*)p->ts, p->nt,
-                         c.src_col, min_year_host, (const float*)g, (long long)R, ncols, c.out_col, C, partials);
+                         c.src_col, min_year_host, (const float*)g, (long long)R, ncols, c.out_col, C, partials, p->row_ids);
     } else {
       (void)hipFuncSetAttribute((const void*)k_encode_ts_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       hipLaunchKernelGGL((k_encode_ts_bwd<bf16_t>), dim3(grid), dim3(256), shm, st, (const long long*)p->ts, p->nt,
-                         c.src_col, min_year_host, (const bf16_t*)g, (long long)R, ncols, c.out_col, C, partials);
+                         c.src_col, min_year_host, (const bf16_t*)g, (long long)R, ncols, c.out_col, C, partials, p->row_ids);
     }
     hipLaunchKernelGGL(k_enc_reduce, dim3(ceil_div(width, 64)), dim3(256), 0, st, partials, grid, width,
                        dflat + c.acc_off, (const int*)nullptr, 0);

@@ -377,3 +377,26 @@ int tg_edge_ports(const int64_t* src, const int64_t* dst, const int64_t* ts, int
 }
 
 }  // extern "C"
+
+// Stable counting sort of M keys in [0, N): rowptr[N+1], perm[M] (input positions, ascending inside a segment) — the
+// same structure tg_csr_build makes on the device (include/tabgnn_hip.h), produced by the sampler's host thread so
+// that the aggregation kernels take the batch's CSR-by-destination / by-source as it arrives.
+extern "C" int tg_host_csr(const int64_t* key, int64_t M, int64_t N, int32_t* rowptr, int32_t* perm) {
+  if (M < 0 || N <= 0 || M > 2147483647LL || N > 2147483646LL || (M > 0 && (!key || !perm)) || !rowptr) {
+    snprintf(g_err, sizeof(g_err), "tg_host_csr: bad arguments M=%lld N=%lld", (long long)M, (long long)N);
+    return 1;
+  }
+  std::fill(rowptr, rowptr + N + 1, 0);
+  for (int64_t i = 0; i < M; ++i) {
+    if (key[i] < 0 || key[i] >= N) {
+      snprintf(g_err, sizeof(g_err), "tg_host_csr: key %lld at position %lld is outside [0, %lld)", (long long)key[i],
+               (long long)i, (long long)N);
+      return 1;
+    }
+    ++rowptr[key[i] + 1];
+  }
+  for (int64_t n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n];
+  std::vector<int32_t> pos(rowptr, rowptr + N);
+  for (int64_t i = 0; i < M; ++i) perm[pos[(size_t)key[i]]++] = (int32_t)i;
+  return 0;
+}

@@ -105,7 +105,7 @@ class EncPtrs(C.Structure):
     _fields_ = [("num", _vp), ("nn", _i32), ("cat", _vp), ("nc", _i32), ("ts", _vp), ("nt", _i32), ("rel", _vp),
                 ("nr", _i32), ("num_mean", _vp), ("num_std", _vp), ("num_w", _vp), ("num_b", _vp),
                 ("cat_table", _vp), ("ts_min_year", _vp), ("ts_w", _vp), ("ts_b", _vp), ("rel_w", _vp),
-                ("rel_b", _vp)]
+                ("rel_b", _vp), ("row_ids", _vp)]
 
 
 _lib = None

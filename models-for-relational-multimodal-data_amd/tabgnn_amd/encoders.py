@@ -84,10 +84,10 @@ class ProjectionEncoder(nn.Module):
 
 class _Encode(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, feats, out_dtype, *params):
+    def forward(ctx, enc, feats, out_dtype, row_ids, *params):
         # params order: num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b (None where the stype is absent)
         plan = enc._plan
-        R = next(iter(feats.values())).shape[0]
+        R = row_ids.shape[0] if row_ids is not None else next(iter(feats.values())).shape[0]
         dev = next(iter(feats.values())).device
         Cc = enc.out_channels
         # The rows are written into columns 1.. of a [R, ncols+1, C] buffer and returned as that view: the backbones
@@ -97,10 +97,10 @@ class _Encode(torch.autograd.Function):
         S = plan["ncols"] + 1
         buf = torch.empty(R, S, Cc, dtype=out_dtype, device=dev)
         out = buf[:, 1:, :]
-        ptrs = enc._ptrs(feats, params)
+        ptrs = enc._ptrs(feats, params, row_ids)
         for desc in plan["descs"]:
             L.call("tg_encode_fwd", C.addressof(desc), C.addressof(ptrs), out.data_ptr(), R, S, Cc, L.dt(out), L.stream())
-        ctx.enc, ctx.feats, ctx.params, ctx.R = enc, feats, params, R
+        ctx.enc, ctx.feats, ctx.params, ctx.R, ctx.row_ids = enc, feats, params, R, row_ids
         out._cls_base = buf
         return out
 
@@ -116,7 +116,7 @@ class _Encode(torch.autograd.Function):
         else:
             g = g.contiguous()
         dev = g.device
-        ptrs = enc._ptrs(feats, params)
+        ptrs = enc._ptrs(feats, params, ctx.row_ids)
         num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b = params
         nblk = L.load().tg_encode_bwd_blocks()
         seg_tables = enc._grad_segment_tables(dev)
@@ -129,7 +129,7 @@ class _Encode(torch.autograd.Function):
                 L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), g.data_ptr(), R, row_cols, Cc, acc_floats,
                        L.ptr(dflat), L.ptr(partials), None, L.dt(g), L.stream())
                 L.call("tg_scatter_add_segments", L.ptr(dflat), L.ptr(table), nseg, max_len, L.stream())
-            return (None,) * (3 + len(params))
+            return (None,) * (4 + len(params))
         grads = [None if p is None else torch.zeros_like(p) for p in params]
         for desc, acc_floats, segs in zip(plan["descs"], plan["acc_floats"], plan["segments"]):
             dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
@@ -146,7 +146,7 @@ class _Encode(torch.autograd.Function):
                     grads[4][src_col] = dflat[off + 56 * Cc:off + 57 * Cc]
                 elif off >= 0:
                     grads[2][tab_off:tab_off + rows] = dflat[off:off + rows * Cc].view(rows, Cc)
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class StypeWiseFeatureEncoder(nn.Module):
@@ -271,9 +271,13 @@ class StypeWiseFeatureEncoder(nn.Module):
         embs = self.encoder_dict["categorical"].embs
         return torch.cat([e.weight for e in embs], dim=0) if len(embs) > 1 else embs[0].weight
 
-    def _ptrs(self, feats, params):
+    def _ptrs(self, feats, params, row_ids=None):
         num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b = params
         p = L.EncPtrs()
+        if row_ids is not None:
+            if row_ids.dtype != torch.int64 or not row_ids.is_contiguous():
+                raise RuntimeError("TensorFrame.row_ids must be a contiguous int64 tensor")
+            p.row_ids = L.ptr(row_ids)
         ed = self.encoder_dict
 
         def raw(s, dtype):
@@ -311,6 +315,6 @@ class StypeWiseFeatureEncoder(nn.Module):
             ed["relation"].weight if "relation" in ed else None,
             ed["relation"].bias if "relation" in ed else None,
         ]
-        x = _Encode.apply(self, feats, self.compute_dtype, *params)
+        x = _Encode.apply(self, feats, self.compute_dtype, tf.row_ids, *params)
         names = [n for s in self.col_names_dict for n in self.col_names_dict[s]]
         return x, names

@@ -32,6 +32,10 @@ class TensorFrame:
     feat_dict: Dict[stype, torch.Tensor]
     col_names_dict: Dict[stype, List[str]]
     y: Optional[torch.Tensor] = None
+    # Lazy row selection (the on-device columnar store): when set, ``feat_dict`` holds the WHOLE raw
+    # table and the frame's rows are table rows ``row_ids`` (int64, same device) — slicing slices the id list, and the
+    # stype encoders read the raw columns by id, so the gathered rows are never materialised.
+    row_ids: Optional[torch.Tensor] = None
 
     @property
     def stypes(self):
@@ -39,6 +43,8 @@ class TensorFrame:
 
     @property
     def num_rows(self):
+        if self.row_ids is not None:
+            return self.row_ids.shape[0]
         return next(iter(self.feat_dict.values())).shape[0]
 
     @property
@@ -51,9 +57,19 @@ class TensorFrame:
     def __getitem__(self, index):
         if isinstance(index, tuple):          # tf[a:b, :] as utils.py:355 writes it
             index = index[0]
+        if self.row_ids is not None:
+            return TensorFrame(self.feat_dict, self.col_names_dict, None if self.y is None else self.y[index],
+                               self.row_ids[index])
         return TensorFrame({k: v[index] for k, v in self.feat_dict.items()}, self.col_names_dict,
                            None if self.y is None else self.y[index])
 
     def to(self, device):
         return TensorFrame({k: v.to(device) for k, v in self.feat_dict.items()}, self.col_names_dict,
-                           None if self.y is None else self.y.to(device))
+                           None if self.y is None else self.y.to(device),
+                           None if self.row_ids is None else self.row_ids.to(device))
+
+    def materialize(self):
+        """The frame with its rows gathered (what ``tensor_frame[idx]`` returns in the reference)."""
+        if self.row_ids is None:
+            return self
+        return TensorFrame({k: v.index_select(0, self.row_ids) for k, v in self.feat_dict.items()}, self.col_names_dict, self.y)

@@ -169,6 +169,27 @@ class SeedIndex:
         self.N = num_nodes
         self.rowptr, self.perm = SubgraphIndex.csr(self.tei, num_nodes)
 
+    @classmethod
+    def from_parts(cls, tei32, rowptr, perm, B, num_nodes):
+        """From structures built elsewhere (the sampler's host thread, sampler.batch_index)."""
+        self = cls.__new__(cls)
+        self.tei, self.src, self.dst, self.B, self.N = tei32, tei32[:B], tei32[B:], B, num_nodes
+        self.rowptr, self.perm, self.err = rowptr, perm, None
+        return self
+
+
+class BatchIndex:
+    """A sampled batch's ``edge_index`` together with its prebuilt index structures: ``graph`` (SubgraphIndex of the
+    neighbour edges, columns B: ) and ``seeds`` (SeedIndex of the first B columns).  Accepted wherever the wrappers take
+    ``edge_index``; ``.edge_index`` is the plain int64 [2,E] tensor."""
+
+    def __init__(self, graph, seeds, edge_index):
+        self.graph, self.seeds, self.edge_index = graph, seeds, edge_index
+
+    @property
+    def shape(self):
+        return self.edge_index.shape
+
 
 # --------------------------------------------------------------------------- dense projection
 

@@ -41,6 +41,8 @@ def _load():
         lib.tg_sampler_sample.argtypes = [C.c_void_p, i64p, i64p, i64p, C.c_int64, i32p, C.c_int32, C.c_uint64,
                                           C.c_int32, C.c_int64, i64p, i64p, i64p, i64p, i64p]
         lib.tg_sampler_sample.restype = C.c_int
+        lib.tg_host_csr.argtypes = [i64p, C.c_int64, C.c_int64, i32p, i32p]
+        lib.tg_host_csr.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -100,6 +102,42 @@ class NeighborSampler:
                 torch.from_numpy(out_nodes[:nn].copy()))
 
 
+def host_csr(keys, num_nodes):
+    """(rowptr int32 [N+1], perm int32 [M]) of int64 ``keys`` in [0, N): stable counting sort on the host
+    (``tg_host_csr``), the structure ``tg_csr_build`` makes on the device."""
+    lib = _load()
+    keys = np.ascontiguousarray(np.asarray(keys, dtype=np.int64))
+    rowptr = np.empty(num_nodes + 1, dtype=np.int32)
+    perm = np.empty(max(keys.shape[0], 1), dtype=np.int32)
+    rc = lib.tg_host_csr(_p64(keys), keys.shape[0], int(num_nodes), rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                         perm.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise ValueError(lib.tg_sampler_last_error().decode())
+    return rowptr, perm
+
+
+def batch_index(edge_index, num_nodes, n_seed, device):
+    """The index structures of one sampled batch, built on the host next to the sampler and uploaded once:
+    ``ops.BatchIndex`` with the CSR-by-destination / by-source of the neighbour edges (columns ``n_seed:``) and the CSR
+    of the 2B seed endpoints — what ``SubgraphIndex.build`` / ``SeedIndex`` otherwise rebuild on the device in every
+    forward (the sampler emits the CSR the aggregation kernels read)."""
+    from . import ops
+    ei = np.ascontiguousarray(edge_index.numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index),
+                              dtype=np.int64)
+    nsrc, ndst = np.ascontiguousarray(ei[0, n_seed:]), np.ascontiguousarray(ei[1, n_seed:])
+    tei = np.ascontiguousarray(np.concatenate([ei[0, :n_seed], ei[1, :n_seed]]))
+    parts = [nsrc.astype(np.int32), ndst.astype(np.int32), *host_csr(ndst, num_nodes), *host_csr(nsrc, num_nodes),
+             tei.astype(np.int32), *host_csr(tei, num_nodes)]
+    flat = torch.from_numpy(np.concatenate([p.ravel() for p in parts])).to(device, non_blocking=True)   # ONE upload
+    views, off = [], 0
+    for p_ in parts:
+        views.append(flat[off:off + p_.size]); off += p_.size
+    src, dst, rp_d, pm_d, rp_s, pm_s, tei_d, rp_t, pm_t = views
+    graph = ops.SubgraphIndex(src, dst, (rp_d, pm_d), (rp_s, pm_s), int(num_nodes))
+    seeds = ops.SeedIndex.from_parts(tei_d, rp_t, pm_t, int(n_seed), int(num_nodes))
+    return ops.BatchIndex(graph, seeds, torch.from_numpy(ei).to(device, non_blocking=True))
+
+
 class ColumnStore:
     """Raw edge table (dict stype -> tensor [E_total, ...]) + labels, node table (dict stype -> [V, ...]); tensors may
     live on the host or on the MI355X (then the per-batch gather runs on the device and nothing crosses PCIe but ids)."""
@@ -118,22 +156,35 @@ class ColumnStore:
     def device(self):
         return self.labels.device
 
-    def graph_inputs(self, sampler: NeighborSampler, seed_eids, rng_seed=0):
-        """``get_graph_inputs`` (ibm…py:159-180): (node_tf, edge_index, edge_tf, y) with the seed edges first."""
+    def graph_inputs(self, sampler: NeighborSampler, seed_eids, rng_seed=0, lazy=None):
+        """``get_graph_inputs`` (ibm…py:159-180): (node_tf, edge_index, edge_tf, y) with the seed edges first.
+        ``lazy`` (default: when the store is on the GPU): the TensorFrames carry the sampled ids (``row_ids``) over the
+        whole HBM-resident table and the stype encoders read the raw columns by id — ``tensor_frame[idx]``
+        (ibm…py:163,168) without ever materialising the gathered rows; ``lazy=False`` gathers them (index_select)."""
         eid, edge_index, nodes = sampler.sample(seed_eids, rng_seed)
+        return self.batch(eid, edge_index, nodes, len(seed_eids), lazy)
+
+    def batch(self, eid, edge_index, nodes, n_seed, lazy=None):
         dev = self.device
-        eid_d, nodes_d = eid.to(dev), nodes.to(dev)
-        edge_tf = TensorFrame({k: v.index_select(0, eid_d) for k, v in self.edge_feats.items()}, self.edge_cols)
-        node_tf = TensorFrame({k: v.index_select(0, nodes_d) for k, v in self.node_feats.items()}, self.node_cols)
-        y = self.labels.index_select(0, eid_d[:len(seed_eids)])
-        return node_tf, edge_index.to(dev), edge_tf, y
+        lazy = (dev.type == "cuda") if lazy is None else lazy
+        eid_d, nodes_d = eid.to(dev, non_blocking=True), nodes.to(dev, non_blocking=True)
+        if lazy:
+            edge_tf = TensorFrame(self.edge_feats, self.edge_cols, None, eid_d)
+            node_tf = TensorFrame(self.node_feats, self.node_cols, None, nodes_d)
+        else:
+            edge_tf = TensorFrame({k: v.index_select(0, eid_d) for k, v in self.edge_feats.items()}, self.edge_cols)
+            node_tf = TensorFrame({k: v.index_select(0, nodes_d) for k, v in self.node_feats.items()}, self.node_cols)
+        y = self.labels.index_select(0, eid_d[:n_seed])
+        if lazy and dev.type == "cuda":      # index structures built on the host too: the model skips its CSR kernels
+            return node_tf, batch_index(edge_index, nodes.numel(), n_seed, dev), edge_tf, y
+        return node_tf, edge_index.to(dev, non_blocking=True), edge_tf, y
 
     def lp_inputs(self, sampler: NeighborSampler, seed_eids, num_neg_samples=64, rng_seed=0):
         """``lp_inputs`` (``src/utils/batch_processing.py:104-147``) for link-prediction pre-training:
         (node_tf, edge_index, edge_tf, neigh_edge_index, neigh_edge_tf, target_edge_index, target_edge_tf) where the
         targets are the B positive (seed) edges followed by the sampled negatives, and every positive's raw row is
         repeated ``num_neg_samples`` times (contiguously) behind the positives' rows for its negatives."""
-        node_tf, edge_index, edge_tf, _ = self.graph_inputs(sampler, seed_eids, rng_seed)
+        node_tf, edge_index, edge_tf, _ = self.graph_inputs(sampler, seed_eids, rng_seed, lazy=False)
         B = len(seed_eids)
         pos = edge_index[:, :B]
         neg = generate_negative_samples(edge_index, pos, num_neg_samples, seed=rng_seed).to(edge_index.device)

@@ -41,11 +41,18 @@ class TABGNNFusedS(nn.Module):
     def forward(self, x, edge_index, edge_attr):
         bs = self.batch_size
         edge_attr, target_edge_attr = edge_attr[bs:, :], edge_attr[:bs, :]
-        edge_index, target_edge_index = edge_index[:, bs:].contiguous(), edge_index[:, :bs].contiguous()
+        prebuilt = edge_index if isinstance(edge_index, ops.BatchIndex) else None
+        if prebuilt is None:
+            edge_index, target_edge_index = edge_index[:, bs:].contiguous(), edge_index[:, :bs].contiguous()
         x, _ = self.node_encoder(x)
         edge_attr, _ = self.edge_encoder(edge_attr)
         target_edge_attr, _ = self.edge_encoder(target_edge_attr)
-        seeds = ops.SeedIndex(target_edge_index, x.shape[0])          # one CSR of the seed endpoints for backbone AND head
+        if prebuilt is not None:      # the sampler built the CSRs with the batch (sampler.batch_index): no index kernels here
+            if prebuilt.seeds.B != bs or prebuilt.graph.N != x.shape[0]:
+                raise RuntimeError("BatchIndex does not match this batch (seed count / node count)")
+            edge_index, seeds = prebuilt.graph, prebuilt.seeds
+        else:
+            seeds = ops.SeedIndex(target_edge_index, x.shape[0])      # one CSR of the seed endpoints for backbone AND head
         x, edge_attr, target_edge_attr = self.model(x, edge_index, edge_attr, seeds, target_edge_attr)
         if self.config["task"] == "edge_classification":
             return self.decoder(x, seeds, target_edge_attr)

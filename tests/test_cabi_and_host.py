@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_structs_match_header_layout():
     from tabgnn_amd import _lib
     assert ctypes.sizeof(_lib.EncCol) == 32 and ctypes.sizeof(_lib.EncDesc) == 8 + 16 * 32
-    assert ctypes.sizeof(_lib.EncPtrs) == 4 * 16 + 10 * 8
+    assert ctypes.sizeof(_lib.EncPtrs) == 4 * 16 + 11 * 8          # + row_ids (ABI 2)
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -101,3 +101,63 @@ def test_config5_wide_mixed_table_c256():
         got_g = p.grad.cpu() if p.grad is not None else torch.zeros_like(ref)   # unused edge-update of the last layer
         err = (got_g - ref).abs().max().item()
         assert err <= 2e-3 * (ref.abs().max().item() + 1e-6) + 1e-7, (k, err, ref.abs().max().item())
+
+
+def test_column_store_batches_by_id_equal_gathered_batches_bit_for_bit():
+    """the HBM-resident raw table + a list of sampled edge / node ids (``TensorFrame.row_ids``) is the
+    batch; the stype encoders read the raw columns BY ID (tg_enc_ptrs.row_ids).  Against the host-assembled batch
+    (``tensor_frame[idx]``, ibm_transactions_for_aml.py:163,168 -> index_select): encoder outputs, seed/neighbour
+    slices, logits and every parameter gradient are bit-for-bit equal (same kernels, same reduction order), and the
+    index columns seen by the kernel are the gathered ones exactly."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    from tabgnn_amd.frame import stype
+    from tabgnn_amd.sampler import ColumnStore, NeighborSampler
+    rs = np.random.RandomState(3)
+    N, E, B = 4000, 30000, 64
+    ei = np.stack([rs.randint(0, N, E), rs.randint(0, N, E)])
+    num, cat, ts = S.edge_table(E, 7)
+    cat[rs.rand(E) < 0.01, 1] = -1                                     # missing categories (padding row)
+    labels = torch.from_numpy((rs.rand(E) < 0.05).astype(np.int64))
+    store = ColumnStore({stype.numerical: torch.from_numpy(num), stype.categorical: torch.from_numpy(cat),
+                         stype.timestamp: torch.from_numpy(ts)}, S.EDGE_COLS,
+                        {stype.relation: torch.ones(N, 1)}, S.NODE_COLS, labels).to(DEV)
+    sampler = NeighborSampler(ei, N, (10, 10), num_threads=1)
+    seeds = rs.choice(E, B, replace=False)
+    eid, lei, nodes = sampler.sample(seeds, 5)
+    lazy = store.batch(eid, lei, nodes, B, lazy=True)          # ids + host-built CSRs (BatchIndex)
+    full = store.batch(eid, lei, nodes, B, lazy=False)         # gathered rows + plain edge_index
+    assert lazy[2].row_ids is not None and full[2].row_ids is None and lazy[2].num_rows == full[2].num_rows == eid.numel()
+    mat = lazy[2].materialize()
+    for k in full[2].feat_dict:                                        # index / raw columns: identical rows
+        assert torch.equal(mat.feat_dict[k], full[2].feat_dict[k])
+    torch.manual_seed(0)
+    cfg = S.make_config(32, 1, 8, B, backbone_dropout=0.0, head_dropout=0.0)
+    model = T.TABGNNFusedS(cfg).to(DEV).train()
+    with torch.no_grad():
+        a, _ = model.edge_encoder(lazy[2][B:, :])
+        b, _ = model.edge_encoder(full[2][B:, :])
+    assert torch.equal(a, b) and a.shape[0] == eid.numel() - B
+    lw = torch.tensor(cfg["loss_weights"], device=DEV)
+    grads = []
+    for batch in (lazy, full):
+        for p in model.parameters():
+            p.grad = None
+        out = model(batch[0], batch[1], batch[2])
+        T.ops.weighted_cross_entropy(out[:B], batch[3], lw).backward()
+        grads.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(grads[0][0], grads[1][0])
+    for k in grads[0][1]:
+        assert torch.equal(grads[0][1][k], grads[1][1][k]), k
+    # the sampler-side index structures (sampler.batch_index: host counting sorts, one upload) are the ones the device
+    # builds from edge_index (tg_csr_build): same rowptr, same stable permutation
+    bi = lazy[1]
+    assert isinstance(bi, T.ops.BatchIndex)
+    dev_graph = T.ops.SubgraphIndex.build(bi.edge_index[:, B:].contiguous(), nodes.numel())
+    dev_seeds = T.ops.SeedIndex(bi.edge_index[:, :B].contiguous(), nodes.numel())
+    En = eid.numel() - B
+    for a_, b_ in ((bi.graph.by_dst, dev_graph.by_dst), (bi.graph.by_src, dev_graph.by_src)):
+        assert torch.equal(a_[0], b_[0]) and torch.equal(a_[1][:En], b_[1][:En])
+    assert torch.equal(bi.graph.src, dev_graph.src) and torch.equal(bi.graph.dst, dev_graph.dst)
+    assert torch.equal(bi.seeds.rowptr, dev_seeds.rowptr) and torch.equal(bi.seeds.perm[:2 * B], dev_seeds.perm[:2 * B])
+    assert torch.equal(bi.seeds.tei, dev_seeds.tei)

@@ -146,3 +146,20 @@ def test_lp_inputs_assembles_positive_and_negative_targets():
     negs = tei[:, B:].reshape(2, B, 2, k // 2)
     assert torch.equal(negs[0, :, 0, :], tei[0, :B, None].expand(B, k // 2))      # first half keeps the source
     assert torch.equal(negs[1, :, 1, :], tei[1, :B, None].expand(B, k // 2))      # second half the destination
+
+
+def test_host_csr_is_a_stable_counting_sort():
+    """tg_host_csr (the CSR the sampler hands to the aggregation kernels): rowptr = prefix sums of the key histogram,
+    perm = input positions ascending inside every segment; bad keys are refused."""
+    from tabgnn_amd.sampler import host_csr
+    rs = np.random.RandomState(0)
+    N, M = 50, 400
+    keys = rs.randint(0, N - 5, M).astype(np.int64)                 # nodes N-5.. have no rows
+    rowptr, perm = host_csr(keys, N)
+    assert rowptr[0] == 0 and rowptr[-1] == M and (np.diff(rowptr) == np.bincount(keys, minlength=N)).all()
+    assert (keys[perm[:M]] == np.sort(keys, kind="stable")).all()
+    assert (perm[:M] == np.argsort(keys, kind="stable")).all()
+    rp0, _ = host_csr(np.zeros(0, dtype=np.int64), 3)
+    assert rp0.tolist() == [0, 0, 0, 0]
+    with pytest.raises(ValueError):
+        host_csr(np.array([0, 7]), 7)
