@@ -145,7 +145,8 @@ def test_column_store_batches_by_id_equal_gathered_batches_bit_for_bit():
             p.grad = None
         out = model(batch[0], batch[1], batch[2])
         T.ops.weighted_cross_entropy(out[:B], batch[3], lw).backward()
-        grads.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+        grads.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert grads[0][1].keys() == grads[1][1].keys() and len(grads[0][1]) > 20
     assert torch.equal(grads[0][0], grads[1][0])
     for k in grads[0][1]:
         assert torch.equal(grads[0][1][k], grads[1][1][k]), k
