@@ -30,13 +30,11 @@ __device__ __forceinline__ int lds_off(int row, int ch) {
 
 // 8 consecutive k (rows r0..r0+7 of the tile) of column (cb*32 + lane&31): MFMA 32x32x16 A/B fragment
 __device__ __forceinline__ uint4 tn_scale8(uint4 v, float s) {   // 8 packed bf16 times s, round to nearest even
-  unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float lo = __uint_as_float(w[j] << 16) * s, hi = __uint_as_float(w[j] & 0xffff0000u) * s;
-    w[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-  }
-  return make_uint4(w[0], w[1], w[2], w[3]);
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  // vector conversions keep (element 2j, element 2j+1) together: one v_cvt_pk_bf16_f32 per output word, no re-pairing
+  f32x8 f = __builtin_convertvector(__builtin_bit_cast(v8bf, v), f32x8);
+  f *= s;
+  return __builtin_bit_cast(uint4, __builtin_convertvector(f, v8bf));
 }
 
 __device__ __forceinline__ v8bf frag_tr(const char* tile, int ks, int cb, int lane) {
@@ -220,6 +218,260 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16(const unsigned short* _
     }
 }
 
+#undef TG_LOAD_PIECE
+#undef TG_STORE_PIECE
+#undef TG_COMPUTE_TILE
+#undef load_tile
+#undef load_tile_b
+#undef store_tile
+#undef store_tile_b
+
+// ---------------------------------------------------------------------------------------------------------------
+// WIDE variant: one 512-thread workgroup (8 waves, the only one resident on its CU: 128 KiB of LDS) owns a 384 x 128
+// output block = THREE 128-column tiles of the "wide" operand against ONE tile of the "narrow" operand, so the narrow
+// tile is staged through LDS once per three output tiles instead of once per tile, and every wave feeds 6 MFMAs from 5
+// fragment reads (2 x 2 per 4 reads in the kernel above): the LDS traffic per MFMA drops by 40 %, which is what bounds
+// the multi-tile problems (W_in: 384 x 128, the PNA message / edge-update first layers: 128 x 384, the fuse MLP, and
+// the scaled post projection, where the three wide tiles are the SAME 128 columns of G times (1, amp, att) — G is
+// then read from HBM once and written to LDS three times).
+//   WIDE_G = true : wide operand = G (M side), narrow = X;  false: wide = X (N side), narrow = G  (operand order of
+//   the MFMA is swapped so that the output's N index stays on the lanes: coalesced partial writes either way).
+// Software pipeline: one staging register set; the loads of tile s+2 are issued right after tile s+1 went to LDS and
+// have the barrier plus the whole MFMA phase of step s+1 to land.
+// The bias gradient (column sums of G) is accumulated from the staging registers: thread t always stages chunk t & 15
+// of its rows, so it keeps 8 running sums per G tile it touches and the 32 threads of a chunk meet in LDS at the end.
+template <bool SCALED, bool WIDE_G>
+__global__ void __launch_bounds__(512) k_gemm_tn_wide(const unsigned short* __restrict__ G,
+                                                      const unsigned short* __restrict__ X,
+                                                      float* __restrict__ partial, float* __restrict__ colsum_part,
+                                                      long long R, int M, int N, long long ldg, long long ldx,
+                                                      long long rows_per_slab, int tw, int tnar, int nslab,
+                                                      const float* __restrict__ scales, int mreal) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];     // [buf][W0|W1|W2|Nn][64 x 256 B] = 128 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T_ = tw * tnar;
+  const int slot = blockIdx.x >> 3;
+  const int slab = (slot / T_) * 8 + (blockIdx.x & 7), tile = slot % T_;
+  if (slab >= nslab) return;
+  const int bw = tile % tw, bn = tile / tw;            // wide block (384 columns, or the scaled 128) and narrow block
+  // column origins of the two operand streams
+  const unsigned short* __restrict__ Wp = WIDE_G ? G : X;
+  const unsigned short* __restrict__ Np = WIDE_G ? X : G;
+  const long long ldw = WIDE_G ? ldg : ldx, ldn = WIDE_G ? ldx : ldg;
+  const int w0 = SCALED ? bw * 128 : bw * 384, n0 = bn * 128;
+  const long long r_begin = (long long)slab * rows_per_slab;
+  long long r_end = r_begin + rows_per_slab;
+  if (r_end > R) r_end = R;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  constexpr int NWP = SCALED ? 2 : 6;                   // wide pieces per thread per step
+  constexpr int NSET = SCALED ? 3 : 2;                  // staging register sets = steps a global load has to land
+  uint4 rw[NSET][NWP], rn[NSET][2];
+  float sc[NSET][2][2];
+  const int prow = tid >> 4, pch = tid & 15;            // piece q: row prow + 32 q, 16-byte chunk pch (fixed per thread)
+  // Addressing: a UNIFORM row base per step (scalar registers) plus a per-lane 32-bit byte offset (row-in-tile,
+  // clamped to the slab's last row, times the row pitch + column): two vector instructions per piece row and step.
+  // The load sequence is the SAME straight-line code for every tile — full, partial or past the end — so that the
+  // s_waitcnt before each LDS store counts exactly the loads of the other sets as outstanding (any `if` around or
+  // between the loads makes the compiler wait for all of them: the prefetch distance collapses to one step).  Rows
+  // past the end are zeroed at STORE time, under a uniform branch that holds no memory instruction and is taken only
+  // for a slab's last, partial tile.  [64-bit per-lane addresses, clamps and zeroing selects on every piece made the
+  // load/store phase ~300 VALU instructions per step and wave: more SIMD time than the 24 MFMAs it feeds.]
+  const unsigned coln = (unsigned)(n0 + pch * 8) * 2u, colw = (unsigned)(w0 + pch * 8) * 2u;
+  const unsigned pitchn = (unsigned)ldn * 2u, pitchw = (unsigned)ldw * 2u;
+  const int soff0 = lds_off(prow, pch), soff1 = lds_off(prow + 32, pch);
+#define TG_WIDE_LOAD(K_, R0)                                                                                  \
+  {                                                                                                           \
+    const long long r0_ = (R0);                                                                               \
+    long long left_ = r_end - r0_;                              /* uniform; <= 0 past the end */              \
+    const long long rb_ = left_ >= 1 ? r0_ : r_end - 1;         /* first row read: always inside the slab */  \
+    const int last_ = left_ >= GK ? GK - 1 : (left_ >= 1 ? (int)left_ - 1 : 0);                               \
+    const char* nb_ = reinterpret_cast<const char*>(Np) + rb_ * ldn * 2;                                      \
+    const char* wb_ = reinterpret_cast<const char*>(Wp) + rb_ * ldw * 2;                                      \
+    const char* sb_ = reinterpret_cast<const char*>(scales) + rb_ * 8;                                        \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+      const unsigned rr_ = (unsigned)min(prow + 32 * q, last_);                                               \
+      rn[K_][q] = *reinterpret_cast<const uint4*>(nb_ + (rr_ * pitchn + coln));                               \
+      if constexpr (SCALED) {                                                                                 \
+        rw[K_][q] = *reinterpret_cast<const uint4*>(wb_ + (rr_ * pitchw + colw));                             \
+        const float2 s2 = *reinterpret_cast<const float2*>(sb_ + rr_ * 8u);                                   \
+        sc[K_][q][0] = s2.x; sc[K_][q][1] = s2.y;                                                             \
+      } else {                                                                                                \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                         \
+          rw[K_][t * 2 + q] = *reinterpret_cast<const uint4*>(wb_ + (rr_ * pitchw + colw) + t * 256);         \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+  // LEFT = rows of the tile in the set that exist (uniform); only a partial tile pays for the zeroing
+#define TG_WIDE_MASK(K_, LEFT)                                                                                \
+  if ((LEFT) < GK) {                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+      if (prow + 32 * q >= (LEFT)) {                                                                          \
+        rn[K_][q] = make_uint4(0u, 0u, 0u, 0u);                                                               \
+        _Pragma("unroll") for (int t = 0; t < (SCALED ? 1 : 3); ++t) rw[K_][SCALED ? q : t * 2 + q] = make_uint4(0u, 0u, 0u, 0u); \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+#define TG_WIDE_STORE(K_, BUF)                                                                                \
+  {                                                                                                           \
+    char* base = lds + (BUF) * 4 * TILE_BYTES;                                                                \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                           \
+      const int off = q ? soff1 : soff0;                                                                      \
+      *reinterpret_cast<uint4*>(base + 3 * TILE_BYTES + off) = rn[K_][q];                                     \
+      if constexpr (SCALED) {                                                                                 \
+        *reinterpret_cast<uint4*>(base + off) = rw[K_][q];                                                    \
+        *reinterpret_cast<uint4*>(base + TILE_BYTES + off) = tn_scale8(rw[K_][q], sc[K_][q][0]);             \
+        *reinterpret_cast<uint4*>(base + 2 * TILE_BYTES + off) = tn_scale8(rw[K_][q], sc[K_][q][1]);         \
+      } else {                                                                                                \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                         \
+          *reinterpret_cast<uint4*>(base + t * TILE_BYTES + off) = rw[K_][t * 2 + q];                         \
+      }                                                                                                       \
+    }                                                                                                         \
+  }
+
+  // bias gradient = column sums of G (never with SCALED): from the staging registers, 8 columns per G tile per thread
+  const bool do_cs = !SCALED && colsum_part != nullptr && (WIDE_G ? bn == 0 : bw == 0);
+  constexpr int NCS = WIDE_G ? 3 : 1;
+  float cs[NCS][8];
+#pragma unroll
+  for (int t = 0; t < NCS; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[t][j] = 0.f;
+#define TG_WIDE_CS(K_)                                                                                        \
+  if constexpr (!SCALED) {                                                                                    \
+    if (do_cs) {                                                                                              \
+      _Pragma("unroll") for (int t = 0; t < NCS; ++t)                                                         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                       \
+          const uint4 v = WIDE_G ? rw[K_][t * 2 + q] : rn[K_][q];                                             \
+          const unsigned w[4] = {v.x, v.y, v.z, v.w};                                                         \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+            cs[t][2 * j] += __uint_as_float(w[j] << 16);                                                      \
+            cs[t][2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);                                          \
+          }                                                                                                   \
+        }                                                                                                     \
+    }                                                                                                         \
+  }
+
+  // fragment addresses: everything but the LDS buffer and the k-step (an immediate: 16 rows = 4096 bytes, and the
+  // swizzle term does not depend on it) is a per-lane constant — ten registers computed once instead of ~15 vector
+  // adds per k-step
+  int fwo[3][2], fno[2][2];
+  {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+      const int row = (g >> 1) * 8 + 4 * hi + q;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const int blk = wm * 3 + a;
+        fwo[a][hi] = (blk >> 2) * TILE_BYTES + lds_off(row, (blk & 3) * 4 + (g & 1) * 2 + (pp >> 1)) + 8 * (pp & 1);
+      }
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
+        fno[b2][hi] = 3 * TILE_BYTES + lds_off(row, (wn * 2 + b2) * 4 + (g & 1) * 2 + (pp >> 1)) + 8 * (pp & 1);
+    }
+  }
+  typedef v4s __attribute__((address_space(3))) * lds_v4s_ptr;
+  typedef short v8s_t __attribute__((ext_vector_type(8)));
+  auto frag_at = [&](const char* base, int off_lo, int off_hi, int ks) -> v8bf {
+    v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base + off_lo + ks * 4096));
+    v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base + off_hi + ks * 4096));
+    v8s_t r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(v8bf, r);
+  };
+  auto compute_tile = [&](int buf) {
+    const char* base = lds + buf * 4 * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < GK / 16; ++ks) {
+      v8bf fw[3], fn[2];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) fw[a] = frag_at(base, fwo[a][0], fwo[a][1], ks);
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2) fn[b2] = frag_at(base, fno[b2][0], fno[b2][1], ks);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = WIDE_G ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[a], fn[b], acc[a][b], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fn[b], fw[a], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // fragments of one k-step live at a time (registers: no spills)
+    }
+  };
+
+  // pipeline: at the top of step s LDS buffer s & 1 holds tile s and the register sets hold tiles s+1 .. s+NSET (tile
+  // j in set j % NSET); after the MFMAs tile s+1 goes to the other LDS buffer and its set takes tile s+1+NSET
+  // Every load below is UNCONDITIONAL (rows past the slab read the clamped last row and are zeroed by `ok`): with the
+  // loads of later tiles under an `if`, the compiler's s_waitcnt placement no longer knows how many are outstanding
+  // and waits for (nearly) all of them before each LDS store — the prefetch distance collapses to one step.
+  TG_WIDE_LOAD(0, r_begin)
+  TG_WIDE_MASK(0, r_end - r_begin)
+  TG_WIDE_CS(0)
+  TG_WIDE_STORE(0, 0)
+#pragma unroll
+  for (int j = 1; j <= NSET; ++j) TG_WIDE_LOAD(j % NSET, r_begin + (long long)j * GK)
+  __syncthreads();
+  int buf = 0;
+  for (long long r0 = r_begin; r0 < r_end; r0 += (long long)NSET * GK) {
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      const long long rs = r0 + (long long)u * GK;                // first row of tile s
+      if (rs >= r_end) break;
+      compute_tile(buf);
+      TG_WIDE_MASK((u + 1) % NSET, r_end - (rs + GK))             // tile s+1: partial or (all zeros) past the end
+      TG_WIDE_CS((u + 1) % NSET)
+      TG_WIDE_STORE((u + 1) % NSET, buf ^ 1)
+      TG_WIDE_LOAD((u + 1) % NSET, rs + (long long)(1 + NSET) * GK)
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#undef TG_WIDE_LOAD
+#undef TG_WIDE_STORE
+#undef TG_WIDE_MASK
+#undef TG_WIDE_CS
+
+  if (do_cs) {   // all tiles consumed (the loop ended with a barrier): the 32 row groups of a chunk meet in LDS
+    float* red = reinterpret_cast<float*>(lds);                 // [32][NCS*128]
+#pragma unroll
+    for (int t = 0; t < NCS; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[prow * (NCS * 128) + t * 128 + pch * 8 + j] = cs[t][j];
+    __syncthreads();
+    if (tid < NCS * 128) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < 32; ++k) s += red[k * (NCS * 128) + tid];
+      colsum_part[(long long)slab * M + (WIDE_G ? w0 : n0) + tid] = s;
+    }
+  }
+
+  // C/D map of the 32x32 tile: col = lane & 31 (the B operand's column), row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+  float* out = partial + (long long)slab * M * N;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int blk = wm * 3 + a;
+    const int wcol = SCALED ? (blk >> 2) * mreal + w0 + (blk & 3) * 32 : w0 + blk * 32;   // first wide index of the tile
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ncol = n0 + wn * 64 + b * 32;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int rr = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5), cc = lane & 31;
+        if constexpr (WIDE_G) out[(long long)(wcol + rr) * N + ncol + cc] = acc[a][b][i];      // rows = wide = m
+        else out[(long long)(ncol + rr) * N + wcol + cc] = acc[a][b][i];                         // rows = narrow = m
+      }
+    }
+  }
+}
+
 // out[i] = sum_s partial[s][i]: 256 threads = 16 float4 columns x 16 slab strips, four loads in flight per
 // thread, strips combined through LDS in strip order (deterministic)
 // Two jobs in one launch (the weight slabs and the bias column sums of the same GEMM): blocks [0, nb1) reduce job 1,
@@ -286,23 +538,66 @@ __global__ void __launch_bounds__(256) k_sum_slabs(const float* __restrict__ par
 
 using namespace tg;
 
-static void tn_geometry(long long R, int M, int N, int& tm, int& tn, int& nslab, long long& rows_per_slab) {
-  tm = ceil_div(M, GM);
-  tn = ceil_div(N, GN);
-  long long steps = ceil_div(R, GK);
+// Which kernel and split a weight-gradient problem gets.  kind: 0 = 128x128 tiles (k_gemm_tn_bf16), 1 = wide on the G
+// (M) side, 2 = wide on the X (N) side (k_gemm_tn_wide: 384x128 blocks, one workgroup per CU).
+struct TnPlan {
+  int kind, tm, tn, nslab;
+  long long rows_per_slab;
+};
+static TnPlan tn_plan(long long R, int M, int N, bool scaled = false, int mreal = 0) {
+  TnPlan p;
+  const long long steps = ceil_div(R, GK);
+  p.kind = 0;
+  if (scaled) {
+    if (N % 128 == 0 && mreal % 128 == 0) p.kind = 1;
+  } else if (M % 384 == 0 && N % 128 == 0) {
+    p.kind = 1;
+  } else if (N % 384 == 0 && M % 128 == 0) {
+    p.kind = 2;
+  }
+  if (p.kind) {
+    // tm = wide blocks, tn = narrow blocks; ONE workgroup per CU is resident, so ~one round of 256 equal slabs
+    p.tm = scaled ? mreal / 128 : (p.kind == 1 ? M / 384 : N / 384);
+    p.tn = p.kind == 1 ? N / 128 : M / 128;
+    const long long tiles = (long long)p.tm * p.tn;
+    long long want = tiles >= 256 ? 1 : 256 / tiles;
+    if (steps < 2 * want) p.kind = 0;                      // too few rows to pipeline: the small-tile kernel
+    else {
+      p.nslab = (int)want;
+      p.rows_per_slab = ceil_div(steps, p.nslab) * (long long)GK;
+      p.nslab = (int)ceil_div(R, p.rows_per_slab);
+      return p;
+    }
+  }
+  p.tm = ceil_div(M, GM);
+  p.tn = ceil_div(N, GN);
   // 64 KiB of LDS per workgroup: two are resident per CU, so for a single output tile 512 workgroups fill the chip in
   // ONE round (768 ran as a full round plus a half-empty one: 337 -> 291 us on the 2.58 M-row 128 x 128 problem);
-  // several output tiles per slab measured faster with the finer split (W_in, 3 tiles: 824 us at 768, 1045 us at 512)
-  long long want = ceil_div(tm * tn == 1 ? 512 : 768, (long long)tm * tn);
-  nslab = (int)(want < 1 ? 1 : (want > steps ? steps : want));
-  rows_per_slab = ceil_div(steps, nslab) * (long long)GK;
-  nslab = (int)ceil_div(R, rows_per_slab);
+  // several output tiles per slab measured faster with the finer split.  A slab is never shorter than 4 steps (256
+  // rows): below that the fp32 partials (64 KiB per tile and slab, written and read back) outweigh the rows it read.
+  long long want = ceil_div(p.tm * p.tn == 1 ? 512 : 768, (long long)p.tm * p.tn);
+  const long long cap = steps / 4 > 0 ? steps / 4 : 1;
+  if (want > cap) want = cap;
+  p.nslab = (int)(want < 1 ? 1 : want);
+  p.rows_per_slab = ceil_div(steps, p.nslab) * (long long)GK;
+  p.nslab = (int)ceil_div(R, p.rows_per_slab);
+  return p;
+}
+
+static void tn_wide_attr() {
+  static bool done = false;
+  if (done) return;
+  const int lds = 2 * 4 * TILE_BYTES;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tn_wide<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tn_wide<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tn_wide<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  done = true;
 }
 
 extern "C" int64_t tg_gemm_tn_workspace_floats(int64_t R, int32_t M, int32_t N) {
-  int tm, tn, nslab;
-  long long rps;
-  tn_geometry(R, M, N, tm, tn, nslab, rps);
+  // the scaled entry point asks with M = 3*mreal: its plan may have fewer slabs than this one, never more
+  const TnPlan a = tn_plan(R, M, N), b = tn_plan(R, M, N, M % 384 == 0, M / 3);
+  const int nslab = a.nslab > b.nslab ? a.nslab : b.nslab;
   return (int64_t)nslab * M * N + (int64_t)nslab * M;
 }
 
@@ -316,15 +611,28 @@ extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* 
   TG_CHECK((reinterpret_cast<uintptr_t>(G) & 15) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
                (reinterpret_cast<uintptr_t>(out) & 15) == 0,
            "tg_gemm_tn_bf16: operands and output must be 16-byte aligned");
-  int tm, tn, nslab;
-  long long rps;
-  tn_geometry(R, M, N, tm, tn, nslab, rps);
+  const TnPlan pl = tn_plan(R, M, N);
+  const int tm = pl.tm, tn = pl.tn, nslab = pl.nslab;
+  const long long rps = pl.rows_per_slab;
   hipStream_t st = (hipStream_t)stream;
   const long long blocks = (long long)((nslab + 7) / 8) * 8 * tm * tn;
   TG_CHECK(blocks <= 2147483647LL, "tg_gemm_tn_bf16: too many tiles");
-  hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
-                     (const unsigned short*)X, workspace, colsum ? workspace + (long long)nslab * M * N : nullptr,
-                     (long long)R, M, N, (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0);
+  float* cs_part = colsum ? workspace + (long long)nslab * M * N : nullptr;
+  if (pl.kind == 1) {
+    tn_wide_attr();
+    hipLaunchKernelGGL((k_gemm_tn_wide<false, true>), dim3((unsigned)blocks), dim3(512), 2 * 4 * TILE_BYTES, st,
+                       (const unsigned short*)G, (const unsigned short*)X, workspace, cs_part, (long long)R, M, N,
+                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0);
+  } else if (pl.kind == 2) {
+    tn_wide_attr();
+    hipLaunchKernelGGL((k_gemm_tn_wide<false, false>), dim3((unsigned)blocks), dim3(512), 2 * 4 * TILE_BYTES, st,
+                       (const unsigned short*)G, (const unsigned short*)X, workspace, cs_part, (long long)R, M, N,
+                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0);
+  } else {
+    hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
+                       (const unsigned short*)X, workspace, cs_part, (long long)R, M, N, (long long)ldg, (long long)ldx,
+                       rps, tm, tn, nslab, (const float*)nullptr, 0);
+  }
   long long mn = (long long)M * N;
   const int nb1 = ceil_div(ceil_div(mn, 4), 16), nb2 = colsum ? ceil_div(ceil_div(M, 4), 16) : 0;
   hipLaunchKernelGGL(k_sum_slabs, dim3(nb1 + nb2), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
@@ -346,15 +654,22 @@ extern "C" int tg_gemm_tn_scaled_bf16(const void* G, const void* X, const float*
                (reinterpret_cast<uintptr_t>(out) & 15) == 0,
            "tg_gemm_tn_scaled_bf16: operands and output must be 16-byte aligned");
   const int M = 3 * mreal;
-  int tm, tn, nslab;
-  long long rps;
-  tn_geometry(R, M, N, tm, tn, nslab, rps);
+  const TnPlan pl = tn_plan(R, M, N, true, mreal);
+  const int tm = pl.tm, tn = pl.tn, nslab = pl.nslab;
+  const long long rps = pl.rows_per_slab;
   hipStream_t st = (hipStream_t)stream;
   const long long blocks = (long long)((nslab + 7) / 8) * 8 * tm * tn;
   TG_CHECK(blocks <= 2147483647LL, "tg_gemm_tn_scaled_bf16: too many tiles");
-  hipLaunchKernelGGL(k_gemm_tn_bf16<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
-                     (const unsigned short*)X, workspace, (float*)nullptr, (long long)R, M, N, (long long)ldg,
-                     (long long)ldx, rps, tm, tn, nslab, scales, mreal);
+  if (pl.kind == 1) {
+    tn_wide_attr();
+    hipLaunchKernelGGL((k_gemm_tn_wide<true, true>), dim3((unsigned)blocks), dim3(512), 2 * 4 * TILE_BYTES, st,
+                       (const unsigned short*)G, (const unsigned short*)X, workspace, (float*)nullptr, (long long)R, M, N,
+                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, scales, mreal);
+  } else {
+    hipLaunchKernelGGL(k_gemm_tn_bf16<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
+                       (const unsigned short*)X, workspace, (float*)nullptr, (long long)R, M, N, (long long)ldg,
+                       (long long)ldx, rps, tm, tn, nslab, scales, mreal);
+  }
   long long mn = (long long)M * N;
   const int nb1 = ceil_div(ceil_div(mn, 4), 16);
   hipLaunchKernelGGL(k_sum_slabs, dim3(nb1), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
