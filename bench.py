@@ -52,6 +52,10 @@ def parse():
                          "(configs[3] / configs[4] shapes) and print its object — for profiling, never the headline")
     ap.add_argument("--reverse-mp", action="store_true", help="PNAConvHetero (forward + reverse message passing); "
                     "not the BASELINE configuration")
+    ap.add_argument("--index", default="sampler", choices=["sampler", "device"],
+                    help="who builds the batch's CSR-by-destination/by-source: 'sampler' = host counting sort next to "
+                         "the sampler (tg_host_csr), uploaded with the batch (SURVEY 8f rank 1); 'device' = rebuilt from "
+                         "edge_index inside every forward (tg_csr_build, +~0.3 ms/step)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the sampling-inclusive loop reported beside `value`")
     ap.add_argument("--e2e-steps", type=int, default=8)
     return ap.parse_args()
@@ -516,6 +520,10 @@ def main():
 
     batches = [S.make_batch(args.batch_size, seed=42 + rank * 1000 + i, device=dev)
                for i in range(args.distinct_batches)]
+    plain_batches = batches
+    if args.index == "sampler":     # the batch as the sampler hands it over: ids + host-built CSRs (ops.BatchIndex)
+        from tabgnn_amd.sampler import batch_index
+        batches = [(b[0], batch_index(b[1].cpu(), b[0].num_rows, args.batch_size, dev), b[2], b[3]) for b in batches]
     E_mean = sum(b[1].shape[1] for b in batches) / len(batches)
     N_mean = sum(b[0].num_rows for b in batches) / len(batches)
 
@@ -574,7 +582,10 @@ def main():
                                f"edges/step/GPU, E={int(E_mean)} sampled edges, N={int(N_mean)} nodes, 5 edge columns "
                                f"(3 cat, 1 num, 1 ts), dropout 0.5/0.083, Adam" + (", reverse_mp" if args.reverse_mp else ""),
                    "batch_size": args.batch_size, "edges_per_step": int(E_mean), "nodes_per_step": int(N_mean),
-                   "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}"},
+                   "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}",
+                   "index": ("CSR-by-destination/by-source of the batch built by the sampler side on the host "
+                             "(tg_host_csr) and resident in HBM with the batch" if args.index == "sampler" else
+                             "CSRs rebuilt from edge_index on the device inside every forward (tg_csr_build)")},
         "roofline": {"kernel": "k_pna_aggregate_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (f"{pmc_path}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -625,7 +636,7 @@ def main():
         if gemms:
             out["roofline_gemm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": gemms}
     if extras:
-        out["eval"] = eval_throughput(model, batches, dev)
+        out["eval"] = eval_throughput(model, plain_batches, dev)
         out["reference_batch"] = reference_batch(args, cdt, dev)
         if args.dtype == "bf16":
             out["other_workloads"] = {"tabgnn-arxiv": leg_tabgnn_arxiv(cdt, dev), "wide64-c256": leg_wide64(cdt, dev)}

@@ -18,7 +18,7 @@
 #define TABGNN_HIP_H_
 #include <stdint.h>
 
-#define TABGNN_HIP_ABI_VERSION 2
+#define TABGNN_HIP_ABI_VERSION 3
 
 #ifdef __cplusplus
 extern "C" {
@@ -181,6 +181,27 @@ int tg_gemm_nt_scaled_bf16(const void* X, const void* W, const float* scales, vo
                            int32_t kreal, int64_t ldx, int64_t ldy, int32_t flags /*0 | 4 (Y +=)*/, void* stream);
 int tg_gemm_tn_scaled_bf16(const void* G, const void* X, const float* scales, float* out, float* workspace, int64_t R,
                            int32_t mreal, int32_t N, int64_t ldg, int64_t ldx, int32_t accumulate, void* stream);
+/* The weight folds of PNAConv (torch_geometric 2.5.3 PNAConv.forward: edge_encoder -> pre_nns[0], post_nns[0] -> lin,
+ * as configured at src/nn/models/fused.py:200-207 / src/nn/gnn/pna.py:59-72), all on fp32 masters, F = node width,
+ * Fe = raw edge width:  w_msg [F,2F+Fe] = [P[:, :2F] | P[:, 2F:] We], b_msg = pb + P[:, 2F:] be;  w_eff = Lw Qw,
+ * b_eff = Lw qb + lb, w_x = w_eff[:, :F];  w_st [3F,4F]: row s*F+f, column kk*F+i = w_eff[f, F + (s*4+order[kk])*F + i]
+ * (order[kk] = slot of the aggregation kernel's block kk = mean|max|min|std in the module's aggregator list).
+ * The bf16 outputs (all or none) are the operand layouts of the step's GEMMs: row-major and transposed shadows of w_msg
+ * and w_x, w_cat [F,12F] (128-column block 3c+s = W_s[:, 128c:128c+128]) and wt_cat [4F,3F] = [W_0^T | W_1^T | W_2^T]
+ * for tg_gemm_nt_scaled_bf16.  tg_pna_fold_bwd maps the gradients of the five folded tensors (any may be NULL = zero)
+ * back to the eight parameters; bit i of `accumulate` (order dP,dpb,dWe,dbe,dQw,dqb,dLw,dlb) adds into the buffer
+ * instead of overwriting it; NULL outputs are skipped. */
+typedef struct { const float *P, *pb, *We, *be, *Qw, *qb, *Lw, *lb; } tg_fold_params;
+typedef struct {
+  float *w_msg, *b_msg, *w_x, *b_eff, *w_st;
+  void *w_msg_lp, *w_msg_lp_t, *w_x_lp, *w_x_lp_t, *w_cat, *wt_cat;
+} tg_fold_out;
+typedef struct { const float *dw_msg, *db_msg, *dw_x, *db_eff, *dw_st; } tg_fold_grads;
+typedef struct { float *dP, *dpb, *dWe, *dbe, *dQw, *dqb, *dLw, *dlb; int32_t accumulate; } tg_fold_dparams;
+int tg_pna_fold_fwd(const tg_fold_params* p, const tg_fold_out* o, int32_t F, int32_t Fe, const int32_t* order /*[4], host*/,
+                    void* stream);
+int tg_pna_fold_bwd(const tg_fold_params* p, const tg_fold_grads* g, const tg_fold_dparams* o, int32_t F, int32_t Fe,
+                    const int32_t* order /*[4], host*/, void* stream);
 /* GINEConv aggregation (src/nn/gnn/gine.py:18-19,62-72 through torch_geometric 2.5.3 GINEConv.forward/message):
  * out[n] = self_scale*x[n] + sum_{e: dst[e]=n} relu(x[src[e]] + le[e]), le = lin(edge_attr) [E,F]; rowptr/perm = the
  * stable by-destination CSR (tg_csr_build); self_scale = 1+eps, or 0 for the (x, None) form of GINEConvHetero

@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TABGNN_LIB_PATH") or os.path.join(_HERE, "libtabgnn_hip.so")     # (override: kernel A/B builds)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i32, _i64, _f32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
 
@@ -59,6 +59,8 @@ SIGNATURES = {
     "tg_pna_degree_scalers": [_vp, _vp, _vp, _i32, _vp],
     "tg_gemm_nt_scaled_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
     "tg_gemm_tn_scaled_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
+    "tg_pna_fold_fwd": [_vp, _vp, _i32, _i32, _vp, _vp],
+    "tg_pna_fold_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "tg_gine_aggregate_fwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _i32, _vp],
     "tg_gine_message_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -106,6 +108,23 @@ class EncPtrs(C.Structure):
                 ("nr", _i32), ("num_mean", _vp), ("num_std", _vp), ("num_w", _vp), ("num_b", _vp),
                 ("cat_table", _vp), ("ts_min_year", _vp), ("ts_w", _vp), ("ts_b", _vp), ("rel_w", _vp),
                 ("rel_b", _vp), ("row_ids", _vp)]
+
+
+class FoldParams(C.Structure):
+    _fields_ = [(k, _vp) for k in ("P", "pb", "We", "be", "Qw", "qb", "Lw", "lb")]
+
+
+class FoldOut(C.Structure):
+    _fields_ = [(k, _vp) for k in ("w_msg", "b_msg", "w_x", "b_eff", "w_st", "w_msg_lp", "w_msg_lp_t", "w_x_lp",
+                                   "w_x_lp_t", "w_cat", "wt_cat")]
+
+
+class FoldGrads(C.Structure):
+    _fields_ = [(k, _vp) for k in ("dw_msg", "db_msg", "dw_x", "db_eff", "dw_st")]
+
+
+class FoldDParams(C.Structure):
+    _fields_ = [(k, _vp) for k in ("dP", "dpb", "dWe", "dbe", "dQw", "dqb", "dLw", "dlb")] + [("accumulate", _i32)]
 
 
 _lib = None

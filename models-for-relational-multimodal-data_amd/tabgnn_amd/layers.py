@@ -152,7 +152,8 @@ class PNAConv(nn.Module):
         # (agg Wid^T) + amp (agg Wamp^T) + att (agg Watt^T): both folds on the (tiny) weights, one autograd node
         w_msg, b_msg, w_x, b_eff, w_st = ops.fold_pna_weights(pre.weight, pre.bias, self.edge_encoder.weight,
                                                               self.edge_encoder.bias, post.weight, post.bias,
-                                                              self.lin.weight, self.lin.bias, self.agg_order)
+                                                              self.lin.weight, self.lin.bias, self.agg_order,
+                                                              lp_dtype=x.dtype)
         # messages are produced directly in destination-sorted order: the aggregation then streams contiguous rows
         h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst_sorted"), w_msg, b_msg)
         agg = ops.pna_aggregate(h, g, sorted_rows=True)                 # [N,4F]

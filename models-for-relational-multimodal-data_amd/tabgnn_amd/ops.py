@@ -6,6 +6,7 @@ everything else (gather, attention core, norms, aggregation, pooling, loss, opti
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import os
 
@@ -262,11 +263,11 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, w_lp, b_lp):
         w = weight if w_lp is None else w_lp
-        b = bias if b_lp is None else b_lp
         x2 = x.reshape(-1, x.shape[-1])
         if nt_ok(x2, w.shape[0], w.shape[1]) and w.dtype == x2.dtype:
-            y = gemm_nt(x2, w, bias.detach() if bias is not None else None)
+            y = gemm_nt(x2, w, bias.detach() if bias is not None else None)      # fp32 bias in the epilogue
         else:
+            b = bias if bias is None or w_lp is None else (b_lp if b_lp is not None else shadow(bias, x2.dtype))
             y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
@@ -364,7 +365,9 @@ def shadow(p, dtype):
 
 def linear(x, weight, bias=None):
     dtype = x.dtype
-    return _Linear.apply(x, weight, bias, shadow(weight, dtype), shadow(bias, dtype))
+    # a bias without a maintained shadow is cast only if the library path needs it (the MFMA epilogue adds it in fp32)
+    b_lp = shadow(bias, dtype) if bias is not None and getattr(bias, "_lp", None) is not None else None
+    return _Linear.apply(x, weight, bias, shadow(weight, dtype), b_lp)
 
 
 class _MLPRelu(torch.autograd.Function):
@@ -856,8 +859,79 @@ class _FoldPNAWeights(torch.autograd.Function):
         return (*grads, None)
 
 
-def fold_pna_weights(P, pb, We, be, Qw, qb, Lw, lb, agg_order):
+class _FoldPNAWeightsHIP(torch.autograd.Function):
+    """The same folds as one launch (tg_pna_fold_fwd) that also writes every bf16 operand layout the step's GEMMs read
+    (attached to the fp32 outputs: ``_lp`` / ``_lp_t`` as FlatParams does for parameters, ``_packs`` on ``w_st`` for the
+    scaled post projection), and one backward call (tg_pna_fold_bwd) that adds the eight parameter gradients into their
+    ``.grad`` buffers.  Replaces ~45 library launches per convolution and step."""
+
+    @staticmethod
+    def forward(ctx, P, pb, We, be, Qw, qb, Lw, lb, agg_order, lp):
+        F, Fe = P.shape[0], We.shape[1]
+        dev = P.device
+        f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        w_msg, b_msg, w_x, b_eff, w_st = f32(F, 2 * F + Fe), f32(F), f32(F, F), f32(F), f32(3 * F, 4 * F)
+        out = L.FoldOut(*(t.data_ptr() for t in (w_msg, b_msg, w_x, b_eff, w_st)))
+        packs = None
+        if lp:      # one allocation for the six bf16 layouts
+            sizes = [F * (2 * F + Fe), F * (2 * F + Fe), F * F, F * F, 12 * F * F, 12 * F * F]
+            flat = torch.empty(sum(sizes), dtype=torch.bfloat16, device=dev)
+            views, off = [], 0
+            for n in sizes:
+                views.append(flat[off:off + n]); off += n
+            packs = (views[0].view(F, 2 * F + Fe), views[1].view(2 * F + Fe, F), views[2].view(F, F), views[3].view(F, F),
+                     views[4].view(F, 12 * F), views[5].view(4 * F, 3 * F))
+            (out.w_msg_lp, out.w_msg_lp_t, out.w_x_lp, out.w_x_lp_t, out.w_cat, out.wt_cat) = (t.data_ptr() for t in packs)
+        params = L.FoldParams(*(t.data_ptr() for t in (P, pb, We, be, Qw, qb, Lw, lb)))
+        order = (C.c_int32 * 4)(*agg_order)
+        L.call("tg_pna_fold_fwd", C.byref(params), C.byref(out), F, Fe, order, L.stream())
+        ctx.save_for_backward(P, pb, We, be, Qw, qb, Lw, lb)
+        ctx.agg_order = tuple(agg_order)
+        _FoldPNAWeightsHIP.last_packs = packs       # picked up by fold_pna_weights right after apply()
+        return w_msg, b_msg, w_x, b_eff, w_st
+
+    @staticmethod
+    def backward(ctx, dw_msg, db_msg, dw_x, db_eff, dw_st):
+        saved = ctx.saved_tensors
+        P, pb, We, be, Qw, qb, Lw, lb = saved
+        F, Fe = P.shape[0], We.shape[1]
+        cont = lambda t: None if t is None else t.contiguous().float()
+        gin = [cont(t) for t in (dw_msg, db_msg, dw_x, db_eff, dw_st)]
+        grads = L.FoldGrads(*(None if t is None else t.data_ptr() for t in gin))
+        outs, ptrs, acc = [], [], 0
+        for i, p in enumerate(saved):
+            tgt = _grad_target(p) if isinstance(p, torch.nn.Parameter) else None
+            if not ctx.needs_input_grad[i]:
+                outs.append(None); ptrs.append(None)
+            elif tgt is not None:                  # add into the flat gradient buffer; autograd gets no tensor
+                outs.append(None); ptrs.append(tgt.data_ptr()); acc |= 1 << i
+            else:
+                t = torch.empty_like(p, dtype=torch.float32)
+                outs.append(t); ptrs.append(t.data_ptr())
+        dpar = L.FoldDParams(*ptrs, acc)
+        params = L.FoldParams(*(t.data_ptr() for t in saved))
+        order = (C.c_int32 * 4)(*ctx.agg_order)
+        L.call("tg_pna_fold_bwd", C.byref(params), C.byref(grads), C.byref(dpar), F, Fe, order, L.stream())
+        return (*outs, None, None)
+
+
+def fold_pna_weights(P, pb, We, be, Qw, qb, Lw, lb, agg_order, lp_dtype=None):
+    """(w_msg, b_msg, w_x, b_eff, w_st) of a PNAConv.  fp32 parameters on the MI355X take the one-launch HIP fold
+    (``lp_dtype == torch.bfloat16`` also asks for the bf16 operand layouts); anything else the torch composition."""
+    ts = (P, pb, We, be, Qw, qb, Lw, lb)
+    if (_FOLD_HIP and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
+            and (lp_dtype != torch.bfloat16 or P.shape[0] % 32 == 0)):
+        lp = lp_dtype == torch.bfloat16
+        w_msg, b_msg, w_x, b_eff, w_st = _FoldPNAWeightsHIP.apply(*ts, tuple(agg_order), lp)
+        if lp:
+            packs, _FoldPNAWeightsHIP.last_packs = _FoldPNAWeightsHIP.last_packs, None
+            w_msg._lp, w_msg._lp_t, w_x._lp, w_x._lp_t = packs[0], packs[1], packs[2], packs[3]
+            w_st._packs = (packs[4], packs[5])
+        return w_msg, b_msg, w_x, b_eff, w_st
     return _FoldPNAWeights.apply(P, pb, We, be, Qw, qb, Lw, lb, tuple(agg_order))
+
+
+_FOLD_HIP = os.environ.get("TABGNN_NO_FOLD_KERNEL") != "1"
 
 
 def degree_scalers(graph, avg_log):
@@ -893,28 +967,34 @@ class _PNAPostScaled(torch.autograd.Function):
         x, agg = x.contiguous(), agg.contiguous()
         N, F = x.shape
         K = agg.shape[1]
-        wx_lp = w_x.detach().to(torch.bfloat16).contiguous()
+        packs = getattr(w_st, "_packs", None)        # written by the fold kernel (tg_pna_fold_fwd) with the weights
+        if packs is not None and getattr(w_x, "_lp", None) is not None:
+            wx_lp, wx_t = w_x._lp, w_x._lp_t
+            w_cat, wt_cat = packs
+        else:
+            wx_lp = w_x.detach().to(torch.bfloat16).contiguous()
+            wx_t = wx_lp.t().contiguous()
+            w_lp = w_st.detach().to(torch.bfloat16).view(3, F, K)
+            # [F, 3K], 128-column block 3c+s = W_s[:, 128c:128c+128] (the kernel's virtual-chunk order)
+            w_cat = w_lp.view(3, F, K // 128, 128).permute(1, 2, 0, 3).reshape(F, 3 * K).contiguous()
+            wt_cat = w_lp.permute(2, 0, 1).reshape(K, 3 * F).contiguous()      # [K, 3F] = [W_0^T | W_1^T | W_2^T]
         out = gemm_nt(x, wx_lp, b_x.detach().float().contiguous())
-        w_lp = w_st.detach().to(torch.bfloat16).view(3, F, K)
-        # [F, 3K], 128-column block 3c+s = W_s[:, 128c:128c+128] (the kernel's virtual-chunk order)
-        w_cat = w_lp.view(3, F, K // 128, 128).permute(1, 2, 0, 3).reshape(F, 3 * K).contiguous()
         scales = degree_scalers(graph, avg_log)
         L.call("tg_gemm_nt_scaled_bf16", L.ptr(agg), L.ptr(w_cat), L.ptr(scales), L.ptr(out), N, F, K, agg.stride(0),
                out.stride(0), NT_ACCUM, L.stream())
-        ctx.save_for_backward(x, wx_lp, agg, w_lp, scales)
+        ctx.save_for_backward(x, wx_t, agg, wt_cat, scales)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, wx_lp, agg, w_lp, scales = ctx.saved_tensors
+        x, wx_t, agg, wt_cat, scales = ctx.saved_tensors
         g = g.contiguous()
         N, F = g.shape
         K = agg.shape[1]
-        dx = gemm_nt(g, wx_lp.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dx = gemm_nt(g, wx_t) if ctx.needs_input_grad[0] else None
         dwx, dbx = weight_grad(g, x, True)
         if dbx is None:
             dbx = g.sum(0, dtype=torch.float32)
-        wt_cat = w_lp.permute(2, 0, 1).reshape(K, 3 * F).contiguous()          # [K, 3F] = [W_0^T | W_1^T | W_2^T]
         dagg = torch.empty_like(agg)
         L.call("tg_gemm_nt_scaled_bf16", L.ptr(g), L.ptr(wt_cat), L.ptr(scales), L.ptr(dagg), N, K, F, g.stride(0),
                dagg.stride(0), 0, L.stream())
