@@ -148,9 +148,15 @@ int tg_gather_concat3(const void* a, const int32_t* ia, int64_t sa, int32_t wa, 
                       int64_t sc, int32_t wc, void* out, int64_t rows, int32_t dt, void* stream);
 /* backward of the two gathered parts as a deterministic segmented sum over CSR(s) */
 int64_t tg_segment_hub_ints(int64_t total_rows); /* size of hub_work for tg_segment_sum2 */
+/* accumulate != 0: dx += the sums (rows with empty segments are not touched): dx is the gradient buffer the consumers of
+ * one tensor share (every consumer adds its part in place: no autograd accumulation pass over [N,F]) */
 int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA, int32_t offB,
                     const int32_t* rpB, const int32_t* pmB, int32_t seedB, const void* relu_src, void* dx, int32_t N,
-                    int32_t F, int32_t* hub_work, int32_t dt, void* stream);
+                    int32_t F, int32_t* hub_work, int32_t accumulate, int32_t dt, void* stream);
+/* dst[r, 0:W] (+)= src[idx ? idx[r] : r, 0:W] (src row pitch sstride elements): a column block of a wider gradient,
+ * optionally row-gathered, delivered into such a shared gradient buffer */
+int tg_rows_add(void* dst, const void* src, const int32_t* idx, int64_t rows, int32_t W, int64_t sstride,
+                int32_t accumulate, int32_t dt, void* stream);
 /* mean|max|min|std of messages h[E,F] per destination -> agg[N,4F]  (PNAConv.aggregate, "the SpMM") */
 /* perm == NULL: h rows are already in CSR (destination-sorted) order (E = number of rows of h) */
 /* hub_work: tg_segment_hub_ints(E) ints with hub_work[0] == 0 on entry, or NULL.  With it, destinations of more than

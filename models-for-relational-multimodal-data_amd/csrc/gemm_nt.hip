@@ -39,13 +39,11 @@ __device__ __forceinline__ nt_v8bf nt_frag(const char* tile, int row, int ch) {
 enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4, NT_GATE = 8 };
 
 __device__ __forceinline__ uint4 nt_scale8(uint4 v, float s) {   // 8 packed bf16 times s, round to nearest even
-  unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float lo = __uint_as_float(w[j] << 16) * s, hi = __uint_as_float(w[j] & 0xffff0000u) * s;
-    w[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
-  }
-  return make_uint4(w[0], w[1], w[2], w[3]);
+  typedef float nt_f32x8 __attribute__((ext_vector_type(8)));
+  // vector conversions keep (element 2j, element 2j+1) together: one v_cvt_pk_bf16_f32 per output word, no re-pairing
+  nt_f32x8 f = __builtin_convertvector(__builtin_bit_cast(nt_v8bf, v), nt_f32x8);
+  f *= s;
+  return __builtin_bit_cast(uint4, __builtin_convertvector(f, nt_v8bf));
 }
 
 // WIDE (K == 128, N > 128: the QKV projection, edge_emb's input gradient): ONE workgroup per row tile walks the

@@ -53,7 +53,8 @@ template <typename T, int VEC>
 __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int offA, const int* __restrict__ rpA,
                                const int* __restrict__ pmA, int offB, const int* __restrict__ rpB,
                                const int* __restrict__ pmB, int seedB, const T* __restrict__ relu_src,
-                               T* __restrict__ dx, int N, int F, int* __restrict__ hub /*[0]=count, [1..]=ids*/) {
+                               T* __restrict__ dx, int N, int F, int* __restrict__ hub /*[0]=count, [1..]=ids*/,
+                               int accumulate) {
   const int lpn = F / VEC;  // lanes per node
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
@@ -66,6 +67,7 @@ __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int o
       if (c == 0) hub[1 + atomicAdd(hub, 1)] = n;
       continue;
     }
+    if (accumulate && eA == sA && eB == sB) continue;      // dx += 0: the row is not touched at all
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
@@ -110,6 +112,12 @@ __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int o
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[j] = x[j] > 0.f ? acc[j] : 0.f;
     }
+    if (accumulate) {       // dx already holds another consumer's gradient of the same tensor (ops.GradSink)
+      float old[VEC];
+      loadv<T, VEC>(dx + (long long)n * F + c, old);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += old[j];
+    }
     storev<T, VEC>(dx + (long long)n * F + c, acc);
   }
 }
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
                                                             int offB, const int* __restrict__ rpB,
                                                             const int* __restrict__ pmB, int seedB,
                                                             const T* __restrict__ relu_src, T* __restrict__ dx, int F,
-                                                            const int* __restrict__ hub) {
+                                                            const int* __restrict__ hub, int accumulate) {
   extern __shared__ float part[];  // [groups][F]
   const int lpn = F / VEC, groups = 1024 / lpn;
   const int gi = threadIdx.x / lpn, c = (threadIdx.x % lpn) * VEC;
@@ -176,9 +184,35 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
       float t = 0.f;
       for (int g2 = 0; g2 < groups; ++g2) t += part[g2 * F + f];
       if (relu_src && !(to_f<T>(relu_src[(long long)n * F + f]) > 0.f)) t = 0.f;
+      if (accumulate) t += to_f<T>(dx[(long long)n * F + f]);
       dx[(long long)n * F + f] = from_f<T>(t);
     }
     __syncthreads();
+  }
+}
+
+// dst[r, 0:W] (+)= src[idx ? idx[r] : r, 0:W]  (src row pitch `sstride` elements): one column block of a wider gradient
+// (the edge-attribute third of d[x_i | x_j | e]), optionally row-gathered back to edge order, delivered into the
+// shared gradient buffer of a tensor with several consumers (ops.GradSink) without an intermediate copy.
+template <typename T, int VEC>
+__global__ void k_rows_add(T* __restrict__ dst, const T* __restrict__ src, const int* __restrict__ idx, long long rows,
+                           int W, long long sstride, int accumulate) {
+  const int lpr = W / VEC;
+  long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x, total = rows * lpr;
+  for (; gid < total; gid += stride) {
+    const long long r = gid / lpr;
+    const int c = (int)(gid % lpr) * VEC;
+    const long long sr = idx ? idx[r] : r;
+    float v[VEC];
+    loadv<T, VEC>(src + sr * sstride + c, v);
+    if (accumulate) {
+      float o[VEC];
+      loadv<T, VEC>(dst + r * W + c, o);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] += o[j];
+    }
+    storev<T, VEC>(dst + r * W + c, v);
   }
 }
 
@@ -695,8 +729,8 @@ extern "C" int64_t tg_segment_hub_ints(int64_t total_rows) { return 2 + total_ro
 
 extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA,
                                int32_t offB, const int32_t* rpB, const int32_t* pmB, int32_t seedB,
-                               const void* relu_src, void* dx, int32_t N, int32_t F, int32_t* hub_work, int32_t dt,
-                               void* stream) {
+                               const void* relu_src, void* dx, int32_t N, int32_t F, int32_t* hub_work,
+                               int32_t accumulate, int32_t dt, void* stream) {
   TG_CHECK(F % 8 == 0 && offA % 8 == 0 && offB % 8 == 0 && gstride % 8 == 0, "tg_segment_sum2: misaligned F=%d", F);
   TG_CHECK(rpA && pmA && hub_work, "tg_segment_sum2: CSR A and hub workspace required");
   hipStream_t st = (hipStream_t)stream;
@@ -706,10 +740,25 @@ extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, con
     long long total = (long long)N * (F / VEC);
     hipLaunchKernelGGL((k_segment_sum2<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 16)), dim3(256), 0, st,
                        (const T*)g, (long long)gstride, offA, rpA, pmA, offB, rpB, pmB, seedB, (const T*)relu_src,
-                       (T*)dx, N, F, hub_work);
+                       (T*)dx, N, F, hub_work, accumulate);
     size_t shm = (size_t)(1024 / (F / VEC)) * F * sizeof(float);
     hipLaunchKernelGGL((k_segment_sum2_hub<T, VEC>), dim3(256), dim3(1024), shm, st, (const T*)g, (long long)gstride,
-                       offA, rpA, pmA, offB, rpB, pmB, seedB, (const T*)relu_src, (T*)dx, F, hub_work);
+                       offA, rpA, pmA, offB, rpB, pmB, seedB, (const T*)relu_src, (T*)dx, F, hub_work, accumulate);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_rows_add(void* dst, const void* src, const int32_t* idx, int64_t rows, int32_t W, int64_t sstride,
+                           int32_t accumulate, int32_t dt, void* stream) {
+  if (rows == 0) return 0;
+  TG_CHECK(dst && src && rows > 0 && W > 0 && W % 8 == 0 && sstride % 8 == 0, "tg_rows_add: bad shape (W=%d)", W);
+  TG_CHECK((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0,
+           "tg_rows_add: operands must be 16-byte aligned");
+  DISPATCH_T(dt, {
+    const long long total = rows * (W / VEC);
+    hipLaunchKernelGGL((k_rows_add<T, VEC>), dim3(grid_cap(ceil_div(total, 256), 256 * 32)), dim3(256), 0,
+                       (hipStream_t)stream, (T*)dst, (const T*)src, idx, (long long)rows, W, (long long)sstride, accumulate);
   })
   TG_LAUNCH_CHECK();
   return 0;

@@ -50,7 +50,8 @@ SIGNATURES = {
     "tg_gather_concat3": [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i32, _vp, _i64,
                           _i32, _vp],
     "tg_segment_hub_ints": [_i64],
-    "tg_segment_sum2": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _vp],
+    "tg_segment_sum2": [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _vp],
+    "tg_rows_add": [_vp, _vp, _vp, _i64, _i32, _i64, _i32, _i32, _vp],
     "tg_pna_aggregate_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp],
     "tg_pna_aggregate_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _vp],
     "tg_pna_aggregate_hubs": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp],

@@ -92,12 +92,12 @@ class BatchNorm(nn.Module):
     def reset_parameters(self):
         self.module.reset_parameters()
 
-    def forward(self, x, res=None, relu=False, alpha=0.0, beta_c=1.0):
+    def forward(self, x, res=None, relu=False, alpha=0.0, beta_c=1.0, sink_res=None):
         m = self.module
         training = self.training and x.shape[0] > 1
         out = ops.batch_norm_act_res(x, m.weight, m.bias, m.running_mean, m.running_var, training, res=res,
                                      momentum=m.momentum, eps=m.eps, relu=relu, alpha=alpha, beta_c=beta_c,
-                                     group=self.sync_group if training else None)
+                                     group=self.sync_group if training else None, sink_res=sink_res)
         if training:
             m.num_batches_tracked += 1
         return out
@@ -144,7 +144,12 @@ class PNAConv(nn.Module):
         for m in (self.edge_encoder, self.pre_nns[0][0], self.post_nns[0][0], self.lin):
             m.reset_parameters()
 
-    def forward(self, x, edge_index, edge_attr):
+    def sinks_ok(self, x):
+        """May the caller hand this convolution the shared gradient buffers (ops.GradSink) of x and edge_attr?  Only on
+        the path where every consumer of x inside it adds into the sink (the scaled post projection)."""
+        return ops.post_scaled_ok(x, None, 4 * self.F)
+
+    def forward(self, x, edge_index, edge_attr, sink_x=None, sink_e=None):
         F = self.F
         g = ops.SubgraphIndex.build(edge_index, x.shape[0])
         pre, post = self.pre_nns[0][0], self.post_nns[0][0]
@@ -155,10 +160,12 @@ class PNAConv(nn.Module):
                                                               self.lin.weight, self.lin.bias, self.agg_order,
                                                               lp_dtype=x.dtype)
         # messages are produced directly in destination-sorted order: the aggregation then streams contiguous rows
-        h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst_sorted"), w_msg, b_msg)
+        if sink_x is not None and not self.sinks_ok(x):
+            raise RuntimeError("PNAConv: gradient sinks need the scaled post projection path (ask sinks_ok first)")
+        h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst_sorted", sink_x, sink_e), w_msg, b_msg)
         agg = ops.pna_aggregate(h, g, sorted_rows=True)                 # [N,4F]
         if ops.post_scaled_ok(x, agg):          # scalers inside the GEMMs: G [N,3F] and its gradient never exist
-            return ops.pna_post_scaled(x, w_x, b_eff, agg, w_st, g, self.aggr_module.avg_deg_log)
+            return ops.pna_post_scaled(x, w_x, b_eff, agg, w_st, g, self.aggr_module.avg_deg_log, sink_x)
         xw = ops.linear(x, w_x, b_eff)
         G = ops.linear(agg, w_st, None)
         return ops.pna_scale_combine(xw, G, g, self.aggr_module.avg_deg_log)

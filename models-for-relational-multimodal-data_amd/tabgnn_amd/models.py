@@ -96,23 +96,32 @@ class FTTransformerPNAFusedLayer(nn.Module):
         p = self.p if self.training else 0.0
         # x_tab + LN(enc(x_tab)) / 2   (sic, fused.py:249)
         x_tab = self.tab_conv(x_tab, self.tab_norm, 1.0, 0.5)
+        # Shared gradient buffers (ops.GradSink) of the three tensors that fan out inside the layer — the layer input
+        # x (message gather, post projection, residual), the edge embedding (two gathers, the edge update) and the new
+        # x (edge-update gather, fuse gather, seed pooling): every consumer adds its part in its own backward kernel,
+        # autograd never runs a [N,F] / [E,F] accumulation pass.  Only when ALL their consumers are sink-aware.
+        from .layers import PNAConv
+        sinks = (isinstance(self.gnn_conv, PNAConv) and x_gnn.is_contiguous() and edge_attr.is_contiguous()
+                 and self.gnn_conv.sinks_ok(x_gnn) and torch.is_grad_enabled())
+        sx, se, sn = ops.new_sink(sinks), ops.new_sink(sinks), ops.new_sink(sinks and not lp)
         # (x_gnn + relu(BN(PNA))) / 2   (fused.py:252)
-        conv = self.gnn_conv(x_gnn, g, edge_attr)
-        x_gnn = self.gnn_norm(conv, res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
+        conv = self.gnn_conv(x_gnn, g, edge_attr, sx, se) if sx is not None else self.gnn_conv(x_gnn, g, edge_attr)
+        x_gnn = self.gnn_norm(conv, res=x_gnn, relu=True, alpha=0.5, beta_c=0.5, sink_res=sx)
         # (e + MLP([x[src], x[dst], e])) / 2   (fused.py:253-254)
-        upd = ops.mlp_relu(ops.edge_gather(x_gnn, edge_attr, g, "src"), self.gnn_edge_update[0], self.gnn_edge_update[2])
-        edge_attr = ops.axpby(edge_attr, upd, 0.5, 0.5)
+        upd = ops.mlp_relu(ops.edge_gather(x_gnn, edge_attr, g, "src", sn, se), self.gnn_edge_update[0],
+                           self.gnn_edge_update[2])
+        edge_attr = ops.axpby(edge_attr, upd, 0.5, 0.5, sink_a=se)
         if not lp:
             seeds = ops.SeedIndex(target_edge_index, N)
             f = self.fuse
-            xf0 = ops.seed_gather(x_gnn, x_tab, seeds, "fuse")                      # [cls_tab, x[src], x[dst]]
+            xf0 = ops.seed_gather(x_gnn, x_tab, seeds, "fuse", sn)                  # [cls_tab, x[src], x[dst]]
             h = ops.layer_norm(xf0, f[0].weight, f[0].bias)
             h = ops.act_dropout(ops.linear(h, f[1].weight, f[1].bias), "leaky_relu", p)
             h = ops.act_dropout(ops.linear(h, f[4].weight, f[4].bias), "leaky_relu", p)
             h = ops.linear(h, f[7].weight, f[7].bias)
             xf = ops.layer_norm(h, self.fuse_norm.weight, self.fuse_norm.bias, res=xf0, alpha=0.5, beta_c=0.5)
             x_tab = ops.cls_merge(x_tab, xf)                                        # fused.py:259-260
-            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=True)    # fused.py:261-268
+            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=True, sink_x=sn)   # fused.py:261-268
         return x_tab, x_gnn, edge_attr
 
 

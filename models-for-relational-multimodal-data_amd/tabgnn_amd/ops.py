@@ -192,6 +192,44 @@ class BatchIndex:
         return self.edge_index.shape
 
 
+class GradSink:
+    """One gradient buffer shared by ALL consumers of a tensor that fans out to several of the operators below (the
+    layer input x feeds the message gather, the post projection and the residual; the edge embedding feeds two gathers
+    and the edge update).  Autograd would materialise one gradient per consumer and add them pairwise (a read-read-write
+    pass over [N,F] or [E,F] each); with a sink every consumer's backward kernel adds its part into the same buffer
+    (first user writes, later ones accumulate in their epilogue) and only the first user hands the buffer to autograd,
+    the others return None.  Contract: EVERY autograd consumer of the tensor must be given the sink (a consumer that
+    returns its own tensor would make autograd sum a snapshot), one backward per forward.  ``TABGNN_NO_GRAD_SINK=1``
+    turns the mechanism off (the layers then pass no sinks)."""
+
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def target(self, shape, dtype, device):
+        """(buffer, accumulate flag, hand the buffer to autograd?)"""
+        if self.buf is None:
+            self.buf = torch.empty(shape, dtype=dtype, device=device)
+            return self.buf, 0, True
+        if self.buf.shape != torch.Size(shape) or self.buf.dtype != dtype:
+            raise RuntimeError("GradSink used for tensors of different shapes")
+        return self.buf, 1, False
+
+
+GRAD_SINKS = os.environ.get("TABGNN_NO_GRAD_SINK") != "1"
+
+
+def new_sink(enabled=True):
+    return GradSink() if (GRAD_SINKS and enabled) else None
+
+
+def _sink_target(sink, shape, dtype, device):
+    if sink is None:
+        return torch.empty(shape, dtype=dtype, device=device), 0, True
+    return sink.target(shape, dtype, device)
+
+
 # --------------------------------------------------------------------------- dense projection
 
 
@@ -505,7 +543,9 @@ class _BatchNormActRes(torch.autograd.Function):
     backward does the same with (sum dz, sum dz*xhat)  (optional SyncBatchNorm)."""
 
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, alpha, beta_c, group):
+    def forward(ctx, x, res, gamma, beta, running_mean, running_var, training, momentum, eps, relu, alpha, beta_c, group,
+                sink_res=None):
+        ctx.sink_res = sink_res
         x = x.contiguous()
         N, F = x.shape
         res = res.contiguous() if res is not None else None
@@ -537,7 +577,11 @@ class _BatchNormActRes(torch.autograd.Function):
         N, F, training, relu, alpha, beta_c, has_res, group, n_stat = ctx.cfg
         g = g.contiguous()
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if has_res else None
+        dres, ret_res, add_res = None, True, None
+        if has_res:
+            dres, acc, ret_res = _sink_target(ctx.sink_res, x.shape, x.dtype, x.device)
+            if acc:                      # not the sink's first user (never the case in the fused layer): add afterwards
+                add_res, dres = dres, torch.empty_like(x)
         dparams = torch.empty(2, F, dtype=torch.float32, device=x.device)
         partials = _workspace(L.load().tg_bn_partials_floats(N, F), x.device)
         head = (L.ptr(x), L.ptr(g), L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(rstd), L.ptr(dx), L.ptr(dres))
@@ -550,13 +594,16 @@ class _BatchNormActRes(torch.autograd.Function):
             L.call("tg_bn_act_res_bwd", *head, L.ptr(glob), *tail, n_stat, 2, L.dt(x), L.stream())
         else:
             L.call("tg_bn_act_res_bwd", *head, L.ptr(dparams), *tail, 0, 0, L.dt(x), L.stream())
-        return dx, dres, dparams[1], dparams[0], None, None, None, None, None, None, None, None, None
+        if add_res is not None:
+            add_res.add_(dres)
+        return (dx, dres if ret_res else None, dparams[1], dparams[0], None, None, None, None, None, None, None, None, None,
+                None)
 
 
 def batch_norm_act_res(x, gamma, beta, running_mean, running_var, training, res=None, momentum=0.1, eps=1e-5,
-                       relu=True, alpha=0.0, beta_c=1.0, group=None):
+                       relu=True, alpha=0.0, beta_c=1.0, group=None, sink_res=None):
     return _BatchNormActRes.apply(x, res, gamma, beta, running_mean, running_var, bool(training), float(momentum),
-                                  float(eps), bool(relu), float(alpha), float(beta_c), group)
+                                  float(eps), bool(relu), float(alpha), float(beta_c), group, sink_res)
 
 
 # --------------------------------------------------------------------------- activation + dropout, axpby
@@ -594,23 +641,33 @@ def act_dropout(x, act="relu", p_drop=0.0):
 
 class _Axpby(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, alpha, beta):
+    def forward(ctx, a, b, alpha, beta, sink_a):
         a, b = a.contiguous(), b.contiguous()
         y = torch.empty_like(a)
         L.call("tg_axpby", L.ptr(a), L.ptr(b), L.ptr(y), a.numel(), alpha, beta, L.dt(a), L.stream())
         ctx.cfg = (alpha, beta)
+        ctx.sink_a = sink_a
         return y
 
     @staticmethod
     def backward(ctx, g):
         alpha, beta = ctx.cfg
+        if ctx.sink_a is not None and ctx.needs_input_grad[0]:
+            g = g.contiguous()
+            buf, acc, ret = ctx.sink_a.target(g.shape, g.dtype, g.device)
+            # buf (+)= alpha * g   (first user: alpha*g + 0*g, so the uninitialised buffer is never read)
+            L.call("tg_axpby", L.ptr(buf if acc else g), L.ptr(g), L.ptr(buf), g.numel(), 1.0 if acc else 0.0, alpha,
+                   L.dt(g), L.stream())
+            gb = g if beta == 1.0 else g * beta
+            return (buf if ret else None), gb, None, None, None
         ga = g if alpha == 1.0 else g * alpha                 # one scaled copy serves both inputs when alpha == beta
         gb = ga if beta == alpha else (g if beta == 1.0 else g * beta)
-        return ga, gb, None, None
+        return ga, gb, None, None, None
 
 
-def axpby(a, b, alpha, beta):
-    return _Axpby.apply(a, b, float(alpha), float(beta))
+def axpby(a, b, alpha, beta, sink_a=None):
+    """alpha*a + beta*b.  ``sink_a``: the GradSink of ``a`` (see GradSink)."""
+    return _Axpby.apply(a, b, float(alpha), float(beta), sink_a)
 
 
 # --------------------------------------------------------------------------- gather-concat and its backward
@@ -633,7 +690,7 @@ class _EdgeGather(torch.autograd.Function):
     """[x[ia] | x[ib] | e]  for all edges (PNAConv.message input / edge update, fused.py:254)."""
 
     @staticmethod
-    def forward(ctx, x, e, graph, first):
+    def forward(ctx, x, e, graph, first, sink_x=None, sink_e=None):
         # first == "dst": [x[dst], x[src], e] (message, x_i = target);  first == "src": [x[src], x[dst], e]
         # first == "dst_sorted": as "dst" but row k is edge perm[k] (destination-sorted layout for the aggregation)
         x, e = x.contiguous(), e.contiguous()
@@ -646,6 +703,7 @@ class _EdgeGather(torch.autograd.Function):
             parts = [(x, ia, F, 0), (x, ib, F, 0), (e, None, e.shape[1], 0)]
         out = _gather3(parts, e.shape[0], x.dtype, x.device)
         ctx.graph, ctx.first, ctx.F, ctx.We = graph, first, F, e.shape[1]
+        ctx.sinks = (sink_x, sink_e)
         return out
 
     @staticmethod
@@ -657,21 +715,28 @@ class _EdgeGather(torch.autograd.Function):
             csr_a, csr_b = (graph.by_dst[0], sv["arange"]), (graph.by_src[0], sv["src_to_sorted"])
         else:
             csr_a, csr_b = (graph.by_dst, graph.by_src) if ctx.first == "dst" else (graph.by_src, graph.by_dst)
-        dx = torch.empty(graph.N, F, dtype=g.dtype, device=g.device)
+        sink_x, sink_e = ctx.sinks
+        dx, acc_x, ret_x = _sink_target(sink_x, (graph.N, F), g.dtype, g.device)
         hub = torch.empty(L.load().tg_segment_hub_ints(2 * graph.E), dtype=torch.int32, device=g.device)
         L.call("tg_segment_sum2", L.ptr(g), g.shape[1], 0, L.ptr(csr_a[0]), L.ptr(csr_a[1]), F, L.ptr(csr_b[0]),
-               L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.ptr(hub), L.dt(g), L.stream())
-        if ctx.first == "dst_sorted":          # de[edge] = g[inv[edge], 2F:]: one row gather back to edge order
-            tail = g[:, 2 * F:]
+               L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.ptr(hub), acc_x, L.dt(g), L.stream())
+        tail = g[:, 2 * F:]
+        if sink_e is not None and ctx.We % 8 == 0:     # the edge third goes straight into e's shared gradient buffer
+            de, acc_e, ret_e = sink_e.target((g.shape[0], ctx.We), g.dtype, g.device)
+            idx = sv["inv"] if ctx.first == "dst_sorted" else None
+            L.call("tg_rows_add", L.ptr(de), tail.data_ptr(), L.ptr(idx), g.shape[0], ctx.We, g.stride(0), acc_e, L.dt(g),
+                   L.stream())
+            de = de if ret_e else None
+        elif ctx.first == "dst_sorted":        # de[edge] = g[inv[edge], 2F:]: one row gather back to edge order
             de = _gather3([(tail, sv["inv"], ctx.We, 0), (tail, None, 0, 0), (tail, None, 0, 0)], g.shape[0], g.dtype,
                           g.device)
         else:
-            de = g[:, 2 * F:]               # a view: autograd's accumulation reads it strided, no [E,F] copy
-        return dx, de, None, None
+            de = tail                       # a view: autograd's accumulation reads it strided, no [E,F] copy
+        return (dx if ret_x else None), de, None, None, None, None
 
 
-def edge_gather(x, e, graph, first):
-    return _EdgeGather.apply(x, e, graph, first)
+def edge_gather(x, e, graph, first, sink_x=None, sink_e=None):
+    return _EdgeGather.apply(x, e, graph, first, sink_x, sink_e)
 
 
 class _SeedGather(torch.autograd.Function):
@@ -679,10 +744,11 @@ class _SeedGather(torch.autograd.Function):
     [relu(x[t_src]) | relu(x[t_dst]) | tail] (ClassifierHead input, decoder.py:18-19)."""
 
     @staticmethod
-    def forward(ctx, x, other, seeds, mode):
+    def forward(ctx, x, other, seeds, mode, sink_x=None):
         x = x.contiguous()
         F = x.shape[1]
         B = seeds.B
+        ctx.sink_x = sink_x
         if mode == "fuse":      # other = x_tab [B,S,C]; lead = its CLS token (row stride S*C)
             C = other.shape[-1]
             other = other.contiguous()
@@ -703,10 +769,11 @@ class _SeedGather(torch.autograd.Function):
         g = g.contiguous()
         seeds, F = ctx.seeds, ctx.F
         relu_src = ctx.saved_tensors[0] if ctx.mode == "head" else None
-        dx = torch.empty(seeds.N, F, dtype=g.dtype, device=g.device)
+        # with a sink that already holds a gradient only the <= 2B seed-endpoint rows are touched
+        dx, acc_x, ret_x = _sink_target(ctx.sink_x, (seeds.N, F), g.dtype, g.device)
         hub = torch.empty(L.load().tg_segment_hub_ints(2 * seeds.B), dtype=torch.int32, device=g.device)
         L.call("tg_segment_sum2", L.ptr(g), g.shape[1], ctx.offs[0], L.ptr(seeds.rowptr), L.ptr(seeds.perm),
-               ctx.offs[1], None, None, seeds.B, L.ptr(relu_src), L.ptr(dx), seeds.N, F, L.ptr(hub), L.dt(g),
+               ctx.offs[1], None, None, seeds.B, L.ptr(relu_src), L.ptr(dx), seeds.N, F, L.ptr(hub), acc_x, L.dt(g),
                L.stream())
         if ctx.mode == "fuse":
             C = ctx.oshape[-1]
@@ -714,11 +781,11 @@ class _SeedGather(torch.autograd.Function):
             dother[:, 0, :] = g[:, :C]
         else:
             dother = g[:, 2 * F:].contiguous()
-        return dx, dother, None, None
+        return (dx if ret_x else None), dother, None, None, None
 
 
-def seed_gather(x, other, seeds, mode):
-    return _SeedGather.apply(x, other, seeds, mode)
+def seed_gather(x, other, seeds, mode, sink_x=None):
+    return _SeedGather.apply(x, other, seeds, mode, sink_x)
 
 
 # --------------------------------------------------------------------------- PNA aggregation + scalers
@@ -950,11 +1017,14 @@ def degree_scalers(graph, avg_log):
 _FUSED_POST = os.environ.get("TABGNN_NO_FUSED_POST") != "1"
 
 
-def post_scaled_ok(x, agg):
-    """bf16, F = 128 node width, 4F-wide aggregate: the shapes tg_gemm_nt_scaled_bf16 / tg_gemm_tn_scaled_bf16 take."""
-    return (_FUSED_POST and agg.dtype == torch.bfloat16 and agg.is_cuda and x.dtype == torch.bfloat16
-            and x.dim() == 2 and nt_ok(x, x.shape[1], x.shape[1]) and agg.shape[1] % 128 == 0
-            and agg.shape[0] == x.shape[0])
+def post_scaled_ok(x, agg, agg_width=None):
+    """bf16, F = 128 node width, 4F-wide aggregate: the shapes tg_gemm_nt_scaled_bf16 / tg_gemm_tn_scaled_bf16 take.
+    ``agg`` may be None when only its width is known yet (``agg_width``)."""
+    if agg is not None and (agg.dtype != torch.bfloat16 or not agg.is_cuda or agg.shape[0] != x.shape[0]):
+        return False
+    K = agg.shape[1] if agg is not None else agg_width
+    return (_FUSED_POST and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and nt_ok(x, x.shape[1], x.shape[1])
+            and K % 128 == 0)
 
 
 class _PNAPostScaled(torch.autograd.Function):
@@ -963,7 +1033,8 @@ class _PNAPostScaled(torch.autograd.Function):
     tg_gemm_tn_scaled_bf16), so neither G = agg w_st^T [N,3F] nor its gradient exists."""
 
     @staticmethod
-    def forward(ctx, x, w_x, b_x, agg, w_st, graph, avg_log):
+    def forward(ctx, x, w_x, b_x, agg, w_st, graph, avg_log, sink_x=None):
+        ctx.sink_x = sink_x
         x, agg = x.contiguous(), agg.contiguous()
         N, F = x.shape
         K = agg.shape[1]
@@ -991,7 +1062,11 @@ class _PNAPostScaled(torch.autograd.Function):
         g = g.contiguous()
         N, F = g.shape
         K = agg.shape[1]
-        dx = gemm_nt(g, wx_t) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:      # g Wx, written (first user) or added in the GEMM epilogue into x's shared buffer
+            buf, acc, ret = _sink_target(ctx.sink_x, (N, wx_t.shape[0]), g.dtype, g.device)
+            gemm_nt(g, wx_t, None, NT_ACCUM if acc else 0, out=buf)
+            dx = buf if ret else None
         dwx, dbx = weight_grad(g, x, True)
         if dbx is None:
             dbx = g.sum(0, dtype=torch.float32)
@@ -1002,11 +1077,11 @@ class _PNAPostScaled(torch.autograd.Function):
         ws = _workspace(L.load().tg_gemm_tn_workspace_floats(N, 3 * F, K), g.device)
         L.call("tg_gemm_tn_scaled_bf16", L.ptr(g), L.ptr(agg), L.ptr(scales), L.ptr(dw), L.ptr(ws), N, F, K, g.stride(0),
                agg.stride(0), 0, L.stream())
-        return dx, dwx, dbx, dagg, dw, None, None
+        return dx, dwx, dbx, dagg, dw, None, None, None
 
 
-def pna_post_scaled(x, w_x, b_x, agg, w_st, graph, avg_log):
-    return _PNAPostScaled.apply(x, w_x, b_x, agg, w_st, graph, avg_log)
+def pna_post_scaled(x, w_x, b_x, agg, w_st, graph, avg_log, sink_x=None):
+    return _PNAPostScaled.apply(x, w_x, b_x, agg, w_st, graph, avg_log, sink_x)
 
 
 class _GINEAggregate(torch.autograd.Function):
@@ -1038,7 +1113,7 @@ class _GINEAggregate(torch.autograd.Function):
         dx = torch.empty_like(x)
         hub = torch.empty(L.load().tg_segment_hub_ints(max(graph.E, 1)), dtype=torch.int32, device=x.device)
         L.call("tg_segment_sum2", L.ptr(dle), F, 0, L.ptr(graph.by_src[0]), L.ptr(graph.by_src[1]), 0, None, None, 0,
-               None, L.ptr(dx), N, F, L.ptr(hub), L.dt(x), L.stream())
+               None, L.ptr(dx), N, F, L.ptr(hub), 0, L.dt(x), L.stream())
         if ctx.self_scale != 0.0:
             L.call("tg_axpby", L.ptr(dx), L.ptr(g), L.ptr(dx), dx.numel(), 1.0, ctx.self_scale, L.dt(dx), L.stream())
         return dx, dle, None, None
@@ -1082,10 +1157,11 @@ class _SeedPool(torch.autograd.Function):
     """x_gnn with every seed endpoint averaged with the mean of its fused embeddings (fused.py:261-268)."""
 
     @staticmethod
-    def forward(ctx, x, xf, seeds, C, inplace):
+    def forward(ctx, x, xf, seeds, C, inplace, sink_x=None):
         xf = xf.contiguous()
         N, F = x.shape
         ctx.seeds, ctx.cfg = seeds, (N, F, C)
+        ctx.sink_x = sink_x
         if inplace and x.is_contiguous():       # touch only the <= 2B seed rows of x (fused.py:268 is in place too)
             ctx.mark_dirty(x)
             L.call("tg_seed_pool_inplace", L.ptr(x), L.ptr(xf), L.ptr(seeds.tei), L.ptr(seeds.rowptr), L.ptr(seeds.perm),
@@ -1102,16 +1178,21 @@ class _SeedPool(torch.autograd.Function):
         g = g.contiguous()
         seeds = ctx.seeds
         N, F, C = ctx.cfg
-        dx = torch.empty_like(g)
+        dx, acc, ret = _sink_target(ctx.sink_x, g.shape, g.dtype, g.device)
+        add_to = None
+        if acc:                          # not the sink's first user (it is, in the fused layer: created last, run first)
+            add_to, dx = dx, torch.empty_like(g)
         dxf = torch.empty(seeds.B, C + 2 * F, dtype=g.dtype, device=g.device)
         L.call("tg_seed_pool_bwd", L.ptr(g), L.ptr(seeds.tei), L.ptr(seeds.rowptr), L.ptr(dx), L.ptr(dxf), N, F,
                seeds.B, C, L.dt(g), L.stream())
-        return dx, dxf, None, None, None
+        if add_to is not None:
+            add_to.add_(dx)
+        return (dx if ret else None), dxf, None, None, None, None
 
 
-def seed_pool(x, xf, seeds, C, inplace=False):
+def seed_pool(x, xf, seeds, C, inplace=False, sink_x=None):
     """``inplace``: update x itself (it must be an intermediate nobody saved for backward; autograd checks)."""
-    return _SeedPool.apply(x, xf, seeds, C, inplace)
+    return _SeedPool.apply(x, xf, seeds, C, inplace, sink_x)
 
 
 # --------------------------------------------------------------------------- loss

@@ -419,3 +419,40 @@ def test_out_of_range_node_ids_raise_after_the_step():
     with pytest.raises(RuntimeError, match="outside"):
         T.IndexGuard.check(wait=True)
     T.IndexGuard.check(wait=True)                               # the flag was consumed
+
+
+def test_gradient_sinks_give_the_gradients_of_plain_autograd_accumulation():
+    """ops.GradSink (every consumer of x / edge_attr adds its part into one shared buffer in its own backward kernel)
+    against autograd's pairwise accumulation of per-consumer gradients: same forward bit for bit, gradients equal up to
+    the rounding of the bf16 partial sums (the sink adds in fp32 before rounding once)."""
+    from tabgnn_amd import ops
+    T, cfg, model, batch = _setup(96, 128, 2, 4, dtype=torch.bfloat16, seed=11)
+    model.to(DEV).train()
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    lw = torch.tensor(cfg["loss_weights"], device=DEV)
+    dbatch = (batch[0].to(DEV), batch[1].to(DEV), batch[2].to(DEV))
+    y = batch[3].to(DEV)
+    res = []
+    assert ops.GRAD_SINKS
+    try:
+        for on in (True, False):
+            ops.GRAD_SINKS = on
+            ops.DropoutRNG.new_step(1234)
+            flat.zero_grad()
+            out = model(*dbatch)
+            T.ops.weighted_cross_entropy(out[:96], y.view(-1), lw).backward()
+            res.append((out.detach().clone(), flat.grad.clone()))
+    finally:
+        ops.GRAD_SINKS = True
+    assert torch.equal(res[0][0], res[1][0])
+    a, b = res[0][1], res[1][1]
+    assert torch.isfinite(a).all()
+    rel = ((a - b).norm() / b.norm()).item()
+    assert rel < 2e-2, rel
+    off = 0                                            # per parameter: none lost a contribution
+    for name, p in model.named_parameters():
+        n = p.numel()
+        sa, sb = a[off:off + n], b[off:off + n]
+        # structurally zero gradients (biases in front of BatchNorm) are rounding noise in both runs: absolute floor
+        assert (sa - sb).norm().item() <= 0.08 * sb.norm().item() + 1e-3 * b.norm().item(), name
+        off += n
