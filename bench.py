@@ -238,6 +238,9 @@ def reference_batch(args, cdt, dev):
     opt = T.FusedAdam(flat, lr=cfg["lr"])
     lw = torch.tensor(cfg["loss_weights"], device=dev)
     batches = [S.make_batch(B, seed=77 + i, device=dev) for i in range(4)]
+    if args.index == "sampler":      # as in the timed region: the batch carries the sampler-built CSRs
+        from tabgnn_amd.sampler import batch_index
+        batches = [(b[0], batch_index(b[1].cpu(), b[0].num_rows, B, dev), b[2], b[3]) for b in batches]
     step = T.GraphedTrainStep(model, flat, opt, lw) if getattr(T, "GraphedTrainStep", None) and os.environ.get("TABGNN_GRAPH") == "1" else None
 
     def one(i):

@@ -203,7 +203,8 @@ typedef struct {
   void *w_msg_lp, *w_msg_lp_t, *w_x_lp, *w_x_lp_t, *w_cat, *wt_cat;
 } tg_fold_out;
 typedef struct { const float *dw_msg, *db_msg, *dw_x, *db_eff, *dw_st; } tg_fold_grads;
-typedef struct { float *dP, *dpb, *dWe, *dbe, *dQw, *dqb, *dLw, *dlb; int32_t accumulate; } tg_fold_dparams;
+typedef struct { float *dP, *dpb, *dWe, *dbe, *dQw, *dqb, *dLw, *dlb, *ws /* tg_pna_fold_ws_floats(F) floats, for dLw */; int32_t accumulate; } tg_fold_dparams;
+int64_t tg_pna_fold_ws_floats(int32_t F);
 int tg_pna_fold_fwd(const tg_fold_params* p, const tg_fold_out* o, int32_t F, int32_t Fe, const int32_t* order /*[4], host*/,
                     void* stream);
 int tg_pna_fold_bwd(const tg_fold_params* p, const tg_fold_grads* g, const tg_fold_dparams* o, int32_t F, int32_t Fe,

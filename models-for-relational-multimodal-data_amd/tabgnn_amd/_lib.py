@@ -62,6 +62,7 @@ SIGNATURES = {
     "tg_gemm_tn_scaled_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
     "tg_pna_fold_fwd": [_vp, _vp, _i32, _i32, _vp, _vp],
     "tg_pna_fold_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "tg_pna_fold_ws_floats": [_i32],
     "tg_gine_aggregate_fwd": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i32, _vp, _i32, _vp],
     "tg_gine_message_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "tg_seed_pool_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -92,7 +93,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,
              "tg_gemm_tn_workspace_floats": _i64, "tg_encoder_pack_bytes": _i64, "tg_encoder_prm_floats": _i64,
-             "tg_encoder_ln_grads_partials_floats": _i64}
+             "tg_encoder_ln_grads_partials_floats": _i64, "tg_pna_fold_ws_floats": _i64}
 
 
 class EncCol(C.Structure):
@@ -125,7 +126,7 @@ class FoldGrads(C.Structure):
 
 
 class FoldDParams(C.Structure):
-    _fields_ = [(k, _vp) for k in ("dP", "dpb", "dWe", "dbe", "dQw", "dqb", "dLw", "dlb")] + [("accumulate", _i32)]
+    _fields_ = [(k, _vp) for k in ("dP", "dpb", "dWe", "dbe", "dQw", "dqb", "dLw", "dlb", "ws")] + [("accumulate", _i32)]
 
 
 _lib = None

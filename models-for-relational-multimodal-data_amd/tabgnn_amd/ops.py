@@ -975,7 +975,8 @@ class _FoldPNAWeightsHIP(torch.autograd.Function):
             else:
                 t = torch.empty_like(p, dtype=torch.float32)
                 outs.append(t); ptrs.append(t.data_ptr())
-        dpar = L.FoldDParams(*ptrs, acc)
+        ws = _workspace(L.load().tg_pna_fold_ws_floats(F), P.device)
+        dpar = L.FoldDParams(*ptrs, ws.data_ptr(), acc)
         params = L.FoldParams(*(t.data_ptr() for t in saved))
         order = (C.c_int32 * 4)(*ctx.agg_order)
         L.call("tg_pna_fold_bwd", C.byref(params), C.byref(grads), C.byref(dpar), F, Fe, order, L.stream())
@@ -987,7 +988,7 @@ def fold_pna_weights(P, pb, We, be, Qw, qb, Lw, lb, agg_order, lp_dtype=None):
     (``lp_dtype == torch.bfloat16`` also asks for the bf16 operand layouts); anything else the torch composition."""
     ts = (P, pb, We, be, Qw, qb, Lw, lb)
     if (_FOLD_HIP and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts)
-            and (lp_dtype != torch.bfloat16 or P.shape[0] % 32 == 0)):
+            and P.shape[0] % 32 == 0 and We.shape[1] % 32 == 0):
         lp = lp_dtype == torch.bfloat16
         w_msg, b_msg, w_x, b_eff, w_st = _FoldPNAWeightsHIP.apply(*ts, tuple(agg_order), lp)
         if lp:

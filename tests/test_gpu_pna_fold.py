@@ -20,7 +20,7 @@ def _params(F, Fe, seed, as_param=False):
     return ts
 
 
-@pytest.mark.parametrize("F,Fe,order", [(128, 128, (0, 1, 2, 3)), (128, 128, (0, 2, 1, 3)), (64, 32, (3, 1, 0, 2)),
+@pytest.mark.parametrize("F,Fe,order", [(128, 128, (0, 1, 2, 3)), (128, 128, (0, 2, 1, 3)), (64, 32, (3, 1, 0, 2)), (96, 64, (1, 0, 3, 2)),
                                         (32, 128, (0, 1, 2, 3))])
 def test_fold_kernels_equal_the_torch_composition(F, Fe, order):
     from tabgnn_amd import ops
