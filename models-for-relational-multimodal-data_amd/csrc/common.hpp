@@ -126,30 +126,57 @@ __device__ __forceinline__ unsigned rng_key(unsigned long long seed, unsigned st
 __device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned stream, unsigned long long idx) {
   return mix32((unsigned)idx ^ rng_key(seed, stream, (unsigned)(idx >> 32)));
 }
-// Keep / drop decisions: ONE 32-bit hash decides TWO consecutive elements (its low and high 16 bits against a 16-bit
-// threshold: p is honoured to 2^-16), so a kernel that walks aligned groups of consecutive elements pays one hash per
-// pair (the two integer multiplies of mix32 are quarter-rate instructions; the hash was ~20 % of the fused encoder
-// kernels' time at one hash per element).  Every kernel of the package derives its masks through these functions, so
-// forward, backward, fused and op-by-op paths agree on every element.
+// Keep / drop decisions: ONE 32-bit hash decides several consecutive elements (the two integer multiplies of mix32 are
+// quarter-rate instructions; at one hash per element the hash was ~20 % of the fused encoder kernels' time):
+//   * BITS = 16: its low / high half against a 16-bit threshold decide elements 2q, 2q+1 (p honoured to 2^-16),
+//   * BITS = 8 : its four bytes against an 8-bit threshold decide elements 4q .. 4q+3.  Used exactly when the threshold
+//     loses nothing in 8 bits, i.e. p is a multiple of 1/256 (the reference's backbone dropout 0.5; drop_bits8()).
+// The choice is a function of the threshold alone and every kernel of the package derives its masks through these
+// functions, so forward, backward, fused and op-by-op paths agree on every element.
+__device__ __host__ __forceinline__ bool drop_bits8(unsigned thresh) { return (thresh & 0x00ffffffu) == 0u; }
 // returns the multiplicative factor: 0 or 1/(1-p)
+template <int BITS>
+__device__ __forceinline__ float drop_scale_key_t(unsigned key, unsigned lo, unsigned thresh, float inv_keep) {
+  if constexpr (BITS == 8) {
+    const unsigned hsh = mix32((lo >> 2) ^ key);
+    return ((hsh >> (8u * (lo & 3u))) & 0xffu) >= (thresh >> 24) ? inv_keep : 0.f;
+  } else {
+    const unsigned hsh = mix32((lo >> 1) ^ key);
+    const unsigned bits = (lo & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
+    return bits >= (thresh >> 16) ? inv_keep : 0.f;
+  }
+}
 // same value as drop_scale(seed, stream, idx) with key = rng_key(seed, stream, idx >> 32), lo = (unsigned)idx
 __device__ __forceinline__ float drop_scale_key(unsigned key, unsigned lo, unsigned thresh, float inv_keep) {
-  const unsigned hsh = mix32((lo >> 1) ^ key);
-  const unsigned bits = (lo & 1u) ? (hsh >> 16) : (hsh & 0xffffu);
-  return bits >= (thresh >> 16) ? inv_keep : 0.f;
+  return drop_bits8(thresh) ? drop_scale_key_t<8>(key, lo, thresh, inv_keep)        // uniform branch
+                            : drop_scale_key_t<16>(key, lo, thresh, inv_keep);
 }
 __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned stream, unsigned long long idx,
                                             unsigned thresh, float inv_keep) {
   return drop_scale_key(rng_key(seed, stream, (unsigned)(idx >> 32)), (unsigned)idx, thresh, inv_keep);
 }
-// factors of the four consecutive elements lo0 .. lo0+3 (lo0 a multiple of 4, same key): two hashes
+// factors of the four consecutive elements lo0 .. lo0+3 (lo0 a multiple of 4, same key): two hashes, or one
+template <int BITS>
+__device__ __forceinline__ void drop_scale4_t(unsigned key, unsigned lo0, unsigned thresh, float inv_keep, float (&m)[4]) {
+  if constexpr (BITS == 8) {
+    const unsigned t8 = thresh >> 24;
+    const unsigned h = mix32((lo0 >> 2) ^ key);
+    m[0] = (h & 0xffu) >= t8 ? inv_keep : 0.f;
+    m[1] = ((h >> 8) & 0xffu) >= t8 ? inv_keep : 0.f;
+    m[2] = ((h >> 16) & 0xffu) >= t8 ? inv_keep : 0.f;
+    m[3] = (h >> 24) >= t8 ? inv_keep : 0.f;
+  } else {
+    const unsigned t16 = thresh >> 16;
+    const unsigned h0 = mix32((lo0 >> 1) ^ key), h1 = mix32(((lo0 >> 1) + 1u) ^ key);
+    m[0] = (h0 & 0xffffu) >= t16 ? inv_keep : 0.f;
+    m[1] = (h0 >> 16) >= t16 ? inv_keep : 0.f;
+    m[2] = (h1 & 0xffffu) >= t16 ? inv_keep : 0.f;
+    m[3] = (h1 >> 16) >= t16 ? inv_keep : 0.f;
+  }
+}
 __device__ __forceinline__ void drop_scale4(unsigned key, unsigned lo0, unsigned thresh, float inv_keep, float (&m)[4]) {
-  const unsigned t16 = thresh >> 16;
-  const unsigned h0 = mix32((lo0 >> 1) ^ key), h1 = mix32(((lo0 >> 1) + 1u) ^ key);
-  m[0] = (h0 & 0xffffu) >= t16 ? inv_keep : 0.f;
-  m[1] = (h0 >> 16) >= t16 ? inv_keep : 0.f;
-  m[2] = (h1 & 0xffffu) >= t16 ? inv_keep : 0.f;
-  m[3] = (h1 >> 16) >= t16 ? inv_keep : 0.f;
+  if (drop_bits8(thresh)) drop_scale4_t<8>(key, lo0, thresh, inv_keep, m);
+  else drop_scale4_t<16>(key, lo0, thresh, inv_keep, m);
 }
 // Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used on the path: on virtual-memory-managed
 // allocations (hipMemCreate/hipMemMap: the debug fence allocator of tools/guard_alloc.cpp, torch's expandable segments)

@@ -293,7 +293,7 @@ struct EfArgs {
 };
 
 // Forward.  HD = head dim (16 or 32).  One workgroup = 8 waves = 8 wave tiles of 32 token slots per iteration.
-template <int HD, bool DROP>
+template <int HD, int DROP /* 0 = off, else hash bits per element: 16 | 8 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf0 = smem;
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
             const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
             const unsigned lo = lo0 + (unsigned)(key - row_lo);
             const unsigned kk = lo < (unsigned)blk0 ? key1 : key0;       // carry into the high word
-            st[i] *= inv * drop_scale_key(kk, lo, a.thresh, a.inv_keep);
+            st[i] *= inv * drop_scale_key_t<DROP ? DROP : 16>(kk, lo, a.thresh, a.inv_keep);
           }
         } else {
 #pragma unroll
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BO + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
           float dm[4];
-          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
+          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * g + j;
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
           float dm[4];
-          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
+          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B2 + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
           float dm[4];
-          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
+          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * g + j;
@@ -661,7 +661,7 @@ __device__ __forceinline__ ef_f32x8 ef_ln_bwd_apply(ef_v8bf d, ef_v8bf zz, float
   return o;
 }
 
-template <bool DROP>
+template <int DROP /* 0 = off, else hash bits per element: 16 | 8 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf0 = smem;
@@ -739,8 +739,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         dzf[f] = __builtin_convertvector(dz, ef_v8bf);
         if constexpr (DROP) {
           float dm0[4], dm1[4];
-          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
-          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
+          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
+          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { dz[j] *= dm0[j]; dz[4 + j] *= dm1[j]; }
           gf[f] = __builtin_convertvector(dz, ef_v8bf);
@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
           const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
           const float bb[4] = {b.x, b.y, b.z, b.w};
           float dm[4];
-          if constexpr (DROP) drop_scale4(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
+          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
@@ -892,7 +892,7 @@ __device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* s
   }
 }
 
-template <bool DROP>
+template <int DROP /* 0 = off, else hash bits per element: 16 | 8 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* wbuf0 = smem;
@@ -953,8 +953,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
         zf[f] = __builtin_convertvector(dxp, ef_v8bf);
         if constexpr (DROP) {
           float dm0[4], dm1[4];
-          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
-          drop_scale4(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
+          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
+          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { dz[j] *= dm0[j]; dz[4 + j] *= dm1[j]; }
         }
@@ -1046,7 +1046,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
           for (int i = 0; i < 16; ++i) {
             const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
             const unsigned lo = lo0 + (unsigned)(key - row_lo);
-            pd[i] *= drop_scale_key(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
+            pd[i] *= drop_scale_key_t<DROP ? DROP : 16>(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
           }
         }
         const ef_v8bf pd0 = ef_pack<0>(pd), pd1 = ef_pack<1>(pd);
@@ -1076,7 +1076,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
           for (int i = 0; i < 16; ++i) {
             const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
             const unsigned lo = lo0 + (unsigned)(key - row_lo);
-            dp[i] *= drop_scale_key(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
+            dp[i] *= drop_scale_key_t<DROP ? DROP : 16>(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
           }
         }
         float delta = 0.f;
@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
           dl2[i] = dls[j];
           if constexpr (DROP) {
             const unsigned lo = (unsigned)blk0 + (unsigned)((q - row_lo) * S + (tl - row_lo));
-            m2[i] = drop_scale_key(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
+            m2[i] = drop_scale_key_t<DROP ? DROP : 16>(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
           } else {
             m2[i] = 1.f;
           }
@@ -1378,19 +1378,24 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
   const long long slots = (long long)n_cu * (EF_DBUF ? 1 : 2);
   const unsigned grid = (unsigned)(n_it < slots ? n_it : slots);
   const size_t lds = EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  // DROP template value: 0 = no dropout, else the hash bits per element the threshold allows (common.hpp)
+  const int drop = a.thresh == 0u ? 0 : (drop_bits8(a.thresh) ? 8 : 16);
+#define EF_LAUNCH_FWD(HD_, DR_)                                                                                \
+  {                                                                                                            \
+    static bool attr_done = false;                                                                             \
+    if (!attr_done) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<HD_, DR_>),                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      attr_done = true;                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL((k_encoder_fwd<HD_, DR_>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);  \
   }
-  const bool drop = a.thresh != 0u;
-  if (H == 4 && drop) hipLaunchKernelGGL((k_encoder_fwd<32, true>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
-  else if (H == 4) hipLaunchKernelGGL((k_encoder_fwd<32, false>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
-  else if (drop) hipLaunchKernelGGL((k_encoder_fwd<16, true>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_encoder_fwd<16, false>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
+  if (H == 4) {
+    if (drop == 0) EF_LAUNCH_FWD(32, 0) else if (drop == 8) EF_LAUNCH_FWD(32, 8) else EF_LAUNCH_FWD(32, 16)
+  } else {
+    if (drop == 0) EF_LAUNCH_FWD(16, 0) else if (drop == 8) EF_LAUNCH_FWD(16, 8) else EF_LAUNCH_FWD(16, 16)
+  }
+#undef EF_LAUNCH_FWD
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -1444,15 +1449,20 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
   a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   a.seed = seed; a.rs2 = rs[2]; a.rs3 = rs[3];
   const size_t lds = ef_lds_bytes();
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_ffn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_ffn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
   const unsigned grid = ef_grid(R, S);
-  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_ffn<true>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((k_encoder_bwd_ffn<false>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);
+  const int drop = a.thresh == 0u ? 0 : (drop_bits8(a.thresh) ? 8 : 16);      // DROP template value (common.hpp)
+#define EF_LAUNCH_B(DR_)                                                                                       \
+  {                                                                                                            \
+    static bool attr_done = false;                                                                             \
+    if (!attr_done) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_ffn<DR_>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      attr_done = true;                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL((k_encoder_bwd_ffn<DR_>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);                    \
+  }
+  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
+#undef EF_LAUNCH_B
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -1505,15 +1515,20 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
   a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1];
   const size_t lds = ef_lds_bytes();
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
   const unsigned grid = ef_grid(R, S);
-  if (a.thresh) hipLaunchKernelGGL((k_encoder_bwd_attn<true>), dim3(grid), dim3(EF_THREADS), lds, st, a);
-  else hipLaunchKernelGGL((k_encoder_bwd_attn<false>), dim3(grid), dim3(EF_THREADS), lds, st, a);
+  const int drop = a.thresh == 0u ? 0 : (drop_bits8(a.thresh) ? 8 : 16);      // DROP template value (common.hpp)
+#define EF_LAUNCH_B(DR_)                                                                                       \
+  {                                                                                                            \
+    static bool attr_done = false;                                                                             \
+    if (!attr_done) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_attn<DR_>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      attr_done = true;                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL((k_encoder_bwd_attn<DR_>), dim3(grid), dim3(EF_THREADS), lds, st, a);                    \
+  }
+  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
+#undef EF_LAUNCH_B
   TG_LAUNCH_CHECK();
   return 0;
 }
