@@ -614,8 +614,8 @@ def main():
     # bytes per launch) in a few extra steps AFTER the timed region: ~80 more event pairs per step inside it would cost
     # the headline number ~0.5 ms
     if extras and args.dtype == "bf16":
-        names = ("tg_gemm_nt_bf16", "tg_gemm_tn_bf16", "tg_encoder_fwd_bf16", "tg_encoder_bwd_ffn_bf16",
-                 "tg_encoder_bwd_attn_bf16")
+        names = ("tg_gemm_nt_bf16", "tg_gemm_tn_bf16", "tg_gemm_nt_gather3_bf16", "tg_gemm_tn_gather3_bf16",
+                 "tg_encoder_fwd_bf16", "tg_encoder_bwd_ffn_bf16", "tg_encoder_bwd_attn_bf16")
         gt = ops.KernelTimer(only=names)
         ops.KernelTimer.active = gt
         run(3, args.warmup + args.steps)

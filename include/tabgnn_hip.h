@@ -240,6 +240,18 @@ int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void*
                     int64_t R, int32_t N, int32_t K, int64_t ldx, int64_t ldy, int32_t flags, float p_drop, uint64_t seed,
                     uint32_t rstream, void* stream);
 
+/* The same product with the X operand GATHERED on the fly: row r of X is [S0[i0[r]] | S1[i1[r]] | S2[i2[r]]], three
+ * 128-column sources (row pitch `stride` elements; idx NULL = row r itself) — the concatenation [x_i | x_j | e] of
+ * PNAConv.message (torch_geometric 2.5.3) / the edge update of fused.py:253-254 read from the node and edge embeddings
+ * without materialising [E,384].  K = 384.  flags: 1 ReLU | 4 Y +=.  tg_gemm_tn_gather3_bf16 is its weight gradient:
+ * out[M,384] fp32 (+)= G[R,M]^T X (M % 128 == 0), colsum = column sums of G, workspace of
+ * tg_gemm_tn_gather3_workspace_floats(R, M) floats. */
+typedef struct { const void* src[3]; const int32_t* idx[3]; int64_t stride[3]; } tg_gather3;
+int tg_gemm_nt_gather3_bf16(const tg_gather3* gs, const void* W, const float* bias, void* Y, int64_t R, int32_t N,
+                            int64_t ldy, int32_t flags, void* stream);
+int64_t tg_gemm_tn_gather3_workspace_floats(int64_t R, int32_t M);
+int tg_gemm_tn_gather3_bf16(const void* G, const tg_gather3* gs, float* out, float* colsum, float* workspace, int64_t R,
+                            int32_t M, int64_t ldg, int32_t accumulate, void* stream);
 /* GEMM + bias + dropout + residual + LayerNorm in one pass (out_proj -> norm1, linear2 -> norm2 of
  * nn.TransformerEncoderLayer, fused.py:83-92), d_model = 128:  Z = res + drop(X W^T + bias)  (kept for the backward:
  * tg_ln_bwd(a = Z, b = NULL, db != NULL) is its "z mode"),  OUT = LayerNorm(Z) * gamma + beta,  stats = (mean, rstd). */

@@ -240,14 +240,24 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn_bf16(const unsigned short* _
 // have the barrier plus the whole MFMA phase of step s+1 to land.
 // The bias gradient (column sums of G) is accumulated from the staging registers: thread t always stages chunk t & 15
 // of its rows, so it keeps 8 running sums per G tile it touches and the 32 threads of a chunk meet in LDS at the end.
-template <bool SCALED, bool WIDE_G>
+// GATHER (WIDE_G = false, N = 384): the wide operand X is never materialised — tile t (128 columns) of row r is row
+// idx[t][r] (or r when idx[t] is NULL) of src[t]: the weight gradient of tg_gemm_nt_gather3_bf16.  The slab's indices
+// (at most TN_GATHER_ROWS rows per slab) are staged in LDS behind the operand tiles once.
+struct TnGather {
+  const unsigned short* src[3];
+  const int* idx[3];
+  long long stride[3];      // row pitch of src[t] in elements
+};
+constexpr int TN_GATHER_ROWS = 2048;
+
+template <bool SCALED, bool WIDE_G, bool GATHER = false>
 __global__ void __launch_bounds__(512) k_gemm_tn_wide(const unsigned short* __restrict__ G,
                                                       const unsigned short* __restrict__ X,
                                                       float* __restrict__ partial, float* __restrict__ colsum_part,
                                                       long long R, int M, int N, long long ldg, long long ldx,
                                                       long long rows_per_slab, int tw, int tnar, int nslab,
-                                                      const float* __restrict__ scales, int mreal) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];     // [buf][W0|W1|W2|Nn][64 x 256 B] = 128 KiB
+                                                      const float* __restrict__ scales, int mreal, TnGather gth) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];     // [buf][W0|W1|W2|Nn][64 x 256 B] = 128 KiB (+ indices)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T_ = tw * tnar;
   const int slot = blockIdx.x >> 3;
@@ -263,6 +273,16 @@ __global__ void __launch_bounds__(512) k_gemm_tn_wide(const unsigned short* __re
   long long r_end = r_begin + rows_per_slab;
   if (r_end > R) r_end = R;
   const int wm = wave >> 1, wn = wave & 1;
+  int* gidx = reinterpret_cast<int*>(lds + 2 * 4 * TILE_BYTES);      // [3][TN_GATHER_ROWS]
+  if constexpr (GATHER) {
+    const int nrows = (int)(r_end - r_begin);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int* ip = gth.idx[t];
+      for (int i = tid; i < nrows; i += 512) gidx[t * TN_GATHER_ROWS + i] = ip ? ip[r_begin + i] : (int)(r_begin + i);
+    }
+    __syncthreads();
+  }
 
   f32x16 acc[3][2];
 #pragma unroll
@@ -304,6 +324,10 @@ __global__ void __launch_bounds__(512) k_gemm_tn_wide(const unsigned short* __re
         rw[K_][q] = *reinterpret_cast<const uint4*>(wb_ + (rr_ * pitchw + colw));                             \
         const float2 s2 = *reinterpret_cast<const float2*>(sb_ + rr_ * 8u);                                   \
         sc[K_][q][0] = s2.x; sc[K_][q][1] = s2.y;                                                             \
+      } else if constexpr (GATHER) {                                                                          \
+        const int li_ = (int)(rb_ - r_begin) + (int)rr_;                                                      \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                         \
+          rw[K_][t * 2 + q] = *reinterpret_cast<const uint4*>(gth.src[t] + (long long)gidx[t * TN_GATHER_ROWS + li_] * gth.stride[t] + pch * 8); \
       } else {                                                                                                \
         _Pragma("unroll") for (int t = 0; t < 3; ++t)                                                         \
           rw[K_][t * 2 + q] = *reinterpret_cast<const uint4*>(wb_ + (rr_ * pitchw + colw) + t * 256);         \
@@ -544,7 +568,7 @@ struct TnPlan {
   int kind, tm, tn, nslab;
   long long rows_per_slab;
 };
-static TnPlan tn_plan(long long R, int M, int N, bool scaled = false, int mreal = 0) {
+static TnPlan tn_plan(long long R, int M, int N, bool scaled = false, int mreal = 0, bool gather = false) {
   TnPlan p;
   const long long steps = ceil_div(R, GK);
   p.kind = 0;
@@ -561,7 +585,12 @@ static TnPlan tn_plan(long long R, int M, int N, bool scaled = false, int mreal 
     p.tn = p.kind == 1 ? N / 128 : M / 128;
     const long long tiles = (long long)p.tm * p.tn;
     long long want = tiles >= 256 ? 1 : 256 / tiles;
-    if (steps < 2 * want) p.kind = 0;                      // too few rows to pipeline: the small-tile kernel
+    if (gather) {                                          // the slab's row indices must fit their LDS table
+      const long long need = ceil_div(steps, (long long)(TN_GATHER_ROWS / GK));
+      if (want < need) want = need;
+      if (want > steps) want = steps;
+    }
+    if (steps < 2 * want && !gather) p.kind = 0;           // too few rows to pipeline: the small-tile kernel
     else {
       p.nslab = (int)want;
       p.rows_per_slab = ceil_div(steps, p.nslab) * (long long)GK;
@@ -591,6 +620,8 @@ static void tn_wide_attr() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tn_wide<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tn_wide<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tn_wide<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_tn_wide<false, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds + 3 * TN_GATHER_ROWS * (int)sizeof(int));
   done = true;
 }
 
@@ -622,17 +653,62 @@ extern "C" int tg_gemm_tn_bf16(const void* G, const void* X, float* out, float* 
     tn_wide_attr();
     hipLaunchKernelGGL((k_gemm_tn_wide<false, true>), dim3((unsigned)blocks), dim3(512), 2 * 4 * TILE_BYTES, st,
                        (const unsigned short*)G, (const unsigned short*)X, workspace, cs_part, (long long)R, M, N,
-                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0);
+                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0, TnGather{});
   } else if (pl.kind == 2) {
     tn_wide_attr();
     hipLaunchKernelGGL((k_gemm_tn_wide<false, false>), dim3((unsigned)blocks), dim3(512), 2 * 4 * TILE_BYTES, st,
                        (const unsigned short*)G, (const unsigned short*)X, workspace, cs_part, (long long)R, M, N,
-                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0);
+                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, (const float*)nullptr, 0, TnGather{});
   } else {
     hipLaunchKernelGGL(k_gemm_tn_bf16<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
                        (const unsigned short*)X, workspace, cs_part, (long long)R, M, N, (long long)ldg, (long long)ldx,
                        rps, tm, tn, nslab, (const float*)nullptr, 0);
   }
+  long long mn = (long long)M * N;
+  const int nb1 = ceil_div(ceil_div(mn, 4), 16), nb2 = colsum ? ceil_div(ceil_div(M, 4), 16) : 0;
+  hipLaunchKernelGGL(k_sum_slabs, dim3(nb1 + nb2), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
+                     workspace + (long long)nslab * mn, (long long)M, colsum, accumulate);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// out[M,384] (fp32) (+)= G[R,M]^T [S0[i0[r]] | S1[i1[r]] | S2[i2[r]]]: tg_gemm_tn_bf16 with the X operand gathered on the
+// fly (the weight gradient of tg_gemm_nt_gather3_bf16).  workspace: tg_gemm_tn_gather3_workspace_floats(R, M) floats.
+extern "C" int64_t tg_gemm_tn_gather3_workspace_floats(int64_t R, int32_t M) {
+  const TnPlan p = tn_plan(R, M, 384, false, 0, true);
+  return (int64_t)p.nslab * M * 384 + (int64_t)p.nslab * M;
+}
+
+extern "C" int tg_gemm_tn_gather3_bf16(const void* G, const tg_gather3* gs, float* out, float* colsum, float* workspace,
+                                       int64_t R, int32_t M, int64_t ldg, int32_t accumulate, void* stream) {
+  const int N = 384;
+  TG_CHECK(G && gs && out && workspace && R > 0 && M > 0 && M % 128 == 0 && ldg % 8 == 0 && ldg >= M,
+           "tg_gemm_tn_gather3_bf16: bad shape (R=%lld M=%d)", (long long)R, M);
+  TG_CHECK(R <= 2147483647LL, "tg_gemm_tn_gather3_bf16: row indices are 32-bit");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+           "tg_gemm_tn_gather3_bf16: operands must be 16-byte aligned");
+  TnGather g;
+  for (int c = 0; c < 3; ++c) {
+    TG_CHECK(gs->src[c] && gs->stride[c] >= 128 && gs->stride[c] % 8 == 0 &&
+                 (reinterpret_cast<uintptr_t>(gs->src[c]) & 15) == 0,
+             "tg_gemm_tn_gather3_bf16: source %d must be a 16-byte aligned [*, >=128] bf16 matrix", c);
+    g.src[c] = (const unsigned short*)gs->src[c];
+    g.idx[c] = gs->idx[c];
+    g.stride[c] = gs->stride[c];
+  }
+  const TnPlan pl = tn_plan(R, M, N, false, 0, true);
+  TG_CHECK(pl.kind == 2 && pl.rows_per_slab <= TN_GATHER_ROWS, "tg_gemm_tn_gather3_bf16: no plan for R=%lld M=%d",
+           (long long)R, M);
+  const int tm = pl.tm, tn = pl.tn, nslab = pl.nslab;
+  hipStream_t st = (hipStream_t)stream;
+  const long long blocks = (long long)((nslab + 7) / 8) * 8 * tm * tn;
+  TG_CHECK(blocks <= 2147483647LL, "tg_gemm_tn_gather3_bf16: too many tiles");
+  float* cs_part = colsum ? workspace + (long long)nslab * M * N : nullptr;
+  tn_wide_attr();
+  hipLaunchKernelGGL((k_gemm_tn_wide<false, false, true>), dim3((unsigned)blocks), dim3(512),
+                     2 * 4 * TILE_BYTES + 3 * TN_GATHER_ROWS * sizeof(int), st, (const unsigned short*)G,
+                     (const unsigned short*)nullptr, workspace, cs_part, (long long)R, M, N, (long long)ldg, 0LL,
+                     pl.rows_per_slab, tm, tn, nslab, (const float*)nullptr, 0, g);
   long long mn = (long long)M * N;
   const int nb1 = ceil_div(ceil_div(mn, 4), 16), nb2 = colsum ? ceil_div(ceil_div(M, 4), 16) : 0;
   hipLaunchKernelGGL(k_sum_slabs, dim3(nb1 + nb2), dim3(256), 0, st, workspace, nslab, mn, out, nb1,
@@ -664,7 +740,7 @@ extern "C" int tg_gemm_tn_scaled_bf16(const void* G, const void* X, const float*
     tn_wide_attr();
     hipLaunchKernelGGL((k_gemm_tn_wide<true, true>), dim3((unsigned)blocks), dim3(512), 2 * 4 * TILE_BYTES, st,
                        (const unsigned short*)G, (const unsigned short*)X, workspace, (float*)nullptr, (long long)R, M, N,
-                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, scales, mreal);
+                       (long long)ldg, (long long)ldx, rps, tm, tn, nslab, scales, mreal, TnGather{});
   } else {
     hipLaunchKernelGGL(k_gemm_tn_bf16<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const unsigned short*)G,
                        (const unsigned short*)X, workspace, (float*)nullptr, (long long)R, M, N, (long long)ldg,

@@ -59,7 +59,16 @@ __device__ __forceinline__ uint4 nt_scale8(uint4 v, float s) {   // 8 packed bf1
 // [amp*agg] / [amp*g] operands of the unfused path were).  Rescaling the accumulators instead (one scale per MFMA B
 // column) was tried first: 64 accumulators through the VALU cost 133 spilled VGPRs.
 // scales = fp32 (amp, att) per row, padded to a whole number of 128-row tiles (rows >= R are never stored).
-template <bool WIDE, bool SCALED>
+// GATHER (narrow form, K = 384): the X operand is never materialised — k chunk c (128 columns) of row r is row
+// idx[c][r] (or r when idx[c] is NULL) of src[c]: [x[ia] | x[ib] | e[ic]] of the PNA message / edge-update projections
+// read straight from the node and edge embeddings.  The row tile's 3 x 128 indices are staged in LDS once.
+struct NtGather {
+  const unsigned short* src[3];
+  const int* idx[3];
+  long long stride[3];      // row pitch of src[c] in elements
+};
+
+template <bool WIDE, bool SCALED, bool GATHER = false>
 __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* __restrict__ X,
                                                            const unsigned short* __restrict__ W,
                                                            const float* __restrict__ bias,
@@ -68,8 +77,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
                                                            long long ldx, long long ldy,
                                                            int flags, unsigned thresh, float inv_keep,
                                                            unsigned long long seed, unsigned rstream,
-                                                           const float* __restrict__ scales, int kreal) {
+                                                           const float* __restrict__ scales, int kreal, NtGather gth) {
   __shared__ __attribute__((aligned(16))) char lds[2 * NT_TILE_BYTES];   // [X image | W image] = 64 KiB
+  __shared__ int gidx[GATHER ? 3 * NT_BM : 1];
   char* xs = lds;
   char* ws = lds + NT_TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,6 +100,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
   if (row_tile * NT_BM >= R) return;
   const long long r0 = row_tile * NT_BM;
   const int wn = wave >> 1, wr = wave & 1;           // wave tile: 64 n x 64 r
+  if constexpr (GATHER) {
+    for (int i = tid; i < 3 * NT_BM; i += 256) {
+      const int c = i / NT_BM, rr = i % NT_BM;
+      const long long r = r0 + rr < R - 1 ? r0 + rr : R - 1;      // clamped: rows past R are never stored
+      const int* ip = c == 0 ? gth.idx[0] : (c == 1 ? gth.idx[1] : gth.idx[2]);
+      gidx[i] = ip ? ip[r] : (int)r;
+    }
+    __syncthreads();
+  }
 
   nt_f32x16 acc[2][2];
 #define NT_ZERO_ACC()                                                                                 \
@@ -105,8 +124,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
 #define NT_LOADX1(P, RX, K0)                                                                          \
   {                                                                                                   \
     const int row = st_row + 16 * (P);                                                                \
-    const long long r = r0 + row < rlast ? r0 + row : rlast;   /* clamped: rows past R are never stored */ \
-    RX = *reinterpret_cast<const uint4*>(X + r * ldx + (K0) + st_ch * 8);                             \
+    if constexpr (GATHER) {                                                                           \
+      const int c_ = (K0) >> 7;                                   /* uniform */                       \
+      const unsigned short* sp_ = c_ == 0 ? gth.src[0] : (c_ == 1 ? gth.src[1] : gth.src[2]);         \
+      const long long ss_ = c_ == 0 ? gth.stride[0] : (c_ == 1 ? gth.stride[1] : gth.stride[2]);      \
+      RX = *reinterpret_cast<const uint4*>(sp_ + (long long)gidx[c_ * NT_BM + row] * ss_ + st_ch * 8); \
+    } else {                                                                                          \
+      const long long r = r0 + row < rlast ? r0 + row : rlast; /* clamped: rows past R are never stored */ \
+      RX = *reinterpret_cast<const uint4*>(X + r * ldx + (K0) + st_ch * 8);                           \
+    }                                                                                                 \
   }
 #define NT_LOADW1(P, RW, N0, K0)                                                                      \
   RW = *reinterpret_cast<const uint4*>(W + (long long)((N0) + st_row + 16 * (P)) * K + (K0) + st_ch * 8);
@@ -317,7 +343,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_ln_bf16(const unsigned short
   char* xs = lds;
   char* ws = lds + NT_TILE_BYTES;
   const int N = NT_BN;
-  constexpr bool SCALED = false;                      // (the shared NT_LOAD_BIAS macro tests it)
+  constexpr bool SCALED = false, GATHER = false;      // (the shared NT_LOAD_BIAS / NT_LOADX1 macros test them)
+  const NtGather gth{};
+  const int* gidx = nullptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long row_tile = blockIdx.x;
   if (row_tile * NT_BM >= R) return;
@@ -466,15 +494,44 @@ extern "C" int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, 
     hipLaunchKernelGGL((k_gemm_nt_bf16<true, false>), dim3((unsigned)row_tiles), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
                        (unsigned short*)Y, (long long)R, N, K, (long long)ldx, (long long)ldy, flags, thresh, inv_keep,
-                       (unsigned long long)seed, rstream, (const float*)nullptr, 0);
+                       (unsigned long long)seed, rstream, (const float*)nullptr, 0, NtGather{});
   } else {
     const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
     TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_bf16: too many tiles (R=%lld)", (long long)R);
     hipLaunchKernelGGL((k_gemm_nt_bf16<false, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)X, (const unsigned short*)W, bias, (const unsigned short*)gate,
                        (unsigned short*)Y, (long long)R, N, K, (long long)ldx, (long long)ldy, flags, thresh, inv_keep,
-                       (unsigned long long)seed, rstream, (const float*)nullptr, 0);
+                       (unsigned long long)seed, rstream, (const float*)nullptr, 0, NtGather{});
   }
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Y[R,N] = epilogue([S0[i0[r]] | S1[i1[r]] | S2[i2[r]]] W[N,384]^T): tg_gemm_nt_bf16 with the X operand gathered on the
+// fly from three 128-column sources (tg_gather3: row pitch in elements, idx NULL = identity).  flags: 1 ReLU, 4 Y +=.
+extern "C" int tg_gemm_nt_gather3_bf16(const tg_gather3* gs, const void* W, const float* bias, void* Y, int64_t R, int32_t N,
+                                       int64_t ldy, int32_t flags, void* stream) {
+  TG_CHECK(gs && W && Y && R > 0 && N > 0 && N % NT_BN == 0, "tg_gemm_nt_gather3_bf16: bad shape (R=%lld N=%d)", (long long)R, N);
+  TG_CHECK(ldy % 8 == 0 && ldy >= N && (flags & ~(NT_RELU | NT_ACCUM)) == 0, "tg_gemm_nt_gather3_bf16: bad ldy / flags");
+  TG_CHECK(R <= 2147483647LL, "tg_gemm_nt_gather3_bf16: row indices are 32-bit");
+  NtGather g;
+  for (int c = 0; c < 3; ++c) {
+    TG_CHECK(gs->src[c] && gs->stride[c] >= 128 && gs->stride[c] % 8 == 0 &&
+                 (reinterpret_cast<uintptr_t>(gs->src[c]) & 15) == 0,
+             "tg_gemm_nt_gather3_bf16: source %d must be a 16-byte aligned [*, >=128] bf16 matrix", c);
+    g.src[c] = (const unsigned short*)gs->src[c];
+    g.idx[c] = gs->idx[c];
+    g.stride[c] = gs->stride[c];
+  }
+  TG_CHECK(((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0,
+           "tg_gemm_nt_gather3_bf16: operands must be 16-byte aligned");
+  const long long row_tiles = (R + NT_BM - 1) / NT_BM;
+  const long long blocks = ((row_tiles + 7) / 8) * 8 * (N / NT_BN);
+  TG_CHECK(blocks <= 2147483647LL, "tg_gemm_nt_gather3_bf16: too many tiles (R=%lld)", (long long)R);
+  hipLaunchKernelGGL((k_gemm_nt_bf16<false, false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned short*)nullptr, (const unsigned short*)W, bias, (const unsigned short*)nullptr,
+                     (unsigned short*)Y, (long long)R, N, 3 * NT_BK, 0LL, (long long)ldy, flags, 0u, 1.f, 0ull, 0u,
+                     (const float*)nullptr, 0, g);
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -498,7 +555,7 @@ extern "C" int tg_gemm_nt_scaled_bf16(const void* X, const void* W, const float*
   hipLaunchKernelGGL((k_gemm_nt_bf16<false, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                      (const unsigned short*)X, (const unsigned short*)W, (const float*)nullptr,
                      (const unsigned short*)nullptr, (unsigned short*)Y, (long long)R, N, 3 * kreal, (long long)ldx,
-                     (long long)ldy, flags, 0u, 1.f, 0ull, 0u, scales, kreal);
+                     (long long)ldy, flags, 0u, 1.f, 0ull, 0u, scales, kreal, NtGather{});
   TG_LAUNCH_CHECK();
   return 0;
 }

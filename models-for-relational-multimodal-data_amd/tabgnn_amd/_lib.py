@@ -73,6 +73,9 @@ SIGNATURES = {
     "tg_gemm_nt_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _f32, _u64, _u32, _vp],
     "tg_gemm_nt_ln_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _f32, _f32, _u64, _u32, _vp],
     "tg_gemm_tn_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
+    "tg_gemm_nt_gather3_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
+    "tg_gemm_tn_gather3_workspace_floats": [_i64, _i32],
+    "tg_gemm_tn_gather3_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
     "tg_encoder_pack_bytes": [],
     "tg_encoder_prm_floats": [],
     "tg_encoder_fused_supported": [_i32, _i32, _i32, _i32],
@@ -93,7 +96,8 @@ SIGNATURES = {
 }
 _RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,
              "tg_gemm_tn_workspace_floats": _i64, "tg_encoder_pack_bytes": _i64, "tg_encoder_prm_floats": _i64,
-             "tg_encoder_ln_grads_partials_floats": _i64, "tg_pna_fold_ws_floats": _i64}
+             "tg_encoder_ln_grads_partials_floats": _i64, "tg_pna_fold_ws_floats": _i64,
+             "tg_gemm_tn_gather3_workspace_floats": _i64}
 
 
 class EncCol(C.Structure):
@@ -110,6 +114,11 @@ class EncPtrs(C.Structure):
                 ("nr", _i32), ("num_mean", _vp), ("num_std", _vp), ("num_w", _vp), ("num_b", _vp),
                 ("cat_table", _vp), ("ts_min_year", _vp), ("ts_w", _vp), ("ts_b", _vp), ("rel_w", _vp),
                 ("rel_b", _vp), ("row_ids", _vp)]
+
+
+class Gather3(C.Structure):
+    """tg_gather3: three 128-column bf16 row sources, optional int32 row indices, row pitches in elements."""
+    _fields_ = [("src", _vp * 3), ("idx", _vp * 3), ("stride", _i64 * 3)]
 
 
 class FoldParams(C.Structure):

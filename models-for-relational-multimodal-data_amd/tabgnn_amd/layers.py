@@ -162,7 +162,7 @@ class PNAConv(nn.Module):
         # messages are produced directly in destination-sorted order: the aggregation then streams contiguous rows
         if sink_x is not None and not self.sinks_ok(x):
             raise RuntimeError("PNAConv: gradient sinks need the scaled post projection path (ask sinks_ok first)")
-        h = ops.linear(ops.edge_gather(x, edge_attr, g, "dst_sorted", sink_x, sink_e), w_msg, b_msg)
+        h = ops.edge_linear(x, edge_attr, g, "dst_sorted", w_msg, b_msg, sink_x, sink_e)
         agg = ops.pna_aggregate(h, g, sorted_rows=True)                 # [N,4F]
         if ops.post_scaled_ok(x, agg):          # scalers inside the GEMMs: G [N,3F] and its gradient never exist
             return ops.pna_post_scaled(x, w_x, b_eff, agg, w_st, g, self.aggr_module.avg_deg_log, sink_x)

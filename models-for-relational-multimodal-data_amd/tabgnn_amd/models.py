@@ -108,8 +108,7 @@ class FTTransformerPNAFusedLayer(nn.Module):
         conv = self.gnn_conv(x_gnn, g, edge_attr, sx, se) if sx is not None else self.gnn_conv(x_gnn, g, edge_attr)
         x_gnn = self.gnn_norm(conv, res=x_gnn, relu=True, alpha=0.5, beta_c=0.5, sink_res=sx)
         # (e + MLP([x[src], x[dst], e])) / 2   (fused.py:253-254)
-        upd = ops.mlp_relu(ops.edge_gather(x_gnn, edge_attr, g, "src", sn, se), self.gnn_edge_update[0],
-                           self.gnn_edge_update[2])
+        upd = ops.edge_mlp_relu(x_gnn, edge_attr, g, "src", self.gnn_edge_update[0], self.gnn_edge_update[2], sn, se)
         edge_attr = ops.axpby(edge_attr, upd, 0.5, 0.5, sink_a=se)
         if not lp:
             seeds = ops.SeedIndex(target_edge_index, N)
@@ -121,7 +120,10 @@ class FTTransformerPNAFusedLayer(nn.Module):
             h = ops.linear(h, f[7].weight, f[7].bias)
             xf = ops.layer_norm(h, self.fuse_norm.weight, self.fuse_norm.bias, res=xf0, alpha=0.5, beta_c=0.5)
             x_tab = ops.cls_merge(x_tab, xf)                                        # fused.py:259-260
-            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=True, sink_x=sn)   # fused.py:261-268
+            # in place (as fused.py:268) unless the gather-fused edge update above kept x_gnn for its backward (it reads
+            # x[src], x[dst] again for dW instead of a saved [E,384] concatenation): then the pooled rows go to a copy
+            saved = ops.gather_gemm_ok(x_gnn, edge_attr, self.nhidden, 3 * self.nhidden) and torch.is_grad_enabled()
+            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=not saved, sink_x=sn)   # fused.py:261-268
         return x_tab, x_gnn, edge_attr
 
 
@@ -223,7 +225,7 @@ class PNALayer(nn.Module):
     def forward(self, x_gnn, edge_index, edge_attr):                                        # tabgnn.py:187-191
         g = ops.SubgraphIndex.build(edge_index, x_gnn.shape[0])
         x_gnn = self.gnn_norm(self.gnn_conv(x_gnn, g, edge_attr), res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
-        upd = ops.mlp_relu(ops.edge_gather(x_gnn, edge_attr, g, "src"), self.gnn_edge_update[0], self.gnn_edge_update[2])
+        upd = ops.edge_mlp_relu(x_gnn, edge_attr, g, "src", self.gnn_edge_update[0], self.gnn_edge_update[2])
         return x_gnn, ops.axpby(edge_attr, upd, 1.0, 0.5)  # e + MLP/2 (sic)
 
 
@@ -303,7 +305,7 @@ class FTTransformerPNAInterleavedLayer(nn.Module):
         edge_attr = self.tab_conv(edge_attr, self.tab_norm, 1.0, 0.5)          # e + LN(enc(e)) / 2   (sic, :217)
         cls = edge_attr[:, 0, :].contiguous()
         x_gnn = self.gnn_norm(self.gnn_conv(x_gnn, g, cls), res=x_gnn, relu=True, alpha=0.5, beta_c=0.5)
-        upd = ops.mlp_relu(ops.edge_gather(x_gnn, cls, g, "src"), self.gnn_edge_update[0], self.gnn_edge_update[2])
+        upd = ops.edge_mlp_relu(x_gnn, cls, g, "src", self.gnn_edge_update[0], self.gnn_edge_update[2])
         cls = ops.axpby(cls, upd, 0.5, 0.5)
         return x_gnn, torch.cat([cls.unsqueeze(1), edge_attr[:, 1:, :]], dim=1)
 
@@ -392,7 +394,7 @@ class PNAS(nn.Module):
         for i in range(self.num_gnn_layers):
             x = self.batch_norms[i](self.convs[i](x, g, e), res=x, relu=True, alpha=0.5, beta_c=0.5)
             if self.edge_updates:
-                e = ops.axpby(e, ops.mlp_relu(ops.edge_gather(x, e, g, "src"), self.emlps[i][0], self.emlps[i][2]), 1.0, 0.5)
+                e = ops.axpby(e, ops.edge_mlp_relu(x, e, g, "src", self.emlps[i][0], self.emlps[i][2]), 1.0, 0.5)
         return x, e
 
 
@@ -431,7 +433,7 @@ class CPNA(nn.Module):
                 x = self.col_batch_norms[c][i](self.col_convs[c][i](x, g, col), res=x, relu=True, alpha=0.5, beta_c=0.5)
                 if self.edge_updates:
                     mlp = self.col_emlps[c][i]
-                    col = ops.axpby(col, ops.mlp_relu(ops.edge_gather(x, col, g, "src"), mlp[0], mlp[2]), 1.0, 0.5)
+                    col = ops.axpby(col, ops.edge_mlp_relu(x, col, g, "src", mlp[0], mlp[2]), 1.0, 0.5)
             cols.append(col)
         return x, torch.stack(cols, dim=1)
 
@@ -464,5 +466,5 @@ class GINe(nn.Module):
         for i in range(self.num_gnn_layers):
             x = self.batch_norms[i](self.convs[i](x, g, e), res=x, relu=True, alpha=0.5, beta_c=0.5)
             if self.edge_updates:
-                e = ops.axpby(e, ops.mlp_relu(ops.edge_gather(x, e, g, "src"), self.emlps[i][0], self.emlps[i][2]), 1.0, 0.5)
+                e = ops.axpby(e, ops.edge_mlp_relu(x, e, g, "src", self.emlps[i][0], self.emlps[i][2]), 1.0, 0.5)
         return x, e

@@ -708,35 +708,166 @@ class _EdgeGather(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
-        graph, F = ctx.graph, ctx.F
-        if ctx.first == "dst_sorted":
-            sv = graph.sorted_view()
-            csr_a, csr_b = (graph.by_dst[0], sv["arange"]), (graph.by_src[0], sv["src_to_sorted"])
-        else:
-            csr_a, csr_b = (graph.by_dst, graph.by_src) if ctx.first == "dst" else (graph.by_src, graph.by_dst)
-        sink_x, sink_e = ctx.sinks
-        dx, acc_x, ret_x = _sink_target(sink_x, (graph.N, F), g.dtype, g.device)
-        hub = torch.empty(L.load().tg_segment_hub_ints(2 * graph.E), dtype=torch.int32, device=g.device)
-        L.call("tg_segment_sum2", L.ptr(g), g.shape[1], 0, L.ptr(csr_a[0]), L.ptr(csr_a[1]), F, L.ptr(csr_b[0]),
-               L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.ptr(hub), acc_x, L.dt(g), L.stream())
-        tail = g[:, 2 * F:]
-        if sink_e is not None and ctx.We % 8 == 0:     # the edge third goes straight into e's shared gradient buffer
-            de, acc_e, ret_e = sink_e.target((g.shape[0], ctx.We), g.dtype, g.device)
-            idx = sv["inv"] if ctx.first == "dst_sorted" else None
-            L.call("tg_rows_add", L.ptr(de), tail.data_ptr(), L.ptr(idx), g.shape[0], ctx.We, g.stride(0), acc_e, L.dt(g),
-                   L.stream())
-            de = de if ret_e else None
-        elif ctx.first == "dst_sorted":        # de[edge] = g[inv[edge], 2F:]: one row gather back to edge order
-            de = _gather3([(tail, sv["inv"], ctx.We, 0), (tail, None, 0, 0), (tail, None, 0, 0)], g.shape[0], g.dtype,
-                          g.device)
-        else:
-            de = tail                       # a view: autograd's accumulation reads it strided, no [E,F] copy
-        return (dx if ret_x else None), de, None, None, None, None
+        dx, de = _edge_gather_backward(g.contiguous(), ctx.graph, ctx.first, ctx.F, ctx.We, ctx.sinks)
+        return dx, de, None, None, None, None
+
+
+def _edge_gather_backward(g, graph, first, F, We, sinks):
+    """(dx, de) from g = d[x[ia] | x[ib] | e[ic]] ([E, 2F+We], contiguous): the node part by a deterministic segmented
+    sum over the two CSRs, the edge part as a column block (row-gathered back to edge order for the destination-sorted
+    layout).  With sinks (GradSink) the parts are added into the shared buffers and None is returned for a buffer that
+    another consumer already handed to autograd."""
+    if first == "dst_sorted":
+        sv = graph.sorted_view()
+        csr_a, csr_b = (graph.by_dst[0], sv["arange"]), (graph.by_src[0], sv["src_to_sorted"])
+    else:
+        csr_a, csr_b = (graph.by_dst, graph.by_src) if first == "dst" else (graph.by_src, graph.by_dst)
+    sink_x, sink_e = sinks
+    dx, acc_x, ret_x = _sink_target(sink_x, (graph.N, F), g.dtype, g.device)
+    hub = torch.empty(L.load().tg_segment_hub_ints(2 * graph.E), dtype=torch.int32, device=g.device)
+    L.call("tg_segment_sum2", L.ptr(g), g.shape[1], 0, L.ptr(csr_a[0]), L.ptr(csr_a[1]), F, L.ptr(csr_b[0]),
+           L.ptr(csr_b[1]), 0, None, L.ptr(dx), graph.N, F, L.ptr(hub), acc_x, L.dt(g), L.stream())
+    tail = g[:, 2 * F:]
+    if sink_e is not None and We % 8 == 0:     # the edge third goes straight into e's shared gradient buffer
+        de, acc_e, ret_e = sink_e.target((g.shape[0], We), g.dtype, g.device)
+        idx = sv["inv"] if first == "dst_sorted" else None
+        L.call("tg_rows_add", L.ptr(de), tail.data_ptr(), L.ptr(idx), g.shape[0], We, g.stride(0), acc_e, L.dt(g),
+               L.stream())
+        de = de if ret_e else None
+    elif first == "dst_sorted":        # de[edge] = g[inv[edge], 2F:]: one row gather back to edge order
+        de = _gather3([(tail, sv["inv"], We, 0), (tail, None, 0, 0), (tail, None, 0, 0)], g.shape[0], g.dtype, g.device)
+    else:
+        de = tail                       # a view: autograd's accumulation reads it strided, no [E,F] copy
+    return (dx if ret_x else None), de
 
 
 def edge_gather(x, e, graph, first, sink_x=None, sink_e=None):
     return _EdgeGather.apply(x, e, graph, first, sink_x, sink_e)
+
+
+_GATHER_GEMM = os.environ.get("TABGNN_NO_GATHER_GEMM") != "1"
+
+
+def gather_gemm_ok(x, e, n_out, k_w):
+    """The shapes tg_gemm_nt_gather3_bf16 / tg_gemm_tn_gather3_bf16 take: bf16 rows on the MI355X, node and edge width
+    128 (three 128-column sources, K = 384), output width a multiple of 128."""
+    return (_GATHER_GEMM and x.is_cuda and x.dtype == torch.bfloat16 and e.dtype == torch.bfloat16 and x.dim() == 2
+            and e.dim() == 2 and x.shape[1] == 128 and e.shape[1] == 128 and k_w == 384 and n_out % 128 == 0
+            and e.shape[0] > 0)
+
+
+def _gather_spec(x, e, graph, first):
+    """tg_gather3 of [x[ia] | x[ib] | e[ic]] (see _EdgeGather.forward for ``first``); x, e contiguous bf16."""
+    if first == "dst_sorted":
+        sv = graph.sorted_view()
+        idx = (sv["dst"], sv["src"], sv["perm"])
+    else:
+        ia, ib = (graph.dst, graph.src) if first == "dst" else (graph.src, graph.dst)
+        idx = (ia, ib, None)
+    gs = L.Gather3()
+    for c, (t, i) in enumerate(((x, idx[0]), (x, idx[1]), (e, idx[2]))):
+        gs.src[c] = t.data_ptr()
+        gs.idx[c] = None if i is None else i.data_ptr()
+        gs.stride[c] = t.stride(0)
+    return gs
+
+
+def _gather_weight_grad(g2, gs, E, wparam, bparam):
+    """(dW [M,384], db [M]) = (g2^T [x[ia]|x[ib]|e[ic]], column sums of g2), accumulated into the parameters' gradient
+    buffers when they own one (then (None, None))."""
+    M = g2.shape[1]
+    wg, bg = _grad_target(wparam), _grad_target(bparam)
+    acc = wg is not None and bg is not None and wg.shape == (M, 384)
+    out = wg if acc else torch.empty(M, 384, dtype=torch.float32, device=g2.device)
+    db = bg if acc else torch.empty(M, dtype=torch.float32, device=g2.device)
+    ws = _workspace(L.load().tg_gemm_tn_gather3_workspace_floats(E, M), g2.device)
+    _launch("tg_gemm_tn_gather3_bf16", g2.data_ptr(), C.byref(gs), L.ptr(out), L.ptr(db), L.ptr(ws), E, M, g2.stride(0),
+            int(acc), L.stream(), nbytes=2 * E * (M + 384))
+    return (None, None) if acc else (out, db)
+
+
+class _GatherLinear(torch.autograd.Function):
+    """y = [x[ia] | x[ib] | e[ic]] W^T + b for all edges with the concatenation gathered inside the GEMMs
+    (tg_gemm_nt_gather3_bf16 forward, tg_gemm_tn_gather3_bf16 for dW): the [E,384] operand of PNAConv.message never
+    exists, forward or backward; only its gradient does (the segmented sums read it)."""
+
+    @staticmethod
+    def forward(ctx, x, e, weight, bias, graph, first, w_lp, sink_x, sink_e):
+        x, e = x.contiguous(), e.contiguous()
+        E, N = e.shape[0], w_lp.shape[0]
+        gs = _gather_spec(x, e, graph, first)
+        y = torch.empty(E, N, dtype=x.dtype, device=x.device)
+        _launch("tg_gemm_nt_gather3_bf16", C.byref(gs), L.ptr(w_lp.contiguous()), L.ptr(bias.detach().float()), L.ptr(y), E, N,
+                N, 0, L.stream(), nbytes=2 * E * (384 + N))
+        ctx.save_for_backward(x, e, w_lp)
+        ctx.cfg = (graph, first, (sink_x, sink_e))
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e, w_lp = ctx.saved_tensors
+        graph, first, sinks = ctx.cfg
+        weight, bias = ctx.params
+        isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
+        g = g.contiguous()
+        dw, db = _gather_weight_grad(g, _gather_spec(x, e, graph, first), e.shape[0], isp(weight), isp(bias))
+        d_cat = gemm_nt(g, wt(w_lp, weight))                                   # [E,384]
+        dx, de = _edge_gather_backward(d_cat, graph, first, x.shape[1], e.shape[1], sinks)
+        return dx, de, dw, db, None, None, None, None, None
+
+
+def edge_linear(x, e, graph, first, weight, bias, sink_x=None, sink_e=None):
+    """``linear([x[ia] | x[ib] | e[ic]], weight, bias)`` for all edges of ``graph`` (``first`` as in edge_gather)."""
+    if bias is not None and gather_gemm_ok(x, e, weight.shape[0], weight.shape[1]):
+        return _GatherLinear.apply(x, e, weight, bias, graph, first, shadow(weight, x.dtype), sink_x, sink_e)
+    return linear(edge_gather(x, e, graph, first, sink_x, sink_e), weight, bias)
+
+
+class _MLPReluGather(torch.autograd.Function):
+    """lin2(relu(lin0([x[ia] | x[ib] | e[ic]]))) — the edge update (fused.py:253-254) — with the concatenation gathered
+    inside the first layer's GEMMs (see _GatherLinear) and the rest as _MLPRelu."""
+
+    @staticmethod
+    def forward(ctx, x, e, w0, b0, w2, b2, graph, first, lw0, lw2, sink_x, sink_e):
+        x, e = x.contiguous(), e.contiguous()
+        E, H = e.shape[0], lw0.shape[0]
+        gs = _gather_spec(x, e, graph, first)
+        m = torch.empty(E, H, dtype=x.dtype, device=x.device)
+        _launch("tg_gemm_nt_gather3_bf16", C.byref(gs), L.ptr(lw0.contiguous()), L.ptr(b0.detach().float()), L.ptr(m), E, H,
+                H, NT_RELU, L.stream(), nbytes=2 * E * (384 + H))
+        y = gemm_nt(m, lw2, b2.detach())
+        ctx.save_for_backward(x, e, m, lw0, lw2)
+        ctx.cfg = (graph, first, (sink_x, sink_e))
+        ctx.params = (w0, b0, w2, b2)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, e, m, lw0, lw2 = ctx.saved_tensors
+        graph, first, sinks = ctx.cfg
+        w0, b0, w2, b2 = ctx.params
+        isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
+        g2 = g.contiguous()
+        dw2, db2 = weight_grad(g2, m, True, isp(w2), isp(b2))
+        if db2 is None and dw2 is not None:
+            db2 = g2.sum(0, dtype=torch.float32)
+        d_pre = gemm_nt(g2, wt(lw2, w2), None, NT_GATE, 0.0, gate=m)            # (g W2) where relu was active
+        dw0, db0 = _gather_weight_grad(d_pre, _gather_spec(x, e, graph, first), e.shape[0], isp(w0), isp(b0))
+        d_cat = gemm_nt(d_pre, wt(lw0, w0))                                     # [E,384]
+        dx, de = _edge_gather_backward(d_cat, graph, first, x.shape[1], e.shape[1], sinks)
+        return dx, de, dw0, db0, dw2, db2, None, None, None, None, None, None
+
+
+def edge_mlp_relu(x, e, graph, first, lin0, lin2, sink_x=None, sink_e=None):
+    """``lin2(relu(lin0([x[ia] | x[ib] | e[ic]])))`` for all edges (two ``nn.Linear`` modules)."""
+    H, K = lin0.weight.shape
+    if (lin0.bias is not None and lin2.bias is not None and H == 128 and lin2.weight.shape[0] == 128
+            and gather_gemm_ok(x, e, H, K)):
+        dt = x.dtype
+        return _MLPReluGather.apply(x, e, lin0.weight, lin0.bias, lin2.weight, lin2.bias, graph, first,
+                                    shadow(lin0.weight, dt), shadow(lin2.weight, dt), sink_x, sink_e)
+    return mlp_relu(edge_gather(x, e, graph, first, sink_x, sink_e), lin0, lin2)
 
 
 class _SeedGather(torch.autograd.Function):
