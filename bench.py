@@ -629,10 +629,18 @@ def main():
                                "algorithmic_bytes_per_step": gt.nbytes[name] / 3}
         if pmc is not None:      # counter bytes / algorithmic bytes of the weight-gradient kernel (incl. its slab reduction)
             kk = pmc["kernels"]
-            tn = [kk[k] for k in kk if "k_gemm_tn_bf16<false>" in k]
+            # kernels behind tg_gemm_tn_bf16: the 128x128-tile kernel and the two unscaled, ungathered wide variants; the
+            # slab reduction is shared with the scaled / gathered entry points: its bytes are split by launch count
+            tn = [kk[k] for k in kk if "k_gemm_tn_bf16<false>" in k or "k_gemm_tn_wide<false, true, false>" in k
+                  or "k_gemm_tn_wide<false, false, false>" in k]
+            oth = [kk[k] for k in kk if "k_gemm_tn_wide<true" in k or "k_gemm_tn_wide<false, false, true>" in k
+                   or "k_gemm_tn_bf16<true>" in k]
             sl = [kk[k] for k in kk if "k_sum_slabs" in k]
             if tn and "tg_gemm_tn_bf16" in gemms:
-                cnt = tn[0]["hbm_bytes_per_launch"] * tn[0]["launches"] + (sl[0]["hbm_bytes_per_launch"] * sl[0]["launches"] if sl else 0)
+                n_tn, n_oth = sum(t["launches"] for t in tn), sum(t["launches"] for t in oth)
+                cnt = sum(t["hbm_bytes_per_launch"] * t["launches"] for t in tn)
+                if sl:
+                    cnt += sl[0]["hbm_bytes_per_launch"] * sl[0]["launches"] * n_tn / max(n_tn + n_oth, 1)
                 steps_profiled = pmc.get("steps_profiled", 6)
                 gemms["tg_gemm_tn_bf16"]["counter_over_algorithmic"] = cnt / steps_profiled / gemms["tg_gemm_tn_bf16"]["algorithmic_bytes_per_step"]
                 gemms["tg_gemm_tn_bf16"]["counter_source"] = pmc_path

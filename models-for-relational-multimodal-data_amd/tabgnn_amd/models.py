@@ -120,10 +120,12 @@ class FTTransformerPNAFusedLayer(nn.Module):
             h = ops.linear(h, f[7].weight, f[7].bias)
             xf = ops.layer_norm(h, self.fuse_norm.weight, self.fuse_norm.bias, res=xf0, alpha=0.5, beta_c=0.5)
             x_tab = ops.cls_merge(x_tab, xf)                                        # fused.py:259-260
-            # in place (as fused.py:268) unless the gather-fused edge update above kept x_gnn for its backward (it reads
-            # x[src], x[dst] again for dW instead of a saved [E,384] concatenation): then the pooled rows go to a copy
-            saved = ops.gather_gemm_ok(x_gnn, edge_attr, self.nhidden, 3 * self.nhidden) and torch.is_grad_enabled()
-            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=not saved, sink_x=sn)   # fused.py:261-268
+            # in place, as fused.py:268.  The gather-fused edge update above re-reads x_gnn in its backward (x[src], x[dst]
+            # for dW instead of a saved [E,384] concatenation): the pool stashes the <= 2B rows it overwrites and that
+            # backward puts them back first (ops._MLPReluGather); TABGNN_NO_POOL_RESTORE=1 pools into a copy instead.
+            reread = ops.gather_gemm_ok(x_gnn, edge_attr, self.nhidden, 3 * self.nhidden) and torch.is_grad_enabled()
+            x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=not reread or ops.POOL_RESTORE, sink_x=sn,
+                                  stash=reread and ops.POOL_RESTORE)                 # fused.py:261-268
         return x_tab, x_gnn, edge_attr
 
 

@@ -837,14 +837,25 @@ class _MLPReluGather(torch.autograd.Function):
         _launch("tg_gemm_nt_gather3_bf16", C.byref(gs), L.ptr(lw0.contiguous()), L.ptr(b0.detach().float()), L.ptr(m), E, H,
                 H, NT_RELU, L.stream(), nbytes=2 * E * (384 + H))
         y = gemm_nt(m, lw2, b2.detach())
-        ctx.save_for_backward(x, e, m, lw0, lw2)
+        # x is held by plain reference, not save_for_backward: the fused layer pools the seed-endpoint rows of this very
+        # tensor IN PLACE afterwards (fused.py:268); the backward below first puts the pre-pool rows back (_SeedPool
+        # stashed them on the tensor), which is safe because every reader of the pooled values — the next layer's
+        # nodes — is upstream of this node in the backward graph and has run by then.
+        ctx.save_for_backward(e, m, lw0, lw2)
+        ctx.x_ref = x
         ctx.cfg = (graph, first, (sink_x, sink_e))
         ctx.params = (w0, b0, w2, b2)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, e, m, lw0, lw2 = ctx.saved_tensors
+        e, m, lw0, lw2 = ctx.saved_tensors
+        x = ctx.x_ref
+        patch = getattr(x, "_pool_patch", None)
+        if patch is not None:
+            with torch.no_grad():
+                x.index_copy_(0, patch[0], patch[1])
+            x._pool_patch = None
         graph, first, sinks = ctx.cfg
         w0, b0, w2, b2 = ctx.params
         isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
@@ -1289,12 +1300,15 @@ class _SeedPool(torch.autograd.Function):
     """x_gnn with every seed endpoint averaged with the mean of its fused embeddings (fused.py:261-268)."""
 
     @staticmethod
-    def forward(ctx, x, xf, seeds, C, inplace, sink_x=None):
+    def forward(ctx, x, xf, seeds, C, inplace, sink_x=None, stash=False):
         xf = xf.contiguous()
         N, F = x.shape
         ctx.seeds, ctx.cfg = seeds, (N, F, C)
         ctx.sink_x = sink_x
         if inplace and x.is_contiguous():       # touch only the <= 2B seed rows of x (fused.py:268 is in place too)
+            if stash:       # keep the rows about to change for a consumer that re-reads x in its backward (_MLPReluGather)
+                idx = seeds.tei.long()
+                x._pool_patch = (idx, x.index_select(0, idx))
             ctx.mark_dirty(x)
             L.call("tg_seed_pool_inplace", L.ptr(x), L.ptr(xf), L.ptr(seeds.tei), L.ptr(seeds.rowptr), L.ptr(seeds.perm),
                    N, F, seeds.B, C, L.dt(x), L.stream())
@@ -1319,12 +1333,19 @@ class _SeedPool(torch.autograd.Function):
                seeds.B, C, L.dt(g), L.stream())
         if add_to is not None:
             add_to.add_(dx)
-        return (dx if ret else None), dxf, None, None, None, None
+        return (dx if ret else None), dxf, None, None, None, None, None
 
 
-def seed_pool(x, xf, seeds, C, inplace=False, sink_x=None):
-    """``inplace``: update x itself (it must be an intermediate nobody saved for backward; autograd checks)."""
-    return _SeedPool.apply(x, xf, seeds, C, inplace, sink_x)
+POOL_RESTORE = os.environ.get("TABGNN_NO_POOL_RESTORE") != "1"
+
+
+def seed_pool(x, xf, seeds, C, inplace=False, sink_x=None, stash=False):
+    """``inplace``: update x itself (it must be an intermediate nobody saved for backward; autograd checks).
+    ``stash``: (in place only) keep the pre-pool rows on the tensor as ``_pool_patch`` for _MLPReluGather's backward."""
+    out = _SeedPool.apply(x, xf, seeds, C, inplace, sink_x, bool(stash and inplace))
+    if stash and inplace and out is not x:
+        out._pool_patch = getattr(x, "_pool_patch", None)
+    return out
 
 
 # --------------------------------------------------------------------------- loss

@@ -456,3 +456,32 @@ def test_gradient_sinks_give_the_gradients_of_plain_autograd_accumulation():
         # structurally zero gradients (biases in front of BatchNorm) are rounding noise in both runs: absolute floor
         assert (sa - sb).norm().item() <= 0.08 * sb.norm().item() + 1e-3 * b.norm().item(), name
         off += n
+
+
+def test_inplace_seed_pool_with_row_restore_equals_pooling_into_a_copy():
+    """The fused layer pools the seed-endpoint rows of x in place (fused.py:268) although the gather-fused edge update
+    re-reads x in its backward: the rows are stashed and put back first (ops._MLPReluGather).  Against pooling into a
+    copy (TABGNN_NO_POOL_RESTORE): same forward, and — the kernels and their inputs being the same — the same gradients
+    bit for bit, over three layers so that two of them back-propagate through their edge update."""
+    from tabgnn_amd import ops
+    T, cfg, model, batch = _setup(80, 128, 3, 4, dtype=torch.bfloat16, seed=21)
+    model.to(DEV).train()
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    lw = torch.tensor(cfg["loss_weights"], device=DEV)
+    dbatch = (batch[0].to(DEV), batch[1].to(DEV), batch[2].to(DEV))
+    y = batch[3].to(DEV)
+    res = []
+    assert ops.POOL_RESTORE
+    try:
+        for on in (True, False):
+            ops.POOL_RESTORE = on
+            ops.DropoutRNG.new_step(77)
+            flat.zero_grad()
+            out = model(*dbatch)
+            T.ops.weighted_cross_entropy(out[:80], y.view(-1), lw).backward()
+            res.append((out.detach().clone(), flat.grad.clone()))
+    finally:
+        ops.POOL_RESTORE = True
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.isfinite(res[0][1]).all() and res[0][1].abs().max() > 0
+    assert torch.equal(res[0][1], res[1][1])
