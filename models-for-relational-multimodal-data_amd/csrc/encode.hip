@@ -124,7 +124,11 @@ __global__ void __launch_bounds__(256) k_encode_fwd(EncDesc d, EncPtrs p, T* __r
 template <typename T>
 __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const T* __restrict__ g, long long R,
                                                      int ncols, int C, int acc_floats, float* __restrict__ partials,
-                                                     float* __restrict__ big_table_grad, int groups) {
+                                                     float* __restrict__ big_table_grad, int groups, int ngen) {
+  // acc_floats here = the accumulators THIS kernel owns: when the timestamp columns come last in the descriptor (the
+  // host plans them so) their 57*C slots are neither allocated in LDS nor enumerated as work items (ngen = the
+  // non-timestamp columns) — with the AML edge table (3 cat + 1 num + 1 ts) that is 21 KB instead of 50 KB of LDS
+  // per row group and 128 instead of 160 items, so two row groups fit and all 256 threads work (they were 128).
   extern __shared__ __align__(16) float acc_all[];   // [groups][acc_floats]
   for (int i = threadIdx.x; i < acc_floats * groups; i += 256) acc_all[i] = 0.f;
   __syncthreads();
@@ -133,7 +137,7 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
   // lane (2-byte loads) ran at 0.76 TB/s, request-bound.  With few columns the block is split into `groups` row
   // groups (each with its own LDS accumulators, summed in group order at the end) so that all 256 threads work.
   constexpr int V = 4;
-  const int nitems = d.ncol * (C / V);
+  const int nitems = ngen * (C / V);
   const int grp = groups > 1 ? threadIdx.x / nitems : 0;
   const int first = groups > 1 ? threadIdx.x % nitems : threadIdx.x;
   const int step = groups > 1 ? nitems : 256;                  // groups > 1  =>  one item per thread
@@ -424,7 +428,18 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
   if (d->nts < d->ncol) {
     TG_CHECK((size_t)acc_floats * sizeof(float) <= 150 * 1024,
              "tg_encode_bwd: column group needs %zu B of LDS (> 150 KiB); split the launch", (size_t)acc_floats * 4);
-    const int nitems = d->ncol * (C / 4);
+    // timestamp columns last in the descriptor => the generic kernel neither allocates nor enumerates them
+    int ngen = d->ncol, first_ts = -1;
+    bool ts_last = true;
+    for (int i = 0; i < d->ncol; ++i) {
+      if (d->col[i].kind == ENC_TS) { if (first_ts < 0) first_ts = i; }
+      else if (first_ts >= 0) ts_last = false;
+    }
+    if (ts_last && first_ts >= 0) {
+      ngen = first_ts;
+      acc_floats = d->col[first_ts].acc_off;                       // the prefix of the reduced vector this kernel owns
+    }
+    const int nitems = ngen * (C / 4);
     int groups = nitems <= 128 ? 256 / nitems : 1;                 // all 256 threads busy when the columns are few
     while (groups > 1 && (size_t)groups * acc_floats * sizeof(float) > 48 * 1024) --groups;
     size_t shm = (size_t)groups * acc_floats * sizeof(float);
@@ -432,12 +447,13 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
     if (dt == F32) {
       (void)hipFuncSetAttribute((const void*)k_encode_bwd<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       hipLaunchKernelGGL((k_encode_bwd<float>), dim3(grid), dim3(256), shm, st, *d, *p, (const float*)g, (long long)R,
-                         ncols, C, acc_floats, partials, big_table_grad, groups);
+                         ncols, C, acc_floats, partials, big_table_grad, groups, ngen);
     } else {
       (void)hipFuncSetAttribute((const void*)k_encode_bwd<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
       hipLaunchKernelGGL((k_encode_bwd<bf16_t>), dim3(grid), dim3(256), shm, st, *d, *p, (const bf16_t*)g,
-                         (long long)R, ncols, C, acc_floats, partials, big_table_grad, groups);
+                         (long long)R, ncols, C, acc_floats, partials, big_table_grad, groups, ngen);
     }
+    if (acc_floats > 0)
     hipLaunchKernelGGL(k_enc_reduce, dim3(ceil_div(acc_floats, 64)), dim3(256), 0, st, partials, grid, acc_floats,
                        dflat, (const int*)nullptr, 0);
   }

@@ -202,7 +202,8 @@ class StypeWiseFeatureEncoder(nn.Module):
             groups.append(cur)
         descs, accs, segments = [], [], []
         for grp in groups:
-            d = L.EncDesc()
+            grp = sorted(grp, key=lambda c: c["kind"] == 2)      # timestamp columns last: tg_encode_bwd's generic kernel
+            d = L.EncDesc()                                       # then skips their accumulator slots and work items
             d.ncol = len(grp)
             off, nts, segs = 0, 0, []
             for j, c in enumerate(grp):
