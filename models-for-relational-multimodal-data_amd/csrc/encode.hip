@@ -85,13 +85,14 @@ __device__ __forceinline__ void ts_features(const long long* t7, float min_year,
 // ------------------------------------------------------------------ generic columns (num / cat / rel)
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_encode_fwd(EncDesc d, EncPtrs p, T* __restrict__ out, long long R, int ncols,
-                                                     int C) {
+                                                     int C, int ngen /* columns to enumerate: the timestamp columns
+                                                     are skipped, or not even enumerated when they come last */) {
   const int vpr = C / VEC;
   for (long long r0 = (long long)blockIdx.x * ENC_RCH; r0 < R; r0 += (long long)gridDim.x * ENC_RCH) {
     int nrows = (int)((R - r0) < ENC_RCH ? (R - r0) : ENC_RCH);
-    int items = nrows * d.ncol * vpr;
+    int items = nrows * ngen * vpr;
     for (int it = threadIdx.x; it < items; it += 256) {
-      int cv = (it % vpr) * VEC, ci = (it / vpr) % d.ncol, rr = it / (vpr * d.ncol);
+      int cv = (it % vpr) * VEC, ci = (it / vpr) % ngen, rr = it / (vpr * ngen);
       const EncCol& c = d.col[ci];
       if (c.kind == ENC_TS) continue;
       long long r = r0 + rr;
@@ -379,6 +380,17 @@ static int check_desc(const EncDesc* d, int C, const char* who) {
   return 0;
 }
 
+// number of leading non-timestamp columns when ALL timestamp columns come last in the descriptor (the host plans them
+// so), else every column (the generic kernels then skip the timestamp ones item by item)
+static int enc_ngen(const tg::EncDesc* d) {
+  int first_ts = -1;
+  for (int i = 0; i < d->ncol; ++i) {
+    if (d->col[i].kind == tg::ENC_TS) { if (first_ts < 0) first_ts = i; }
+    else if (first_ts >= 0) return d->ncol;
+  }
+  return first_ts < 0 ? d->ncol : first_ts;
+}
+
 extern "C" int tg_encode_fwd(const void* desc, const void* ptrs, void* out, int64_t R, int32_t ncols, int32_t C,
                              int32_t dt, void* stream) {
   const EncDesc* d = (const EncDesc*)desc;
@@ -390,10 +402,10 @@ extern "C" int tg_encode_fwd(const void* desc, const void* ptrs, void* out, int6
     int grid = grid_cap(ceil_div(R, ENC_RCH), 256 * 8);
     if (dt == F32)
       hipLaunchKernelGGL((k_encode_fwd<float, 4>), dim3(grid), dim3(256), 0, st, *d, *p, (float*)out, (long long)R,
-                         ncols, C);
+                         ncols, C, enc_ngen(d));
     else
       hipLaunchKernelGGL((k_encode_fwd<bf16_t, 8>), dim3(grid), dim3(256), 0, st, *d, *p, (bf16_t*)out, (long long)R,
-                         ncols, C);
+                         ncols, C, enc_ngen(d));
   }
   for (int i = 0; i < d->ncol; ++i) {
     const EncCol& c = d->col[i];
@@ -429,16 +441,8 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
     TG_CHECK((size_t)acc_floats * sizeof(float) <= 150 * 1024,
              "tg_encode_bwd: column group needs %zu B of LDS (> 150 KiB); split the launch", (size_t)acc_floats * 4);
     // timestamp columns last in the descriptor => the generic kernel neither allocates nor enumerates them
-    int ngen = d->ncol, first_ts = -1;
-    bool ts_last = true;
-    for (int i = 0; i < d->ncol; ++i) {
-      if (d->col[i].kind == ENC_TS) { if (first_ts < 0) first_ts = i; }
-      else if (first_ts >= 0) ts_last = false;
-    }
-    if (ts_last && first_ts >= 0) {
-      ngen = first_ts;
-      acc_floats = d->col[first_ts].acc_off;                       // the prefix of the reduced vector this kernel owns
-    }
+    const int ngen = enc_ngen(d);
+    if (ngen < d->ncol) acc_floats = d->col[ngen].acc_off;         // the prefix of the reduced vector this kernel owns
     const int nitems = ngen * (C / 4);
     int groups = nitems <= 128 ? 256 / nitems : 1;                 // all 256 threads busy when the columns are few
     while (groups > 1 && (size_t)groups * acc_floats * sizeof(float) > 48 * 1024) --groups;
