@@ -74,6 +74,12 @@ int tg_encode_fwd(const void* desc, const void* ptrs, void* out /*[R,ncols,C]*/,
 int tg_encode_bwd(const void* desc, const void* ptrs, const void* g /*[R,ncols,C]*/, int64_t R, int32_t ncols,
                   int32_t C, int32_t acc_floats, float* dflat, float* partials, float* big_table_grad, int32_t dt,
                   void* stream);
+/* The calendar features of timestamp column src_col (TimestampEncoder: 7 fields x out_size 8 sinusoidal / cyclic
+ * values, oracle/encoders.py) as a bf16 GEMM operand feats [R,128]: columns 0..55 the features, column 56 = 1 (bias
+ * column), the rest 0; row r reads table row row_ids[r] when row_ids != NULL.  The encoder column is then
+ * tg_gemm_nt_bf16(feats, [W | b | 0]) and its parameter gradient tg_gemm_tn_bf16(g, feats). */
+int tg_encode_ts_features(const int64_t* ts, int32_t nt, int32_t src_col, const float* min_year /*[nt]*/,
+                          const int64_t* row_ids, void* feats, int64_t R, void* stream);
 /* adds segments of a reduced gradient vector into parameter gradient buffers in one launch: table int64 [nseg][3] on
  * the device = (destination float* as integer, offset into src, length).  Used by the encoder backward so that no
  * per-parameter zero-fill / slice copy / autograd add runs. */

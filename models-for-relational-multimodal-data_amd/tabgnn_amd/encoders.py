@@ -9,6 +9,7 @@ Parameter names follow upstream: ``encoder_dict.<stype>.…``.  Semantics restat
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import torch
@@ -82,6 +83,9 @@ class ProjectionEncoder(nn.Module):
         nn.init.zeros_(self.bias)
 
 
+_TS_GEMM = os.environ.get("TABGNN_NO_TS_GEMM") != "1"
+
+
 class _Encode(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, feats, out_dtype, row_ids, *params):
@@ -98,8 +102,30 @@ class _Encode(torch.autograd.Function):
         buf = torch.empty(R, S, Cc, dtype=out_dtype, device=dev)
         out = buf[:, 1:, :]
         ptrs = enc._ptrs(feats, params, row_ids)
-        for desc in plan["descs"]:
-            L.call("tg_encode_fwd", C.addressof(desc), C.addressof(ptrs), out.data_ptr(), R, S, Cc, L.dt(out), L.stream())
+        # bf16, C = 128: the timestamp columns run as GEMMs over a [R,128] feature operand (tg_encode_ts_features) — the
+        # generic kernels get the descriptor without them
+        ts_gemm = _TS_GEMM and out_dtype == torch.bfloat16 and Cc == 128 and R > 0 and any(n[2] for n in plan["nots"])
+        ts_feats = {}
+        if ts_gemm:
+            ts_w, ts_b = params[3], params[4]
+            ts_raw = feats[stype.timestamp]
+            for dn, _, ts_cols in plan["nots"]:
+                if dn.ncol > 0:
+                    L.call("tg_encode_fwd", C.addressof(dn), C.addressof(ptrs), out.data_ptr(), R, S, Cc, L.dt(out), L.stream())
+                for src_col, out_col, _ in ts_cols:
+                    f = torch.empty(R, 128, dtype=torch.bfloat16, device=dev)
+                    L.call("tg_encode_ts_features", L.ptr(ts_raw), ts_raw.shape[1], src_col, L.ptr(enc.encoder_dict["timestamp"].min_year),
+                           L.ptr(row_ids), L.ptr(f), R, L.stream())
+                    wext = torch.zeros(Cc, 128, dtype=torch.bfloat16, device=dev)          # [W | b | 0]
+                    wext[:, :56] = ts_w[src_col].detach().reshape(56, Cc).t()
+                    wext[:, 56] = ts_b[src_col].detach()
+                    L.call("tg_gemm_nt_bf16", L.ptr(f), L.ptr(wext), None, None, out.data_ptr() + 2 * out_col * Cc, R, Cc, 128,
+                           128, S * Cc, 0, 0.0, 0, 0, L.stream())
+                    ts_feats[src_col] = f
+        else:
+            for desc in plan["descs"]:
+                L.call("tg_encode_fwd", C.addressof(desc), C.addressof(ptrs), out.data_ptr(), R, S, Cc, L.dt(out), L.stream())
+        ctx.ts_feats = ts_feats if ts_gemm else None
         ctx.enc, ctx.feats, ctx.params, ctx.R, ctx.row_ids = enc, feats, params, R, row_ids
         out._cls_base = buf
         return out
@@ -119,23 +145,41 @@ class _Encode(torch.autograd.Function):
         ptrs = enc._ptrs(feats, params, ctx.row_ids)
         num_w, num_b, cat_table, ts_w, ts_b, rel_w, rel_b = params
         nblk = L.load().tg_encode_bwd_blocks()
+        ts_feats = ctx.ts_feats
+
+        def run_group(gi, desc, acc_floats, dflat, partials, big_grad):
+            """the reduced gradient vector of column group gi into dflat (layout of plan['segments'][gi])"""
+            if ts_feats is None:
+                L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), g.data_ptr(), R, row_cols, Cc, acc_floats,
+                       L.ptr(dflat), L.ptr(partials), big_grad, L.dt(g), L.stream())
+                return
+            dn, acc_gen, ts_cols = plan["nots"][gi]
+            if dn.ncol > 0:
+                L.call("tg_encode_bwd", C.addressof(dn), C.addressof(ptrs), g.data_ptr(), R, row_cols, Cc, acc_gen,
+                       L.ptr(dflat), L.ptr(partials), big_grad, L.dt(g), L.stream())
+            for src_col, out_col, off in ts_cols:       # [W | b] gradient = g_col^T feats  (column 56 of feats is 1)
+                f = ts_feats[src_col]
+                dw = torch.empty(Cc, 128, dtype=torch.float32, device=dev)
+                ws = torch.empty(max(L.load().tg_gemm_tn_workspace_floats(R, Cc, 128), 1), dtype=torch.float32, device=dev)
+                L.call("tg_gemm_tn_bf16", g.data_ptr() + 2 * out_col * Cc, L.ptr(f), L.ptr(dw), None, L.ptr(ws), R, Cc, 128,
+                       row_cols * Cc, 128, 0, L.stream())
+                dflat[off:off + 57 * Cc].view(57, Cc).copy_(dw[:, :57].t())
+
         seg_tables = enc._grad_segment_tables(dev)
         if seg_tables is not None:
             # every encoder parameter already owns a gradient buffer: the reduced vector of each column group is
             # added into them by one scatter-add launch (no zero-fill / slice copy / autograd add per column)
-            for desc, acc_floats, (table, nseg, max_len) in zip(plan["descs"], plan["acc_floats"], seg_tables):
+            for gi, (desc, acc_floats, (table, nseg, max_len)) in enumerate(zip(plan["descs"], plan["acc_floats"], seg_tables)):
                 dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
                 partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
-                L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), g.data_ptr(), R, row_cols, Cc, acc_floats,
-                       L.ptr(dflat), L.ptr(partials), None, L.dt(g), L.stream())
+                run_group(gi, desc, acc_floats, dflat, partials, None)
                 L.call("tg_scatter_add_segments", L.ptr(dflat), L.ptr(table), nseg, max_len, L.stream())
             return (None,) * (4 + len(params))
         grads = [None if p is None else torch.zeros_like(p) for p in params]
-        for desc, acc_floats, segs in zip(plan["descs"], plan["acc_floats"], plan["segments"]):
+        for gi, (desc, acc_floats, segs) in enumerate(zip(plan["descs"], plan["acc_floats"], plan["segments"])):
             dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
             partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
-            L.call("tg_encode_bwd", C.addressof(desc), C.addressof(ptrs), g.data_ptr(), R, row_cols, Cc, acc_floats,
-                   L.ptr(dflat), L.ptr(partials), L.ptr(grads[2]), L.dt(g), L.stream())
+            run_group(gi, desc, acc_floats, dflat, partials, L.ptr(grads[2]))
             for kind, src_col, off, rows, tab_off in segs:
                 if kind == 0:
                     grads[0][src_col] = dflat[off:off + Cc]; grads[1][src_col] = dflat[off + Cc:off + 2 * Cc]
@@ -200,7 +244,7 @@ class StypeWiseFeatureEncoder(nn.Module):
             cur.append(c); cur_f += need
         if cur:
             groups.append(cur)
-        descs, accs, segments = [], [], []
+        descs, accs, segments, nots = [], [], [], []
         for grp in groups:
             grp = sorted(grp, key=lambda c: c["kind"] == 2)      # timestamp columns last: tg_encode_bwd's generic kernel
             d = L.EncDesc()                                       # then skips their accumulator slots and work items
@@ -222,7 +266,14 @@ class StypeWiseFeatureEncoder(nn.Module):
                 off += need
             d.nts = nts
             descs.append(d); accs.append(off); segments.append(segs)
-        return dict(ncols=out_col, descs=descs, acc_floats=accs, segments=segments)
+            # the same group without its (trailing) timestamp columns, for the GEMM route of those columns (bf16, C = 128):
+            # (descriptor, floats of the reduced vector the generic kernel owns, [(src_col, out_col, acc_off)] of the rest)
+            dn = L.EncDesc()
+            C.memmove(C.addressof(dn), C.addressof(d), C.sizeof(d))
+            dn.ncol, dn.nts = len(grp) - nts, 0
+            ts_cols = [(c["src_col"], c["out_col"], d.col[j].acc_off) for j, c in enumerate(grp) if c["kind"] == 2]
+            nots.append((dn, min([t[2] for t in ts_cols], default=off), ts_cols))
+        return dict(ncols=out_col, descs=descs, acc_floats=accs, segments=segments, nots=nots)
 
     def _grad_segment_tables(self, dev):
         """Per column group: (device int64 table [nseg,3] = (gradient-buffer address, offset in the group's reduced

@@ -105,3 +105,48 @@ def test_gather_gemms_at_ragged_row_counts(E):
         rb = g.float().sum(0) + (-0.25 if acc else 0.0)
         assert (dw - rw).abs().max().item() <= 1e-4 * max(rw.abs().max().item(), 1.0)
         assert (db - rb).abs().max().item() <= 1e-4 * max(rb.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("R,lazy", [(1, False), (33, False), (5000, True)])
+def test_timestamp_columns_as_gemms_agree_with_the_vector_kernels(R, lazy):
+    """bf16, C = 128: the timestamp encoder through tg_encode_ts_features + the NT / TN GEMMs against the per-row
+    kernels (k_encode_ts_fwd / k_encode_ts_bwd, themselves pinned by the oracle tests): outputs within bf16 rounding of
+    the 56-term products, parameter gradients within 1 %; every other column bit-identical; ids into a larger table."""
+    from tabgnn_amd import encoders, synthetic as S
+    from tabgnn_amd.frame import TensorFrame, stype
+    num, cat, ts = S.edge_table(max(R, 64) * (3 if lazy else 1), 5)
+    feat = {stype.numerical: torch.from_numpy(num).to(DEV), stype.categorical: torch.from_numpy(cat).to(DEV),
+            stype.timestamp: torch.from_numpy(ts).to(DEV)}
+    if lazy:
+        ids = torch.randperm(feat[stype.numerical].shape[0], device=DEV)[:R].contiguous()
+        tf = TensorFrame(feat, S.EDGE_COLS, row_ids=ids)
+    else:
+        tf = TensorFrame({k: v[:R].contiguous() for k, v in feat.items()}, S.EDGE_COLS)
+    torch.manual_seed(1)
+    enc = encoders.StypeWiseFeatureEncoder(128, S.EDGE_STATS, S.EDGE_COLS, torch.bfloat16).to(DEV)
+    with torch.no_grad():
+        enc.encoder_dict["timestamp"].weight.normal_(0, 0.3)
+        enc.encoder_dict["timestamp"].bias.normal_(0, 0.3)
+    cot = torch.randn(R, 5, 128, device=DEV, generator=torch.Generator(DEV).manual_seed(2)).to(torch.bfloat16)
+    res = []
+    try:
+        for on in (True, False):
+            encoders._TS_GEMM = on
+            for p in enc.parameters():
+                p.grad = None
+            x, _ = enc(tf)
+            (x.float() * cot.float()).sum().backward()
+            res.append((x.detach().float().clone(), {k: p.grad.clone() for k, p in enc.named_parameters()}))
+    finally:
+        encoders._TS_GEMM = True
+    a, b = res
+    ts_col = 4                                             # columns: 1 numerical, 3 categorical, 1 timestamp
+    assert torch.equal(a[0][:, :ts_col], b[0][:, :ts_col])
+    scale = b[0][:, ts_col].abs().max().item()
+    assert (a[0][:, ts_col] - b[0][:, ts_col]).abs().max().item() <= 3e-2 * scale
+    for k in b[1]:
+        ga, gb = a[1][k], b[1][k]
+        if "timestamp" in k:
+            assert (ga - gb).norm().item() <= 1e-2 * gb.norm().item() + 1e-6, k
+        else:
+            assert torch.equal(ga, gb), k
