@@ -77,9 +77,11 @@ int tg_encode_bwd(const void* desc, const void* ptrs, const void* g /*[R,ncols,C
 /* The calendar features of timestamp column src_col (TimestampEncoder: 7 fields x out_size 8 sinusoidal / cyclic
  * values, oracle/encoders.py) as a bf16 GEMM operand feats [R,128]: columns 0..55 the features, column 56 = 1 (bias
  * column), the rest 0; row r reads table row row_ids[r] when row_ids != NULL.  The encoder column is then
- * tg_gemm_nt_bf16(feats, [W | b | 0]) and its parameter gradient tg_gemm_tn_bf16(g, feats). */
+ * tg_gemm_nt_bf16(feats, [W | b | 0]) and its parameter gradient tg_gemm_tn_bf16(g, feats).  With w (fp32 [56,C], the
+ * column's TimestampEncoder weight) the same launch also packs that GEMM weight wext = [W^T | b | 0] (bf16 [C,128]). */
 int tg_encode_ts_features(const int64_t* ts, int32_t nt, int32_t src_col, const float* min_year /*[nt]*/,
-                          const int64_t* row_ids, void* feats, int64_t R, void* stream);
+                          const int64_t* row_ids, void* feats, int64_t R, const float* w, const float* b, void* wext,
+                          int32_t C, void* stream);
 /* adds segments of a reduced gradient vector into parameter gradient buffers in one launch: table int64 [nseg][3] on
  * the device = (destination float* as integer, offset into src, length).  Used by the encoder backward so that no
  * per-parameter zero-fill / slice copy / autograd add runs. */

@@ -276,10 +276,22 @@ __global__ void __launch_bounds__(256) k_encode_ts_fwd(const long long* __restri
 __global__ void __launch_bounds__(256) k_encode_ts_feats(const long long* __restrict__ ts, int nt, int src_col,
                                                           const float* __restrict__ min_year_p,
                                                           const long long* __restrict__ row_ids,
-                                                          unsigned short* __restrict__ out, long long R) {
+                                                          unsigned short* __restrict__ out, long long R,
+                                                          const float* __restrict__ w /*[56,C] or NULL*/,
+                                                          const float* __restrict__ b /*[C]*/,
+                                                          unsigned short* __restrict__ wext /*[C,128]*/, int C) {
   __shared__ __attribute__((aligned(16))) float feats[TS_RCH * TS_K];
+  if (w != nullptr && blockIdx.x == gridDim.x - 1) {       // the extra last block packs the GEMM weight [W | b | 0] (bf16)
+    for (int i = threadIdx.x; i < C * 128; i += 256) {
+      const int c = i >> 7, k = i & 127;
+      const float v = k < TS_K ? w[(long long)k * C + c] : (k == TS_K ? b[c] : 0.f);
+      wext[i] = f2bf(v);
+    }
+    return;
+  }
   const float min_year = min_year_p[0];
-  for (long long r0 = (long long)blockIdx.x * TS_RCH; r0 < R; r0 += (long long)gridDim.x * TS_RCH) {
+  const int nrow_blocks = w != nullptr ? (int)gridDim.x - 1 : (int)gridDim.x;
+  for (long long r0 = (long long)blockIdx.x * TS_RCH; r0 < R; r0 += (long long)nrow_blocks * TS_RCH) {
     const int nrows = (int)((R - r0) < TS_RCH ? (R - r0) : TS_RCH);
     __syncthreads();
     if (threadIdx.x < nrows * TS_F) {
@@ -522,13 +534,16 @@ extern "C" int tg_encode_bwd(const void* desc, const void* ptrs, const void* g, 
 }
 
 extern "C" int tg_encode_ts_features(const int64_t* ts, int32_t nt, int32_t src_col, const float* min_year,
-                                     const int64_t* row_ids, void* feats, int64_t R, void* stream) {
+                                     const int64_t* row_ids, void* feats, int64_t R, const float* w, const float* b,
+                                     void* wext, int32_t C, void* stream) {
   if (R == 0) return 0;
   TG_CHECK(ts && min_year && feats && nt > 0 && src_col >= 0 && src_col < nt, "tg_encode_ts_features: bad argument");
   TG_CHECK((reinterpret_cast<uintptr_t>(feats) & 15) == 0, "tg_encode_ts_features: feats must be 16-byte aligned");
-  const int grid = grid_cap(ceil_div(R, TS_RCH), 256 * 16);
+  TG_CHECK(!w || (b && wext && C > 0), "tg_encode_ts_features: the weight pack needs w, b, wext and C");
+  const int grid = grid_cap(ceil_div(R, TS_RCH), 256 * 16) + (w ? 1 : 0);
   hipLaunchKernelGGL(k_encode_ts_feats, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long long*)ts, nt, src_col,
-                     min_year + src_col, (const long long*)row_ids, (unsigned short*)feats, (long long)R);
+                     min_year + src_col, (const long long*)row_ids, (unsigned short*)feats, (long long)R, w, b,
+                     (unsigned short*)wext, C);
   TG_LAUNCH_CHECK();
   return 0;
 }

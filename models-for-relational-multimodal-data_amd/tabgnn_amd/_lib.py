@@ -60,7 +60,7 @@ SIGNATURES = {
     "tg_pna_degree_scalers": [_vp, _vp, _vp, _i32, _vp],
     "tg_gemm_nt_scaled_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
     "tg_gemm_tn_scaled_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i64, _i32, _vp],
-    "tg_encode_ts_features": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp],
+    "tg_encode_ts_features": [_vp, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp],
     "tg_pna_fold_fwd": [_vp, _vp, _i32, _i32, _vp, _vp],
     "tg_pna_fold_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "tg_pna_fold_ws_floats": [_i32],

@@ -114,11 +114,10 @@ class _Encode(torch.autograd.Function):
                     L.call("tg_encode_fwd", C.addressof(dn), C.addressof(ptrs), out.data_ptr(), R, S, Cc, L.dt(out), L.stream())
                 for src_col, out_col, _ in ts_cols:
                     f = torch.empty(R, 128, dtype=torch.bfloat16, device=dev)
+                    wext = torch.empty(Cc, 128, dtype=torch.bfloat16, device=dev)          # [W^T | b | 0], packed by the launch
                     L.call("tg_encode_ts_features", L.ptr(ts_raw), ts_raw.shape[1], src_col, L.ptr(enc.encoder_dict["timestamp"].min_year),
-                           L.ptr(row_ids), L.ptr(f), R, L.stream())
-                    wext = torch.zeros(Cc, 128, dtype=torch.bfloat16, device=dev)          # [W | b | 0]
-                    wext[:, :56] = ts_w[src_col].detach().reshape(56, Cc).t()
-                    wext[:, 56] = ts_b[src_col].detach()
+                           L.ptr(row_ids), L.ptr(f), R, ts_w[src_col].data_ptr(), ts_b[src_col].data_ptr(), L.ptr(wext), Cc,
+                           L.stream())
                     L.call("tg_gemm_nt_bf16", L.ptr(f), L.ptr(wext), None, None, out.data_ptr() + 2 * out_col * Cc, R, Cc, 128,
                            128, S * Cc, 0, 0.0, 0, 0, L.stream())
                     ts_feats[src_col] = f
