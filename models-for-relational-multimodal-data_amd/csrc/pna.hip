@@ -48,6 +48,15 @@ __global__ void k_gather_concat3(GatherPart p0, GatherPart p1, GatherPart p2, T*
 // Nodes whose segments together exceed HUB_THRESH rows are deferred to k_segment_sum2_hub (one block per hub),
 // so a heavy-tailed degree distribution does not serialise on one lane group.
 constexpr int HUB_THRESH = 256;
+// hub_work layout of the segmented sum: [0] = number of hubs, [1 .. HUB_SPLIT_HUBS] = arrival tickets of the big hubs,
+// [HUB_BIG_CNT] = number of big hubs, [HUB_BIG_IDS ..) their ids, [HUB_PART_OFF ..) = HUB_SPLIT_HUBS * HUB_SPLIT *
+// HUB_FMAX fp32 partial rows, [HUB_IDS ..] = ids of the other hubs.
+// Hubs of more than HUB_BIG rows (the first HUB_SPLIT_HUBS of them) are reduced by HUB_SPLIT workgroups each (a
+// 12.8 k-row hub account was one 1024-thread block walking 25 dependent rounds: 73 us, three times per step); the
+// block that arrives last sums the partial rows in part order, so the result does not depend on the arrival order.
+constexpr int HUB_SPLIT = 8, HUB_SPLIT_HUBS = 32, HUB_FMAX = 512, HUB_BIG = 2048, HUB_BIG_CNT = 1 + HUB_SPLIT_HUBS,
+              HUB_BIG_IDS = HUB_BIG_CNT + 1, HUB_PART_OFF = 128,
+              HUB_IDS = HUB_PART_OFF + HUB_SPLIT_HUBS * HUB_SPLIT * HUB_FMAX;
 
 template <typename T, int VEC>
 __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int offA, const int* __restrict__ rpA,
@@ -64,7 +73,15 @@ __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int o
     int sA = rpA[n], eA = rpA[n + 1];
     int sB = rpB ? rpB[n] : 0, eB = rpB ? rpB[n + 1] : 0;
     if ((eA - sA) + (eB - sB) > HUB_THRESH) {
-      if (c == 0) hub[1 + atomicAdd(hub, 1)] = n;
+      if (c == 0) {
+        bool big = (eA - sA) + (eB - sB) > HUB_BIG;
+        if (big) {
+          const int k = atomicAdd(hub + HUB_BIG_CNT, 1);
+          if (k < HUB_SPLIT_HUBS) hub[HUB_BIG_IDS + k] = n;
+          else big = false;                                  // more big hubs than split slots: an ordinary hub
+        }
+        if (!big) hub[HUB_IDS + atomicAdd(hub, 1)] = n;
+      }
       continue;
     }
     if (accumulate && eA == sA && eB == sB) continue;      // dx += 0: the row is not touched at all
@@ -122,27 +139,37 @@ __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int o
   }
 }
 
-// one 1024-thread block per hub node: lane groups take strided rows, partial sums meet in LDS in group order
+// hub nodes: 1024-thread blocks, lane groups take strided rows (eight in flight each), partial sums meet in LDS in group
+// order.  The big hubs are cut into HUB_SPLIT contiguous parts of their CSR ranges (one work item each); the ordinary
+// hubs get a whole block each.
 template <typename T, int VEC>
 __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__ g, long long gstride, int offA,
                                                             const int* __restrict__ rpA, const int* __restrict__ pmA,
                                                             int offB, const int* __restrict__ rpB,
                                                             const int* __restrict__ pmB, int seedB,
                                                             const T* __restrict__ relu_src, T* __restrict__ dx, int F,
-                                                            const int* __restrict__ hub, int accumulate) {
+                                                            int* __restrict__ hub, float* __restrict__ partials,
+                                                            int accumulate) {
   extern __shared__ float part[];  // [groups][F]
+  __shared__ int ticket_s;
   const int lpn = F / VEC, groups = 1024 / lpn;
   const int gi = threadIdx.x / lpn, c = (threadIdx.x % lpn) * VEC;
   const int nh = hub[0];
-  for (int hIdx = blockIdx.x; hIdx < nh; hIdx += gridDim.x) {
-    int n = hub[1 + hIdx];
+  const int nsplit = hub[HUB_BIG_CNT] < HUB_SPLIT_HUBS ? hub[HUB_BIG_CNT] : HUB_SPLIT_HUBS;
+  // work items: (big hub, part) pairs first, then one item per ordinary hub
+  const int nitems = nsplit * HUB_SPLIT + nh;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const bool split = item < nsplit * HUB_SPLIT;
+    const int hIdx = split ? item / HUB_SPLIT : item - nsplit * HUB_SPLIT;
+    const int pi = split ? item % HUB_SPLIT : 0, np = split ? HUB_SPLIT : 1;
+    const int n = split ? hub[HUB_BIG_IDS + hIdx] : hub[HUB_IDS + hIdx];
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     if (gi < groups) {
-      int sA = rpA[n], eA = rpA[n + 1];
-      // eight rows in flight per lane group (clamped index + select: no load sits behind a branch); a 12.8k-row
-      // hub is 25 dependent rounds instead of 200
+      // this block's share of segment A and of segment B (contiguous slices of the CSR ranges)
+      const int sA0 = rpA[n], eA0 = rpA[n + 1];
+      const int lenA = eA0 - sA0, sA = sA0 + (int)((long long)lenA * pi / np), eA = sA0 + (int)((long long)lenA * (pi + 1) / np);
       for (int q = sA + gi; q < eA; q += groups * 8) {
         float t[8][VEC];
 #pragma unroll
@@ -160,7 +187,8 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
         }
       }
       if (rpB) {
-        int sB = rpB[n], eB = rpB[n + 1];
+        const int sB0 = rpB[n], eB0 = rpB[n + 1];
+        const int lenB = eB0 - sB0, sB = sB0 + (int)((long long)lenB * pi / np), eB = sB0 + (int)((long long)lenB * (pi + 1) / np);
         for (int q = sB + gi; q < eB; q += groups * 8) {
           float t[8][VEC];
 #pragma unroll
@@ -180,12 +208,33 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
       for (int j = 0; j < VEC; ++j) part[gi * F + c + j] = acc[j];
     }
     __syncthreads();
-    for (int f = threadIdx.x; f < F; f += 1024) {
-      float t = 0.f;
-      for (int g2 = 0; g2 < groups; ++g2) t += part[g2 * F + f];
-      if (relu_src && !(to_f<T>(relu_src[(long long)n * F + f]) > 0.f)) t = 0.f;
-      if (accumulate) t += to_f<T>(dx[(long long)n * F + f]);
-      dx[(long long)n * F + f] = from_f<T>(t);
+    bool finish = true;
+    float* prow = partials + ((long long)hIdx * HUB_SPLIT) * HUB_FMAX;      // this hub's HUB_SPLIT partial rows
+    if (split) {
+      for (int f = threadIdx.x; f < F; f += 1024) {
+        float t = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) t += part[g2 * F + f];
+        prow[pi * HUB_FMAX + f] = t;
+      }
+      __threadfence();                                   // the partial row is visible before the ticket is taken
+      __syncthreads();
+      if (threadIdx.x == 0) ticket_s = atomicAdd(hub + 1 + hIdx, 1);
+      __syncthreads();
+      finish = ticket_s == HUB_SPLIT - 1;                // the last part to arrive combines them, in part order
+      if (finish) __threadfence();
+    }
+    if (finish) {
+      for (int f = threadIdx.x; f < F; f += 1024) {
+        float t = 0.f;
+        if (split) {
+          for (int k = 0; k < HUB_SPLIT; ++k) t += __builtin_nontemporal_load(prow + k * HUB_FMAX + f);
+        } else {
+          for (int g2 = 0; g2 < groups; ++g2) t += part[g2 * F + f];
+        }
+        if (relu_src && !(to_f<T>(relu_src[(long long)n * F + f]) > 0.f)) t = 0.f;
+        if (accumulate) t += to_f<T>(dx[(long long)n * F + f]);
+        dx[(long long)n * F + f] = from_f<T>(t);
+      }
     }
     __syncthreads();
   }
@@ -725,7 +774,11 @@ extern "C" int tg_gather_concat3(const void* a, const int32_t* ia, int64_t sa, i
   return 0;
 }
 
-extern "C" int64_t tg_segment_hub_ints(int64_t total_rows) { return 2 + total_rows / HUB_THRESH; }
+// ints of hub_work for total_rows CSR rows (also sizes the work lists of the aggregation's hub pass, which uses its
+// own [count | ids] prefix of the same buffer)
+extern "C" int64_t tg_segment_hub_ints(int64_t total_rows) {
+  return (int64_t)HUB_IDS + total_rows / HUB_THRESH + 4;
+}
 
 extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA,
                                int32_t offB, const int32_t* rpB, const int32_t* pmB, int32_t seedB,
@@ -734,7 +787,9 @@ extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, con
   TG_CHECK(F % 8 == 0 && offA % 8 == 0 && offB % 8 == 0 && gstride % 8 == 0, "tg_segment_sum2: misaligned F=%d", F);
   TG_CHECK(rpA && pmA && hub_work, "tg_segment_sum2: CSR A and hub workspace required");
   hipStream_t st = (hipStream_t)stream;
-  zero_async(hub_work, sizeof(int), st);
+  TG_CHECK(F <= HUB_FMAX, "tg_segment_sum2: F = %d exceeds %d", F, HUB_FMAX);
+  zero_async(hub_work, sizeof(int) * (HUB_BIG_CNT + 1), st);     // hub counts + the big hubs' tickets
+  // CSR rows = the larger row pointer's total: the id list is sized for it by tg_segment_hub_ints(total rows)
   DISPATCH_T(dt, {
     TG_CHECK(1024 % (F / VEC) == 0, "tg_segment_sum2: F/VEC must divide 1024 (F=%d)", F);
     long long total = (long long)N * (F / VEC);
@@ -743,7 +798,8 @@ extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, con
                        (T*)dx, N, F, hub_work, accumulate);
     size_t shm = (size_t)(1024 / (F / VEC)) * F * sizeof(float);
     hipLaunchKernelGGL((k_segment_sum2_hub<T, VEC>), dim3(256), dim3(1024), shm, st, (const T*)g, (long long)gstride,
-                       offA, rpA, pmA, offB, rpB, pmB, seedB, (const T*)relu_src, (T*)dx, F, hub_work, accumulate);
+                       offA, rpA, pmA, offB, rpB, pmB, seedB, (const T*)relu_src, (T*)dx, F, hub_work,
+                       reinterpret_cast<float*>(hub_work + HUB_PART_OFF), accumulate);
   })
   TG_LAUNCH_CHECK();
   return 0;
