@@ -156,7 +156,8 @@ int tg_gather_concat3(const void* a, const int32_t* ia, int64_t sa, int32_t wa, 
                       int64_t sc, int32_t wc, void* out, int64_t rows, int32_t dt, void* stream);
 /* backward of the two gathered parts as a deterministic segmented sum over CSR(s) */
 int64_t tg_segment_hub_ints(int64_t total_rows); /* size of hub_work for tg_segment_sum2 */
-/* accumulate != 0: dx += the sums (rows with empty segments are not touched): dx is the gradient buffer the consumers of
+/* pmA == NULL: segment A's rows are the CSR positions themselves (g laid out in CSR order: the destination-sorted
+ * messages).  accumulate != 0: dx += the sums (rows with empty segments are not touched): dx is the gradient buffer the consumers of
  * one tensor share (every consumer adds its part in place: no autograd accumulation pass over [N,F]) */
 int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, const int32_t* rpA, const int32_t* pmA, int32_t offB,
                     const int32_t* rpB, const int32_t* pmB, int32_t seedB, const void* relu_src, void* dx, int32_t N,

@@ -90,7 +90,7 @@ __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int o
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     int q = sA;
     for (; q + 1 < eA; q += 2) {   // two rows in flight
-      int r0 = pmA[q], r1 = pmA[q + 1], o0 = offA, o1 = offA;
+      int r0 = pmA ? pmA[q] : q, r1 = pmA ? pmA[q + 1] : q + 1, o0 = offA, o1 = offA;
       if (seedB > 0) {
         if (r0 >= seedB) { r0 -= seedB; o0 = offB; }
         if (r1 >= seedB) { r1 -= seedB; o1 = offB; }
@@ -102,7 +102,7 @@ __global__ void k_segment_sum2(const T* __restrict__ g, long long gstride, int o
       for (int j = 0; j < VEC; ++j) acc[j] = (acc[j] + t0[j]) + t1[j];
     }
     if (q < eA) {
-      int row = pmA[q], off = offA;
+      int row = pmA ? pmA[q] : q, off = offA;
       if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
       float t[VEC];
       loadv<T, VEC>(g + (long long)row * gstride + off + c, t);
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(1024) k_segment_sum2_hub(const T* __restrict__
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int qq = q + u * groups;
-          int row = pmA[qq < eA ? qq : q], off = offA;
+          int row = pmA ? pmA[qq < eA ? qq : q] : (qq < eA ? qq : q), off = offA;
           if (seedB > 0 && row >= seedB) { row -= seedB; off = offB; }
           loadv<T, VEC>(g + (long long)row * gstride + off + c, t[u]);
         }
@@ -785,7 +785,7 @@ extern "C" int tg_segment_sum2(const void* g, int64_t gstride, int32_t offA, con
                                const void* relu_src, void* dx, int32_t N, int32_t F, int32_t* hub_work,
                                int32_t accumulate, int32_t dt, void* stream) {
   TG_CHECK(F % 8 == 0 && offA % 8 == 0 && offB % 8 == 0 && gstride % 8 == 0, "tg_segment_sum2: misaligned F=%d", F);
-  TG_CHECK(rpA && pmA && hub_work, "tg_segment_sum2: CSR A and hub workspace required");
+  TG_CHECK(rpA && hub_work, "tg_segment_sum2: CSR A and hub workspace required");
   hipStream_t st = (hipStream_t)stream;
   TG_CHECK(F <= HUB_FMAX, "tg_segment_sum2: F = %d exceeds %d", F, HUB_FMAX);
   zero_async(hub_work, sizeof(int) * (HUB_BIG_CNT + 1), st);     // hub counts + the big hubs' tickets

@@ -149,7 +149,6 @@ class SubgraphIndex:
             inv = torch.empty(self.E, dtype=torch.int32, device=perm.device)
             inv[perm] = torch.arange(self.E, dtype=torch.int32, device=perm.device)
             sv = dict(perm=self.by_dst[1], dst=self.dst[perm].contiguous(), src=self.src[perm].contiguous(), inv=inv,
-                      arange=torch.arange(max(self.E, 1), dtype=torch.int32, device=perm.device),
                       src_to_sorted=inv[self.by_src[1][:self.E].long()].contiguous())
             self._sorted = sv
         return sv
@@ -719,7 +718,7 @@ def _edge_gather_backward(g, graph, first, F, We, sinks):
     another consumer already handed to autograd."""
     if first == "dst_sorted":
         sv = graph.sorted_view()
-        csr_a, csr_b = (graph.by_dst[0], sv["arange"]), (graph.by_src[0], sv["src_to_sorted"])
+        csr_a, csr_b = (graph.by_dst[0], None), (graph.by_src[0], sv["src_to_sorted"])   # A: rows already in CSR order
     else:
         csr_a, csr_b = (graph.by_dst, graph.by_src) if first == "dst" else (graph.by_src, graph.by_dst)
     sink_x, sink_e = sinks

@@ -126,14 +126,23 @@ def batch_index(edge_index, num_nodes, n_seed, device):
                               dtype=np.int64)
     nsrc, ndst = np.ascontiguousarray(ei[0, n_seed:]), np.ascontiguousarray(ei[1, n_seed:])
     tei = np.ascontiguousarray(np.concatenate([ei[0, :n_seed], ei[1, :n_seed]]))
-    parts = [nsrc.astype(np.int32), ndst.astype(np.int32), *host_csr(ndst, num_nodes), *host_csr(nsrc, num_nodes),
-             tei.astype(np.int32), *host_csr(tei, num_nodes)]
+    rp_d_h, pm_d_h = host_csr(ndst, num_nodes)
+    rp_s_h, pm_s_h = host_csr(nsrc, num_nodes)
+    En = nsrc.shape[0]
+    # the destination-sorted message layout (SubgraphIndex.sorted_view): row k of the sorted layout is edge perm[k]
+    perm = pm_d_h[:En].astype(np.int64)
+    inv = np.empty(En, dtype=np.int32)
+    inv[perm] = np.arange(En, dtype=np.int32)
+    src32, dst32 = nsrc.astype(np.int32), ndst.astype(np.int32)
+    parts = [src32, dst32, rp_d_h, pm_d_h, rp_s_h, pm_s_h, tei.astype(np.int32), *host_csr(tei, num_nodes),
+             dst32[perm], src32[perm], inv, inv[pm_s_h[:En].astype(np.int64)]]
     flat = torch.from_numpy(np.concatenate([p.ravel() for p in parts])).to(device, non_blocking=True)   # ONE upload
     views, off = [], 0
     for p_ in parts:
         views.append(flat[off:off + p_.size]); off += p_.size
-    src, dst, rp_d, pm_d, rp_s, pm_s, tei_d, rp_t, pm_t = views
+    src, dst, rp_d, pm_d, rp_s, pm_s, tei_d, rp_t, pm_t, dst_sorted, src_sorted, inv_d, s2s = views
     graph = ops.SubgraphIndex(src, dst, (rp_d, pm_d), (rp_s, pm_s), int(num_nodes))
+    graph._sorted = dict(perm=pm_d, dst=dst_sorted, src=src_sorted, inv=inv_d, src_to_sorted=s2s)
     seeds = ops.SeedIndex.from_parts(tei_d, rp_t, pm_t, int(n_seed), int(num_nodes))
     return ops.BatchIndex(graph, seeds, torch.from_numpy(ei).to(device, non_blocking=True))
 
