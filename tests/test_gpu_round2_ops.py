@@ -150,3 +150,48 @@ def test_timestamp_columns_as_gemms_agree_with_the_vector_kernels(R, lazy):
             assert (ga - gb).norm().item() <= 1e-2 * gb.norm().item() + 1e-6, k
         else:
             assert torch.equal(ga, gb), k
+
+
+def _ref_tn(g, x, scale=None):
+    out = torch.zeros(g.shape[1], x.shape[1], device=DEV, dtype=torch.float32)
+    for i in range(0, g.shape[0], 1 << 18):
+        gg = g[i:i + (1 << 18)].float()
+        if scale is not None:
+            gg = (gg * scale[i:i + (1 << 18), None]).bfloat16().float()
+        out += gg.t() @ x[i:i + (1 << 18)].float()
+    return out
+
+
+@pytest.mark.parametrize("R,M,N", [(2580972, 384, 128), (430162, 128, 768), (430162, 128, 384), (8192, 1536, 1536),
+                                   (100003, 384, 256), (300, 384, 128), (129, 128, 384)])
+def test_wide_weight_gradient_kernel_at_the_step_shapes(R, M, N):
+    """tg_gemm_tn_bf16 on the shapes that take the 384 x 128-block kernel (wide on either side), at the bench's full row
+    counts: weight and bias gradient against a chunked fp32 product, and accumulate mode."""
+    from tabgnn_amd import _lib as L
+    torch.manual_seed(R % 1000)
+    g = torch.randn(R, M, device=DEV, dtype=torch.bfloat16)
+    x = torch.randn(R, N, device=DEV, dtype=torch.bfloat16)
+    ref, rb = _ref_tn(g, x), g.float().sum(0)
+    ws = torch.empty(L.load().tg_gemm_tn_workspace_floats(R, M, N), device=DEV, dtype=torch.float32)
+    for acc in (0, 1):
+        out = torch.full((M, N), 2.0, device=DEV)
+        db = torch.full((M,), -1.0, device=DEV)
+        L.call("tg_gemm_tn_bf16", L.ptr(g), L.ptr(x), L.ptr(out), L.ptr(db), L.ptr(ws), R, M, N, M, N, acc, L.stream())
+        want, wantb = ref + (2.0 if acc else 0.0), rb + (-1.0 if acc else 0.0)
+        assert (out - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+        assert (db - wantb).abs().max().item() <= 2e-5 * max(wantb.abs().max().item(), 1.0)
+
+
+def test_scaled_post_projection_weight_gradient_at_the_bench_size():
+    from tabgnn_amd import _lib as L
+    N, F, K = 524165, 128, 512
+    torch.manual_seed(3)
+    g = torch.randn(N, F, device=DEV, dtype=torch.bfloat16)
+    agg = torch.randn(N, K, device=DEV, dtype=torch.bfloat16)
+    scales = (torch.rand(N, 2, device=DEV) * 2 + 0.1).float()
+    scales[::7, 0] = 0.0                                      # isolated nodes: amplification 0
+    dw = torch.empty(3 * F, K, device=DEV, dtype=torch.float32)
+    ws = torch.empty(L.load().tg_gemm_tn_workspace_floats(N, 3 * F, K), device=DEV, dtype=torch.float32)
+    L.call("tg_gemm_tn_scaled_bf16", L.ptr(g), L.ptr(agg), L.ptr(scales), L.ptr(dw), L.ptr(ws), N, F, K, F, K, 0, L.stream())
+    ref = torch.cat([_ref_tn(g, agg), _ref_tn(g, agg, scales[:, 0]), _ref_tn(g, agg, scales[:, 1])], 0)
+    assert (dw - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
