@@ -11,6 +11,8 @@ model = T.TABGNNFusedS(cfg).to(dev).train()
 flat = T.FlatParams(model, shadow_dtype=torch.bfloat16); opt = T.FusedAdam(flat, lr=cfg["lr"])
 lw = torch.tensor(cfg["loss_weights"], device=dev)
 b = S.make_batch(bs, seed=1, device=dev)
+from tabgnn_amd.sampler import batch_index
+b = (b[0], batch_index(b[1].cpu(), b[0].num_rows, bs, dev), b[2], b[3])      # as bench.py: sampler-built CSRs
 for _ in range(5):
     T.train_step(model, flat, opt, b, lw)
 torch.cuda.synchronize()
@@ -20,4 +22,5 @@ for _ in range(20):
     T.train_step(model, flat, opt, b, lw)
 torch.cuda.synchronize()
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(40)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(25)
+st.sort_stats("cumtime").print_stats(r"tabgnn_amd", 45)
