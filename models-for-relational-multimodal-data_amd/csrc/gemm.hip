@@ -11,6 +11,7 @@
 //     ds_read_b64_tr_b16 (hardware transpose) from the row-major image — no transposed copy of G or X ever exists,
 //   * v_mfma_f32_32x32x16_bf16, 2x2 accumulator tiles per wave (64x64 per wave, 128x128 per workgroup),
 //   * fp32 slab partials are summed by a second kernel in slab order: deterministic, no float atomics.
+#include <stdlib.h>
 #include "common.hpp"
 #include "../../include/tabgnn_hip.h"
 
@@ -605,7 +606,8 @@ static TnPlan tn_plan(long long R, int M, int N, bool scaled = false, int mreal 
   // several output tiles per slab measured faster with the finer split.  A slab is never shorter than 4 steps (256
   // rows): below that the fp32 partials (64 KiB per tile and slab, written and read back) outweigh the rows it read.
   long long want = ceil_div(p.tm * p.tn == 1 ? 512 : 768, (long long)p.tm * p.tn);
-  const long long cap = steps / 4 > 0 ? steps / 4 : 1;
+  static const int min_steps = getenv("TABGNN_TN_MINSTEPS") ? atoi(getenv("TABGNN_TN_MINSTEPS")) : 4;   // tuning aid
+  const long long cap = steps / min_steps > 0 ? steps / min_steps : 1;
   if (want > cap) want = cap;
   p.nslab = (int)(want < 1 ? 1 : want);
   p.rows_per_slab = ceil_div(steps, p.nslab) * (long long)GK;

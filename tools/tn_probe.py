@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "models-for-relational-multimodal-data_amd
 from tabgnn_amd import _lib as L
 dev = "cuda:0"
 E, N, S = 430162, 524165, 6
-shapes = [("encoder 128x128", E * S, 128, 128), ("encoder W_in", E * S, 384, 128), ("edge_emb", E, 128, 768),
+shapes = [("seed rows", 8192 * 6, 128, 128), ("seed W_in", 8192 * 6, 384, 128), ("B rows 128", 8192, 128, 128), ("B rows 384x128", 8192, 384, 128), ("nodes 128", N, 128, 128)] if os.environ.get("TN_SMALL") else [("encoder 128x128", E * S, 128, 128), ("encoder W_in", E * S, 384, 128), ("edge_emb", E, 128, 768),
           ("pna msg", E, 128, 384), ("edge-upd 2", E, 128, 128), ("post x", N, 128, 128), ("seed rows", 8192 * 6, 128, 128),
           ("fuse 1", 8192, 1536, 384), ("fuse 2", 8192, 1536, 1536), ("fuse 3", 8192, 384, 1536), ("ragged", 100003, 384, 256),
           ("tiny", 300, 384, 128)]
