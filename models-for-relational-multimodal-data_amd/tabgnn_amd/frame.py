@@ -8,7 +8,7 @@ not part of this build, so the same surface is kept here: ``feat_dict`` (stype -
 from __future__ import annotations
 
 import enum
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional
 
 import torch

@@ -8,7 +8,6 @@
 """
 from __future__ import annotations
 
-import math
 
 import torch
 from torch import nn

@@ -7,7 +7,6 @@ everything else (gather, attention core, norms, aggregation, pooling, loss, opti
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 
 import torch
