@@ -551,6 +551,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ops.KernelTimer.active = None
+    peak_hbm_gb = torch.cuda.max_memory_allocated(dev) / 1e9          # model + optimiser + one step's activations
 
     tot = torch.tensor([elapsed, float(edges)], dtype=torch.float64, device=dev)
     if use_dist:
@@ -586,6 +587,7 @@ def main():
                                f"(3 cat, 1 num, 1 ts), dropout 0.5/0.083, Adam" + (", reverse_mp" if args.reverse_mp else ""),
                    "batch_size": args.batch_size, "edges_per_step": int(E_mean), "nodes_per_step": int(N_mean),
                    "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}",
+                   "peak_hbm_gb": peak_hbm_gb,
                    "index": ("CSR-by-destination/by-source of the batch built by the sampler side on the host "
                              "(tg_host_csr) and resident in HBM with the batch" if args.index == "sampler" else
                              "CSRs rebuilt from edge_index on the device inside every forward (tg_csr_build)")},
