@@ -13,7 +13,7 @@ out = {"how": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_C
               "of k_gemm_nt_bf16: 32 cycles x 32 MFMAs per wave tile); the GEMMs of this path are HBM-bound (K = 128..768), so a low MFMA utilisation is the "
               "expected reading", "kernels": {}}
 for k, c in acc.items():
-    if "gemm" not in k.lower() and "Cijk" not in k:
+    if "gemm" not in k.lower() and "Cijk" not in k and "k_encoder_" not in k:
         continue
     mf, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", [0.0]), c.get("GRBM_GUI_ACTIVE", [0.0])
     name = k.split("(")[0].replace("void ", "")[:90]
