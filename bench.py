@@ -152,18 +152,37 @@ def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
     for w in range(n_workers):
         threading.Thread(target=work, args=(w,), daemon=True).start()
     edges = n_nodes = 0
+    timer = T.ops.KernelTimer(only=("tg_pna_aggregate_fwd",))      # 2 event pairs per step: the named kernel on THIS shape
+    t_model = []
     for i in range(total):
         eid, lei, nodes = slots[i].get()
         ahead.release()
         if i == warm:
             torch.cuda.synchronize(); t0 = time.perf_counter(); edges = n_nodes = 0
+            T.ops.KernelTimer.active = timer
         # ids only cross PCIe: raw columns are read by id from the HBM-resident table, the CSRs arrive with the batch
-        T.train_step(model, flat, opt, store.batch(eid, lei, nodes, batch_size), loss_w)
+        batch = store.batch(eid, lei, nodes, batch_size, index=True)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        T.train_step(model, flat, opt, batch, loss_w)
+        ev[1].record()
+        if i >= warm:
+            t_model.append(ev)
         edges += eid.numel()
         n_nodes += nodes.numel()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return dict(value=edges / dt, unit="edges/s", ms_per_step=1e3 * dt / steps, steps=steps,
+    T.ops.KernelTimer.active = None
+    F, b_act = model.config["n_hidden"], 2
+    agg_bytes = (edges / steps - batch_size) * (F * b_act + 4) + (n_nodes / steps) * 4 * F * b_act
+    agg_ms = timer.mean_ms("tg_pna_aggregate_fwd")
+    sampled = dict(kernel="k_pna_aggregate_fwd", bound="hbm", achieved=agg_bytes / (agg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                   unit="GB/s", frac=agg_bytes / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=agg_bytes,
+                   avg_launch_ms=agg_ms, launches_timed=timer.count("tg_pna_aggregate_fwd"),
+                   shape="the batch the native sampler draws from the HI-Small-shaped graph (mean over the timed steps): "
+                         f"E={int(edges / steps)}, N={int(n_nodes / steps)}")
+    return dict(value=edges / dt, unit="edges/s", ms_per_step=1e3 * dt / steps, steps=steps, roofline_sampled=sampled,
+                model_only_ms_per_step=sum(a.elapsed_time(b) for a, b in t_model) / len(t_model),
                 edges_per_step=edges / steps, nodes_per_step=n_nodes / steps, sampler_ms_per_batch=1e3 * float(np.mean(t_sample[warm:])),
                 sampler=f"libtabgnn_sampler.so k-hop [100,100], {n_workers} host threads (one handle each), prefetch <= "
                         f"{2 * n_workers} batches; batch = ids + host-built CSRs (no row gather, no device CSR build)",
@@ -648,6 +667,19 @@ def main():
                 gemms["tg_gemm_tn_bf16"]["counter_source"] = pmc_path
         if gemms:
             out["roofline_gemm"] = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": gemms}
+    if extras and args.index == "sampler":
+        # the same step with the CSRs rebuilt from edge_index on the device inside every forward (tg_csr_build): what
+        # `value` measured in round 1 and what the CPU oracle's step includes
+        batches_s, batches = batches, plain_batches
+        run(3, 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e_dev = run(10, 3)
+        torch.cuda.synchronize()
+        d_dev = time.perf_counter() - t1
+        batches = batches_s
+        out["index_device"] = {"value": e_dev / d_dev, "unit": "edges/s", "ms_per_step": 1e3 * d_dev / 10, "steps": 10,
+                               "what": "same workload with --index device: the batch's CSRs built inside the forward"}
     if extras:
         out["eval"] = eval_throughput(model, plain_batches, dev)
         out["reference_batch"] = reference_batch(args, cdt, dev)
@@ -658,6 +690,7 @@ def main():
                                            cfg["lr"], cfg["loss_weights"])
     if extras and not args.no_e2e and args.dtype == "bf16":
         out["end_to_end"] = end_to_end(model, flat, opt, loss_w, args.batch_size, args.e2e_steps, dev)
+        out["roofline_sampled"] = out["end_to_end"].pop("roofline_sampled")
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

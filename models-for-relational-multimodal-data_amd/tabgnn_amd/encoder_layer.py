@@ -42,10 +42,21 @@ def pack_layer(lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, b1, b2, g2, be2, gt, b
     dev = lw_in.device
     wpack = torch.empty(lib.tg_encoder_pack_bytes(), dtype=torch.uint8, device=dev)
     prm = torch.empty(lib.tg_encoder_prm_floats(), dtype=torch.float32, device=dev)
-    f = lambda t: None if t is None else L.ptr(t.detach().float().contiguous() if t.dtype != torch.float32 else t.detach())
-    L.call("tg_encoder_pack", L.ptr(lw_in.contiguous()), L.ptr(lw_o.contiguous()), L.ptr(lw1.contiguous()),
-           L.ptr(lw2.contiguous()), f(b_in), f(b_o), f(g1), f(be1), f(b1), f(b2), f(g2), f(be2), f(gt), f(bt),
-           L.ptr(wpack), L.ptr(prm), L.stream())
+    keep = []            # converted copies stay alive until the launch is queued (their blocks must not be reused before)
+
+    def f(t):
+        if t is None:
+            return None
+        t = t.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.float().contiguous()
+        keep.append(t)
+        return L.ptr(t)
+
+    weights = [w.contiguous() for w in (lw_in, lw_o, lw1, lw2)]
+    L.call("tg_encoder_pack", *(L.ptr(w) for w in weights), f(b_in), f(b_o), f(g1), f(be1), f(b1), f(b2), f(g2), f(be2),
+           f(gt), f(bt), L.ptr(wpack), L.ptr(prm), L.stream())
+    del keep, weights    # (stream-ordered allocator: freeing after the launch call is safe)
     return wpack, prm
 
 

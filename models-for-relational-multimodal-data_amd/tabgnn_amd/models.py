@@ -108,6 +108,8 @@ class FTTransformerPNAFusedLayer(nn.Module):
         conv = self.gnn_conv(x_gnn, g, edge_attr, sx, se) if sx is not None else self.gnn_conv(x_gnn, g, edge_attr)
         x_gnn = self.gnn_norm(conv, res=x_gnn, relu=True, alpha=0.5, beta_c=0.5, sink_res=sx)
         # (e + MLP([x[src], x[dst], e])) / 2   (fused.py:253-254)
+        reread = (ops.edge_mlp_rereads_x(x_gnn, edge_attr, self.gnn_edge_update[0], self.gnn_edge_update[2])
+                  and torch.is_grad_enabled())
         upd = ops.edge_mlp_relu(x_gnn, edge_attr, g, "src", self.gnn_edge_update[0], self.gnn_edge_update[2], sn, se)
         edge_attr = ops.axpby(edge_attr, upd, 0.5, 0.5, sink_a=se)
         if not lp:
@@ -123,7 +125,7 @@ class FTTransformerPNAFusedLayer(nn.Module):
             # in place, as fused.py:268.  The gather-fused edge update above re-reads x_gnn in its backward (x[src], x[dst]
             # for dW instead of a saved [E,384] concatenation): the pool stashes the <= 2B rows it overwrites and that
             # backward puts them back first (ops._MLPReluGather); TABGNN_NO_POOL_RESTORE=1 pools into a copy instead.
-            reread = ops.gather_gemm_ok(x_gnn, edge_attr, self.nhidden, 3 * self.nhidden) and torch.is_grad_enabled()
+            # (``reread`` = edge_mlp_relu's own route predicate, taken above on the tensors it saw.)
             x_gnn = ops.seed_pool(x_gnn, xf, seeds, self.channels, inplace=not reread or ops.POOL_RESTORE, sink_x=sn,
                                   stash=reread and ops.POOL_RESTORE)                 # fused.py:261-268
         return x_tab, x_gnn, edge_attr

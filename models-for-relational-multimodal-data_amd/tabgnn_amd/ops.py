@@ -839,8 +839,11 @@ class _MLPReluGather(torch.autograd.Function):
         # tensor IN PLACE afterwards (fused.py:268); the backward below first puts the pre-pool rows back (_SeedPool
         # stashed them on the tensor), which is safe because every reader of the pooled values — the next layer's
         # nodes — is upstream of this node in the backward graph and has run by then.
+        # Because x is outside save_for_backward, autograd's version check does not cover it: the check is done by
+        # hand in the backward against the version recorded here.
         ctx.save_for_backward(e, m, lw0, lw2)
         ctx.x_ref = x
+        ctx.x_ver = x._version
         ctx.cfg = (graph, first, (sink_x, sink_e))
         ctx.params = (w0, b0, w2, b2)
         return y
@@ -850,7 +853,14 @@ class _MLPReluGather(torch.autograd.Function):
         e, m, lw0, lw2 = ctx.saved_tensors
         x = ctx.x_ref
         patch = getattr(x, "_pool_patch", None)
-        if patch is not None:
+        if x._version != ctx.x_ver:
+            # the only in-place change this node can undo: ONE seed_pool(..., inplace=True, stash=True) on the tensor it
+            # read (the stash records the version it saw and the version it left)
+            if patch is None or patch[2] != ctx.x_ver or patch[3] != x._version:
+                raise RuntimeError(
+                    "edge_mlp_relu: its node input was modified in place after the forward (version "
+                    f"{ctx.x_ver} -> {x._version}) and the pre-modification rows were not stashed: call "
+                    "seed_pool(..., inplace=True, stash=True) exactly once on that tensor, or use inplace=False")
             with torch.no_grad():
                 x.index_copy_(0, patch[0], patch[1])
             x._pool_patch = None
@@ -868,11 +878,17 @@ class _MLPReluGather(torch.autograd.Function):
         return dx, de, dw0, db0, dw2, db2, None, None, None, None, None, None
 
 
+def edge_mlp_rereads_x(x, e, lin0, lin2):
+    """True when ``edge_mlp_relu`` takes the gather-fused route, whose backward re-reads ``x`` (the ONE predicate both
+    ``edge_mlp_relu`` and the caller that pools ``x`` in place afterwards use: models.FTTransformerPNAFusedLayer)."""
+    H, K = lin0.weight.shape
+    return bool(lin0.bias is not None and lin2.bias is not None and H == 128 and lin2.weight.shape[0] == 128
+                and gather_gemm_ok(x, e, H, K))
+
+
 def edge_mlp_relu(x, e, graph, first, lin0, lin2, sink_x=None, sink_e=None):
     """``lin2(relu(lin0([x[ia] | x[ib] | e[ic]])))`` for all edges (two ``nn.Linear`` modules)."""
-    H, K = lin0.weight.shape
-    if (lin0.bias is not None and lin2.bias is not None and H == 128 and lin2.weight.shape[0] == 128
-            and gather_gemm_ok(x, e, H, K)):
+    if edge_mlp_rereads_x(x, e, lin0, lin2):
         dt = x.dtype
         return _MLPReluGather.apply(x, e, lin0.weight, lin0.bias, lin2.weight, lin2.bias, graph, first,
                                     shadow(lin0.weight, dt), shadow(lin2.weight, dt), sink_x, sink_e)
@@ -1306,7 +1322,7 @@ class _SeedPool(torch.autograd.Function):
         if inplace and x.is_contiguous():       # touch only the <= 2B seed rows of x (fused.py:268 is in place too)
             if stash:       # keep the rows about to change for a consumer that re-reads x in its backward (_MLPReluGather)
                 idx = seeds.tei.long()
-                x._pool_patch = (idx, x.index_select(0, idx))
+                x._pool_patch = (idx, x.index_select(0, idx), x._version, None)
             ctx.mark_dirty(x)
             L.call("tg_seed_pool_inplace", L.ptr(x), L.ptr(xf), L.ptr(seeds.tei), L.ptr(seeds.rowptr), L.ptr(seeds.perm),
                    N, F, seeds.B, C, L.dt(x), L.stream())
@@ -1338,11 +1354,15 @@ POOL_RESTORE = os.environ.get("TABGNN_NO_POOL_RESTORE") != "1"
 
 
 def seed_pool(x, xf, seeds, C, inplace=False, sink_x=None, stash=False):
-    """``inplace``: update x itself (it must be an intermediate nobody saved for backward; autograd checks).
-    ``stash``: (in place only) keep the pre-pool rows on the tensor as ``_pool_patch`` for _MLPReluGather's backward."""
+    """``inplace``: update x itself.  It must be an intermediate nobody needs unchanged in the backward: autograd's
+    version check catches tensors saved with save_for_backward; ``edge_mlp_relu`` (which re-reads its node input by
+    plain reference) checks the version by hand and raises unless the change was stashed, see ``stash``.
+    ``stash``: (in place only) keep the pre-pool rows on the tensor as ``_pool_patch`` = (row ids, rows, version seen,
+    version left) for _MLPReluGather's backward, which puts them back before it re-reads x."""
     out = _SeedPool.apply(x, xf, seeds, C, inplace, sink_x, bool(stash and inplace))
-    if stash and inplace and out is not x:
-        out._pool_patch = getattr(x, "_pool_patch", None)
+    patch = getattr(x, "_pool_patch", None)
+    if stash and inplace and patch is not None:
+        out._pool_patch = x._pool_patch = (patch[0], patch[1], patch[2], out._version)
     return out
 
 

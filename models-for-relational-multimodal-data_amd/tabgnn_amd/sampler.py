@@ -165,15 +165,18 @@ class ColumnStore:
     def device(self):
         return self.labels.device
 
-    def graph_inputs(self, sampler: NeighborSampler, seed_eids, rng_seed=0, lazy=None):
+    def graph_inputs(self, sampler: NeighborSampler, seed_eids, rng_seed=0, lazy=None, index=False):
         """``get_graph_inputs`` (ibm…py:159-180): (node_tf, edge_index, edge_tf, y) with the seed edges first.
         ``lazy`` (default: when the store is on the GPU): the TensorFrames carry the sampled ids (``row_ids``) over the
         whole HBM-resident table and the stype encoders read the raw columns by id — ``tensor_frame[idx]``
-        (ibm…py:163,168) without ever materialising the gathered rows; ``lazy=False`` gathers them (index_select)."""
+        (ibm…py:163,168) without ever materialising the gathered rows; ``lazy=False`` gathers them (index_select).
+        ``edge_index`` is the plain int64 [2, E] tensor every wrapper of ``utils.py`` takes (drop-in for main.py:48);
+        ``index=True`` (opt-in, GPU store, ``TABGNNFusedS`` only) hands over an ``ops.BatchIndex`` instead: the same
+        tensor plus the batch's CSRs built on the host next to the sampler."""
         eid, edge_index, nodes = sampler.sample(seed_eids, rng_seed)
-        return self.batch(eid, edge_index, nodes, len(seed_eids), lazy)
+        return self.batch(eid, edge_index, nodes, len(seed_eids), lazy, index)
 
-    def batch(self, eid, edge_index, nodes, n_seed, lazy=None):
+    def batch(self, eid, edge_index, nodes, n_seed, lazy=None, index=False):
         dev = self.device
         lazy = (dev.type == "cuda") if lazy is None else lazy
         eid_d, nodes_d = eid.to(dev, non_blocking=True), nodes.to(dev, non_blocking=True)
@@ -184,7 +187,9 @@ class ColumnStore:
             edge_tf = TensorFrame({k: v.index_select(0, eid_d) for k, v in self.edge_feats.items()}, self.edge_cols)
             node_tf = TensorFrame({k: v.index_select(0, nodes_d) for k, v in self.node_feats.items()}, self.node_cols)
         y = self.labels.index_select(0, eid_d[:n_seed])
-        if lazy and dev.type == "cuda":      # index structures built on the host too: the model skips its CSR kernels
+        if index:                            # index structures built on the host too: the model skips its CSR kernels
+            if dev.type != "cuda":
+                raise ValueError("index=True needs a store on the GPU (ops.BatchIndex holds device CSRs)")
             return node_tf, batch_index(edge_index, nodes.numel(), n_seed, dev), edge_tf, y
         return node_tf, edge_index.to(dev, non_blocking=True), edge_tf, y
 

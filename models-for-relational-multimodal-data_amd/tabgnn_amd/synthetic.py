@@ -13,6 +13,7 @@ from .frame import TensorFrame, stype
 
 EDGES_PER_SEED = 10702 / 200.0
 NODES_PER_SEED = 12797 / 200.0
+GRAPH_NODES = 515_080    # HI-Small's node table: a sampled subgraph cannot hold more nodes than the graph
 CARDS = (15, 7, 15)   # 'Payment Currency', 'Payment Format', 'Receiving Currency' (sorted names)
 
 EDGE_COLS = {stype.numerical: ["Amount Paid"],
@@ -35,7 +36,7 @@ def sampled_subgraph(batch_size, seed=0):
     max 345, 43 % of nodes without in-edges at B=200)."""
     rs = np.random.RandomState(seed)
     E = int(round(EDGES_PER_SEED * batch_size))
-    N = min(int(round(NODES_PER_SEED * batch_size)), 2 * E)
+    N = min(int(round(NODES_PER_SEED * batch_size)), 2 * E, GRAPH_NODES)
     flat = np.empty(2 * E, dtype=np.int64)
     cover = rs.permutation(2 * E)[:N]
     flat[cover] = rs.permutation(N)

@@ -1,0 +1,209 @@
+"""GPU: the bf16 paths that ``bench.py`` times, against the fp32 oracle (oracle/step.py) — every parameter gradient.
+
+VERDICT r02 item 3: (a) BASELINE configs[1] with the reference's default 8 heads (``fused.py:61``), (b) the ``tabgnn``
+path at S = 130 column tokens (configs[3], ``src/nn/models/tabgnn.py:127-129``) on >= 2 000 node rows, (c) 64 mixed
+columns at C = 256 (configs[4]) with B >= 256 seed edges.  Dropout 0 in both (masks are a separate matter: the
+mask-equality tests of test_gpu_encoder_fused.py / test_gpu_wrapper.py).
+
+Tolerance (stated): activations and GEMM operands are rounded to bf16 (2^-9 relative per rounding) along ~40 operators
+per direction; accumulators, statistics and master weights are fp32.  Per parameter
+
+    ||g - g_ref||_F  <=  REL * ||g_ref||_F  +  ABS * max_k ||g_ref_k||_F
+
+so a tensor of ordinary size must be right to REL in Frobenius norm, and a tensor whose gradient is small against the
+model's largest one may carry rounding noise up to ABS of that — a dropped term in a small gradient (relative error ~1)
+fails the first part unless the whole tensor is below the noise floor.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+REL, ABS = 0.05, 2e-3
+LOGIT_ABS = 0.06
+
+
+def _feats(tf):
+    return {k.value: v for k, v in tf.feat_dict.items()}
+
+
+def compare_gradients(model, want, flat=None, rel=REL, abs_=ABS, min_tensors=20, label=""):
+    """Every parameter gradient of ``model`` (after backward) against ``want`` (dict key -> fp32 oracle gradient)."""
+    gscale = max(v.double().norm().item() for v in want.values())
+    rows = []
+    for k, p in model.named_parameters():
+        ref = want[k]
+        g = p.grad.detach().float().cpu() if p.grad is not None else torch.zeros_like(ref)
+        if flat is not None and p.grad is not None:
+            assert flat.grad.data_ptr() <= p.grad.data_ptr() < flat.grad.data_ptr() + 4 * flat.grad.numel(), k
+        den = ref.double().norm().item()
+        err = (g.double() - ref.double()).norm().item()
+        rows.append((err / max(rel * den + abs_ * gscale, 1e-30), err / max(den, 1e-30), den / gscale, k))
+    rows.sort(reverse=True)
+    print(f"{label} bf16 gradients vs fp32 oracle — worst 6 (gate ratio, rel. Frobenius error, ||g||/max||g||, name):")
+    for r in rows[:6]:
+        print("   %.3f  %.4f  %.2e  %s" % r)
+    big = sorted(r[1] for r in rows if r[2] >= 0.01)
+    if big:
+        print(f"   tensors with ||g|| >= 1% of the largest: {len(big)}, median rel. error {big[len(big) // 2]:.4f}, worst {big[-1]:.4f}")
+    assert len(rows) >= min_tensors
+    bad = [r for r in rows if r[0] > 1.0]
+    assert not bad, bad[:5]
+    return rows
+
+
+def _oracle_grads(sd, forward):
+    from oracle import step as ostep
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    keys = ostep.trainable_keys(sd)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    logits, loss = forward(sd)
+    loss.backward()
+    want = {k: (sd[k].grad.clone() if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in keys}
+    return logits.detach(), float(loss.detach()), want
+
+
+def test_configs1_eight_heads_bf16_every_gradient():
+    """(a) d = 128, L = 2, **H = 8** (reference default ``nhead``, fused.py:61): the fused column-transformer kernels with
+    head dim 16 forward and backward, B = 1024 (wide QKV form, hub pass of the segmented sums, scaled post projection)."""
+    import tabgnn_amd as T
+    import tabgnn_amd.encoder_layer as EL
+    from oracle import step as ostep
+    from tabgnn_amd import synthetic as S
+    B = 1024
+    torch.manual_seed(31)
+    cfg = S.make_config(128, 2, 8, B, backbone_dropout=0.0, head_dropout=0.0, compute_dtype=torch.bfloat16)
+    model = T.TABGNNFusedS(cfg).train()
+    batch = S.make_batch(B, seed=36)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    node_tf, ei, edge_tf, y = batch
+    lw = torch.tensor(cfg["loss_weights"])
+
+    def fwd(sd_):
+        lg = ostep.wrapper_forward(sd_, 8, B, _feats(node_tf), ei, _feats(edge_tf), training=True)
+        return lg, ostep.weighted_ce(lg[:B], y.view(-1), lw)
+    logits, loss, want = _oracle_grads(sd, fwd)
+    model.to(DEV)
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    flat.zero_grad()
+    n0 = dict(EL.STATS)
+    out = model(node_tf.to(DEV), ei.to(DEV), edge_tf.to(DEV))
+    dl = T.ops.weighted_cross_entropy(out[:B], y.to(DEV), lw.to(DEV))
+    dl.backward()
+    assert EL.STATS["fused_fwd"] > n0["fused_fwd"] and EL.STATS["fused_bwd"] > n0["fused_bwd"]      # the benched kernels ran
+    assert (out.detach().float().cpu() - logits).abs().max().item() <= LOGIT_ABS
+    assert abs(dl.item() - loss) <= 2e-2 * abs(loss)
+    compare_gradients(model, want, flat, min_tensors=90, label="configs[1] H=8")
+
+
+def _arxiv_like(V, fan, B, ncol, seed):
+    rs = np.random.RandomState(seed)
+    src, dst, frontier = [], [], rs.choice(V, B, replace=False)
+    for f in fan:
+        nb = rs.randint(0, V, size=(frontier.size, f))
+        src.append(nb.reshape(-1)); dst.append(np.repeat(frontier, f))
+        frontier = np.unique(nb)
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    nodes, inv = np.unique(np.concatenate([src, dst]), return_inverse=True)
+    return inv.reshape(2, -1).astype(np.int64), nodes.size
+
+
+def test_configs3_tabgnn_s130_bf16_every_gradient():
+    """(b) ``TABGNNS`` (utils.py:235-328 -> tabgnn.py:100-151), node classification: S = 130 column attention over >= 2 000
+    sampled node rows (129 numerical columns + CLS), S = 2 over the edge rows, d = 128, 8 heads, 2 FT + 2 PNA layers."""
+    import tabgnn_amd as T
+    from oracle import step as ostep
+    st = T.stype
+    C, ncol = 128, 129
+    ei_np, N = _arxiv_like(40_000, (15, 10), 24, ncol, 3)
+    assert N >= 2000
+    E = ei_np.shape[1]
+    g = torch.Generator().manual_seed(8)
+    names_n = {st.numerical: [f"f_{i}" for i in range(ncol - 1)] + ["year"]}
+    stats_n = {n: dict(mean=-0.1, std=0.11) for n in names_n[st.numerical]}
+    names_e = {st.relation: ["edge_attr"]}
+    node_tf = T.TensorFrame({st.numerical: torch.randn(N, ncol, generator=g) * 0.11 - 0.1}, names_n)
+    edge_tf = T.TensorFrame({st.relation: torch.ones(E, 1)}, names_e)
+    ei = torch.from_numpy(ei_np)
+    y = torch.randint(0, 40, (N,), generator=g)
+    torch.manual_seed(9)
+    cfg = dict(model="tabgnn", task="node_classification", batch_size=24, n_hidden=C, n_gnn_layers=2, n_classes=40,
+               dropout=0.0, backbone_dropout=0.0, nhead=8, num_node_features=ncol, num_edge_features=1,
+               in_degrees=torch.bincount(ei[1], minlength=N), reverse_mp=False,
+               node_encoder=T.StypeWiseFeatureEncoder(C, stats_n, names_n, torch.bfloat16),
+               edge_encoder=T.StypeWiseFeatureEncoder(C, {}, names_e, torch.bfloat16))
+    model = T.TABGNNS(cfg).train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    def fwd(sd_):
+        lg = ostep.tabgnn_wrapper_forward(sd_, 8, 24, _feats(node_tf), ei, _feats(edge_tf), "node_classification",
+                                          training=True)
+        return lg, torch.nn.functional.cross_entropy(lg, y)
+    logits, loss, want = _oracle_grads(sd, fwd)
+    model.to(DEV)
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    flat.zero_grad()
+    out = model(node_tf.to(DEV), ei.to(DEV), edge_tf.to(DEV))
+    assert out.shape == (N, 40)
+    dl = T.ops.weighted_cross_entropy(out, y.to(DEV))
+    dl.backward()
+    err = (out.detach().float().cpu() - logits).abs()
+    print("configs[3] bf16 logits: max abs err %.4f, mean %.5f" % (err.max().item(), err.mean().item()))
+    assert err.max().item() <= 2 * LOGIT_ABS and err.mean().item() <= 0.01      # 40 logits x N rows: the max over 80 k values
+    assert abs(dl.item() - loss) <= 2e-2 * abs(loss)
+    compare_gradients(model, want, flat, min_tensors=50, label="configs[3] S=130")
+
+
+def test_configs4_wide64_c256_bf16_every_gradient():
+    """(c) the fused model on 64 mixed stype columns (32 categorical with up to 10^4 categories, 24 numerical, 8
+    timestamp) at C = 256, S = 65, 8 heads, 2 layers, B = 256 seed edges, bf16 (the shape of bench.py's wide64-c256 leg)."""
+    import tabgnn_amd as T
+    from detparams import rand_subgraph
+    from oracle import step as ostep
+    st = T.stype
+    rs = np.random.RandomState(5)
+    C, B, N, E = 256, 256, 900, 2200
+    cards = [int(c) for c in np.exp(rs.uniform(np.log(2), np.log(1e4), 32))]
+    names = {st.numerical: [f"n{i}" for i in range(24)], st.categorical: [f"c{i}" for i in range(32)],
+             st.timestamp: [f"t{i}" for i in range(8)]}
+    stats = {**{f"n{i}": dict(mean=0.0, std=1.0) for i in range(24)},
+             **{f"c{i}": dict(cardinality=cards[i]) for i in range(32)},
+             **{f"t{i}": dict(min_year=2015) for i in range(8)}}
+    g = torch.Generator().manual_seed(55)
+    cat = torch.stack([torch.randint(-1, c, (E,), generator=g) for c in cards], dim=1)
+    ts = torch.stack([torch.randint(2015, 2024, (E, 8), generator=g), torch.randint(0, 12, (E, 8), generator=g),
+                      torch.randint(0, 31, (E, 8), generator=g), torch.randint(0, 7, (E, 8), generator=g),
+                      torch.randint(0, 24, (E, 8), generator=g), torch.randint(0, 60, (E, 8), generator=g),
+                      torch.randint(0, 60, (E, 8), generator=g)], dim=2)
+    edge_tf = T.TensorFrame({st.numerical: torch.randn(E, 24, generator=g), st.categorical: cat, st.timestamp: ts}, names)
+    node_names = {st.relation: ["node_attr"]}
+    node_tf = T.TensorFrame({st.relation: torch.ones(N, 1)}, node_names)
+    ei = torch.from_numpy(rand_subgraph(N, E, B, 56))
+    y = (torch.arange(B) % 2).long()
+    torch.manual_seed(6)
+    cfg = dict(model="tabgnnfused", task="edge_classification", batch_size=B, n_hidden=C, n_gnn_layers=2, n_classes=2,
+               dropout=0.0, backbone_dropout=0.0, nhead=8, num_node_features=1, num_edge_features=64,
+               in_degrees=torch.bincount(ei[1], minlength=N), reverse_mp=False, load_model=None, checkpoint=False,
+               node_encoder=T.StypeWiseFeatureEncoder(C, {}, node_names, torch.bfloat16),
+               edge_encoder=T.StypeWiseFeatureEncoder(C, stats, names, torch.bfloat16))
+    model = T.TABGNNFusedS(cfg).train()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    lw = torch.tensor([1.0, 9.23])
+
+    def fwd(sd_):
+        lg = ostep.wrapper_forward(sd_, 8, B, _feats(node_tf), ei, _feats(edge_tf), training=True)
+        return lg, ostep.weighted_ce(lg, y, lw)
+    logits, loss, want = _oracle_grads(sd, fwd)
+    model.to(DEV)
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    flat.zero_grad()
+    out = model(node_tf.to(DEV), ei.to(DEV), edge_tf.to(DEV))
+    dl = T.ops.weighted_cross_entropy(out, y.to(DEV), lw.to(DEV))
+    dl.backward()
+    assert (out.detach().float().cpu() - logits).abs().max().item() <= LOGIT_ABS
+    assert abs(dl.item() - loss) <= 2e-2 * abs(loss)
+    compare_gradients(model, want, flat, min_tensors=120, label="configs[4] C=256")

@@ -125,7 +125,7 @@ def test_column_store_batches_by_id_equal_gathered_batches_bit_for_bit():
     sampler = NeighborSampler(ei, N, (10, 10), num_threads=1)
     seeds = rs.choice(E, B, replace=False)
     eid, lei, nodes = sampler.sample(seeds, 5)
-    lazy = store.batch(eid, lei, nodes, B, lazy=True)          # ids + host-built CSRs (BatchIndex)
+    lazy = store.batch(eid, lei, nodes, B, lazy=True, index=True)          # ids + host-built CSRs (BatchIndex, opt-in)
     full = store.batch(eid, lei, nodes, B, lazy=False)         # gathered rows + plain edge_index
     assert lazy[2].row_ids is not None and full[2].row_ids is None and lazy[2].num_rows == full[2].num_rows == eid.numel()
     mat = lazy[2].materialize()
@@ -162,3 +162,40 @@ def test_column_store_batches_by_id_equal_gathered_batches_bit_for_bit():
     assert torch.equal(bi.graph.src, dev_graph.src) and torch.equal(bi.graph.dst, dev_graph.dst)
     assert torch.equal(bi.seeds.rowptr, dev_seeds.rowptr) and torch.equal(bi.seeds.perm[:2 * B], dev_seeds.perm[:2 * B])
     assert torch.equal(bi.seeds.tei, dev_seeds.tei)
+
+
+def test_gpu_store_graph_inputs_feed_every_wrapper_as_plain_edge_index():
+    """``ColumnStore.graph_inputs`` on a GPU store is the drop-in for ``get_graph_inputs`` (main.py:48): its ``edge_index``
+    is a plain int64 tensor, so the non-fused wrappers (``TABGNNS``, ``GNN``: utils.py:111-328) take the batch as it
+    comes; the prebuilt ``ops.BatchIndex`` is opt-in (``index=True``) and only ``TABGNNFusedS`` unwraps it."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    from tabgnn_amd.frame import stype
+    from tabgnn_amd.sampler import ColumnStore, NeighborSampler
+    rs = np.random.RandomState(5)
+    N, E, B = 3000, 20000, 32
+    ei = np.stack([rs.randint(0, N, E), rs.randint(0, N, E)])
+    num, cat, ts = S.edge_table(E, 11)
+    labels = torch.from_numpy((rs.rand(E) < 0.05).astype(np.int64))
+    store = ColumnStore({stype.numerical: torch.from_numpy(num), stype.categorical: torch.from_numpy(cat),
+                         stype.timestamp: torch.from_numpy(ts)}, S.EDGE_COLS,
+                        {stype.relation: torch.ones(N, 1)}, S.NODE_COLS, labels).to(DEV)
+    sampler = NeighborSampler(ei, N, (8, 8), num_threads=1)
+    seeds = rs.choice(E, B, replace=False)
+    node_tf, edge_index, edge_tf, y = store.graph_inputs(sampler, seeds, rng_seed=2)
+    assert isinstance(edge_index, torch.Tensor) and edge_index.dtype == torch.int64 and edge_index.is_cuda
+    _, bi, _, _ = store.graph_inputs(sampler, seeds, rng_seed=2, index=True)
+    assert isinstance(bi, T.ops.BatchIndex) and torch.equal(bi.edge_index, edge_index)
+    torch.manual_seed(0)
+    cfg = S.make_config(32, 2, 4, B, backbone_dropout=0.0, head_dropout=0.0)
+    outs = {}
+    for name, cls in (("tabgnnfused", T.TABGNNFusedS), ("tabgnn", T.TABGNNS), ("pna", T.GNN)):
+        c = dict(cfg)
+        c["model"] = name
+        model = cls(c).to(DEV).train()
+        out = model(node_tf, edge_index, edge_tf)
+        assert out.shape[0] >= B and torch.isfinite(out.float()).all(), name
+        outs[name] = out
+    fused = T.TABGNNFusedS(dict(cfg)).to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(fused(node_tf, edge_index, edge_tf), fused(node_tf, bi, edge_tf))

@@ -154,9 +154,10 @@ def test_fused_training_gradients_match_op_by_op_kernels(S, H, R, use_tail, alph
     assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
 
 
-def test_fused_training_gradients_match_torch_fp32_autograd():
-    """p = 0: against torch.nn.TransformerEncoderLayer + LayerNorm tail in fp32 autograd (the module the reference builds)."""
-    S, H, R = 6, 4, 2000
+@pytest.mark.parametrize("S,H,R", [(6, 4, 2000), (6, 8, 1500), (2, 4, 3000), (2, 8, 999), (32, 4, 120), (32, 8, 77)])
+def test_fused_training_gradients_match_torch_fp32_autograd(S, H, R):
+    """p = 0: against torch.nn.TransformerEncoderLayer + LayerNorm tail in fp32 autograd (the module the reference
+    builds; ``nhead`` 8 is its default, fused.py:61), 4 and 8 heads, S = 2 (edge rows of the tabgnn path), 6 (AML), 32."""
     layer, tail = _layer(H, seed=5)
     x = (torch.randn(R, S, 128) * 1.2).to(torch.bfloat16)
     co = torch.randn(R, S, 128)

@@ -55,3 +55,40 @@ def test_gather_gemms_equal_the_materialised_composition(N, E, first, hub):
         assert (a[i] - b[i]).abs().max().item() <= 2e-2 * scale, i      # bf16 partial sums in different orders
     for pa, pb in zip(a[4], b[4]):
         assert (pa - pb).abs().max().item() <= 2e-3 * pb.abs().max().item() + 1e-6
+
+
+def test_edge_mlp_relu_refuses_an_unstashed_inplace_change_of_its_node_input():
+    """ops._MLPReluGather re-reads its node input in the backward by plain reference (outside autograd's saved-tensor
+    version check).  An in-place ``seed_pool`` on that tensor WITHOUT ``stash`` must raise there instead of giving a
+    silently wrong dW0; with ``stash`` the rows are put back and the gradients equal those of pooling into a copy."""
+    from tabgnn_amd import ops
+    torch.manual_seed(0)
+    N, E, B, F, C = 500, 3000, 40, 128, 128
+    g = _graph(N, E, 2)
+    rs = np.random.RandomState(9)
+    tei = torch.from_numpy(np.stack([rs.randint(0, N, B), rs.randint(0, N, B)])).to(DEV)
+    seeds = ops.SeedIndex(tei, N)
+    lin0, lin2 = torch.nn.Linear(3 * F, F).to(DEV), torch.nn.Linear(F, F).to(DEV)
+    x0 = (torch.randn(N, F, device=DEV) * 0.5).to(torch.bfloat16)
+    e0 = (torch.randn(E, F, device=DEV) * 0.5).to(torch.bfloat16)
+    xf0 = (torch.randn(B, C + 2 * F, device=DEV) * 0.5).to(torch.bfloat16)
+
+    def run(inplace, stash):
+        for p in list(lin0.parameters()) + list(lin2.parameters()):
+            p.grad = None
+        xin = x0.clone().requires_grad_(True)
+        x = xin * 1.0                                   # an intermediate, as x_gnn in the fused layer
+        e = e0.clone().requires_grad_(True)
+        assert ops.edge_mlp_rereads_x(x, e, lin0, lin2)
+        u = ops.edge_mlp_relu(x, e, g, "src", lin0, lin2)
+        pooled = ops.seed_pool(x, xf0.clone().requires_grad_(True), seeds, C, inplace=inplace, stash=stash)
+        (u.float().sum() + pooled.float().sum()).backward()
+        return xin.grad.float().clone(), [p.grad.clone() for p in list(lin0.parameters()) + list(lin2.parameters())]
+
+    with pytest.raises(RuntimeError, match="modified in place"):
+        run(True, False)
+    gx_c, gp_c = run(False, False)
+    gx_s, gp_s = run(True, True)
+    assert torch.equal(gx_c, gx_s)
+    for a, b in zip(gp_c, gp_s):
+        assert torch.equal(a, b)

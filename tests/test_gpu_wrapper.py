@@ -264,13 +264,15 @@ def test_gnn_wrapper_routes_match_oracle(name):
     assert np.isfinite(float(l0)) and np.isfinite(float(l1)) and float(l1) < float(l0)
 
 
-# relative Frobenius tolerance of bf16 gradients against the fp32 oracle: activations and GEMM operands are rounded to
-# 8 significant bits (2^-9 relative per rounding) along a chain of ~40 operators per direction, master weights /
-# accumulators / statistics are fp32.  Measured at B=1024 (tools/dbg_e2e_grad.py): median 0.02, worst 0.118 on the
-# first PNA layer's weights — every node enters that layer with the SAME embedding (node_attr == 1), so its BatchNorm
-# normalises a small variance and amplifies the rounding of the convolution output; the same kernels in fp32 are within
-# 1e-4 of the oracle at this size (next test), and the op-by-op and the fused encoder paths give the same figures.
-BF16_GRAD_REL_FRO = 0.15
+# Tolerance of bf16 gradients against the fp32 oracle (tests/test_gpu_bf16_parity.py states it): per parameter
+#     ||g - g_ref|| <= 0.05 ||g_ref|| + 2e-3 max_k ||g_ref_k||      (Frobenius norms)
+# Activations and GEMM operands are rounded to 8 significant bits (2^-9 relative per rounding) along a chain of ~40
+# operators per direction, master weights / accumulators / statistics are fp32.  Measured at B=1024
+# (tools/dbg_e2e_grad.py): median relative error 0.02; the largest relative errors (0.118 in round 2) sit on the first
+# PNA layer's weights — every node enters that layer with the SAME embedding (node_attr == 1), so its BatchNorm
+# normalises a small variance and amplifies the rounding of the convolution output — whose gradient norms are small
+# against the model's largest, which is what the absolute term is for; the same kernels in fp32 are within 1e-4 of the
+# oracle at this size (next test), and the op-by-op and the fused encoder paths give the same figures.
 BF16_GRAD_REL_FRO_MEDIAN = 0.04
 BF16_LOGIT_ABS = 0.06
 
@@ -307,25 +309,10 @@ def test_bf16_train_step_every_gradient_against_fp32_oracle():
     dl.backward()
     assert (out.detach().float().cpu() - logits.detach()).abs().max().item() <= BF16_LOGIT_ABS
     assert abs(dl.item() - loss.item()) <= 2e-2 * abs(loss.item())
-    worst = []
-    gscale = max(v.double().norm().item() for v in want.values())
-    for k, p in model.named_parameters():
-        g = p.grad.detach().float().cpu()
-        assert p.grad.data_ptr() >= flat.grad.data_ptr() and p.grad.data_ptr() < flat.grad.data_ptr() + 4 * flat.grad.numel(), k
-        ref = want[k]
-        den = ref.double().norm().item()
-        err = (g.double() - ref.double()).norm().item()
-        rel = err / max(den, 1e-12)
-        if den < 1e-7:      # structurally zero gradients (padding rows; biases in front of a BatchNorm, whose mean
-            # subtraction cancels them exactly in exact arithmetic) must stay at rounding-noise level
-            assert err <= 1e-3 * gscale, (k, err, gscale)
-            continue
-        worst.append((rel, k))
-    worst.sort(reverse=True)
-    print("bf16 gradient rel. Frobenius error, worst 5:", [(round(r, 4), k) for r, k in worst[:5]])
-    assert len(worst) >= 90
-    assert worst[0][0] <= BF16_GRAD_REL_FRO, worst[:5]
-    assert worst[len(worst) // 2][0] <= BF16_GRAD_REL_FRO_MEDIAN, worst[len(worst) // 2]
+    from test_gpu_bf16_parity import compare_gradients
+    rows = compare_gradients(model, want, flat, min_tensors=90, label="configs[1] H=4")
+    rels = sorted(r[1] for r in rows if r[2] >= 1e-3)
+    assert rels[len(rels) // 2] <= BF16_GRAD_REL_FRO_MEDIAN, rels[len(rels) // 2]
     # 3-step trajectory: the oracle's Adam against FusedAdam on the flat buffer
     sd2 = {k: v.detach().cpu().clone() for k, v in T.TABGNNFusedS(cfg).state_dict().items()}
     for k in sd2:
