@@ -18,7 +18,7 @@
 #define TABGNN_HIP_H_
 #include <stdint.h>
 
-#define TABGNN_HIP_ABI_VERSION 3
+#define TABGNN_HIP_ABI_VERSION 4
 
 #ifdef __cplusplus
 extern "C" {
@@ -269,7 +269,7 @@ int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bias, const vo
                        float p_drop, uint64_t seed, uint32_t rstream, void* stream);
 
 /* ---- the whole column-transformer layer in one kernel per direction (bf16, d_model = dim_feedforward = 128,
- *      4 or 8 heads, S <= 32 tokens per table row): torch nn.TransformerEncoderLayer as configured at
+ *      4 or 8 heads, 2 <= S <= 32 tokens per table row): torch nn.TransformerEncoderLayer as configured at
  *      src/nn/models/fused.py:83-92,187-196 (post-norm, ReLU, dropout p on attention probabilities / both
  *      sub-layer outputs / the hidden activation) + the tab_norm LayerNorm and residual combine of its call sites
  *      (fused.py:160,164,249; tabgnn.py:219):  out = alpha*x + beta_c*LN_t(enc(x))  (tail = 1)  |  out = enc(x).
@@ -279,6 +279,7 @@ int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bias, const vo
  *      backward needs; qkv, scores, attention output, x1 and the hidden activation never reach memory.
  *      rs[4]: dropout streams (attention, norm1, ffn, norm2), the same element indexing as the unfused kernels. ---- */
 int64_t tg_encoder_pack_bytes(void);
+int64_t tg_encoder_stage_bytes(void);   /* bytes of ONE LDS weight image (a [128,128] tile): the backward packs are n of them */
 int64_t tg_encoder_prm_floats(void);
 int32_t tg_encoder_fused_supported(int32_t S, int32_t C, int32_t H, int32_t FF);
 int tg_encoder_pack(const void* w_in, const void* w_o, const void* w1, const void* w2, const float* b_in,

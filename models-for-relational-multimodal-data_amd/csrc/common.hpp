@@ -129,15 +129,27 @@ __device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned st
 // Keep / drop decisions: ONE 32-bit hash decides several consecutive elements (the two integer multiplies of mix32 are
 // quarter-rate instructions; at one hash per element the hash was ~20 % of the fused encoder kernels' time):
 //   * BITS = 16: its low / high half against a 16-bit threshold decide elements 2q, 2q+1 (p honoured to 2^-16),
-//   * BITS = 8 : its four bytes against an 8-bit threshold decide elements 4q .. 4q+3.  Used exactly when the threshold
-//     loses nothing in 8 bits, i.e. p is a multiple of 1/256 (the reference's backbone dropout 0.5; drop_bits8()).
+//   * BITS = 8 : its four bytes against an 8-bit threshold decide elements 4q .. 4q+3.  Used when the threshold loses
+//     nothing in 8 bits, i.e. p is a multiple of 1/256 (drop_bits8()),
+//   * BITS = 1 : p = 1/2 exactly (the reference's backbone dropout, fused.py:62; drop_bits1()): ONE hash decides the 32
+//     consecutive elements 32q .. 32q+31, element e is kept when bit (e & 31) of mix32((e >> 5) ^ key) is set.  The
+//     fused encoder kernels then pay 4 hashes per token row of 128 channels and site, and turn a bit into an AND mask
+//     with one v_bfe_i32 (no compare / select).
 // The choice is a function of the threshold alone and every kernel of the package derives its masks through these
 // functions, so forward, backward, fused and op-by-op paths agree on every element.
+__device__ __host__ __forceinline__ bool drop_bits1(unsigned thresh) { return thresh == 0x80000000u; }
 __device__ __host__ __forceinline__ bool drop_bits8(unsigned thresh) { return (thresh & 0x00ffffffu) == 0u; }
+// template value of a threshold: 0 = no dropout, else the hash bits per element (1 | 8 | 16)
+__host__ __forceinline__ int drop_mode(unsigned thresh) {
+  return thresh == 0u ? 0 : drop_bits1(thresh) ? 1 : drop_bits8(thresh) ? 8 : 16;
+}
 // returns the multiplicative factor: 0 or 1/(1-p)
 template <int BITS>
 __device__ __forceinline__ float drop_scale_key_t(unsigned key, unsigned lo, unsigned thresh, float inv_keep) {
-  if constexpr (BITS == 8) {
+  if constexpr (BITS == 1) {
+    const unsigned hsh = mix32((lo >> 5) ^ key);
+    return ((hsh >> (lo & 31u)) & 1u) ? inv_keep : 0.f;
+  } else if constexpr (BITS == 8) {
     const unsigned hsh = mix32((lo >> 2) ^ key);
     return ((hsh >> (8u * (lo & 3u))) & 0xffu) >= (thresh >> 24) ? inv_keep : 0.f;
   } else {
@@ -148,7 +160,8 @@ __device__ __forceinline__ float drop_scale_key_t(unsigned key, unsigned lo, uns
 }
 // same value as drop_scale(seed, stream, idx) with key = rng_key(seed, stream, idx >> 32), lo = (unsigned)idx
 __device__ __forceinline__ float drop_scale_key(unsigned key, unsigned lo, unsigned thresh, float inv_keep) {
-  return drop_bits8(thresh) ? drop_scale_key_t<8>(key, lo, thresh, inv_keep)        // uniform branch
+  return drop_bits1(thresh) ? drop_scale_key_t<1>(key, lo, thresh, inv_keep)        // uniform branches
+       : drop_bits8(thresh) ? drop_scale_key_t<8>(key, lo, thresh, inv_keep)
                             : drop_scale_key_t<16>(key, lo, thresh, inv_keep);
 }
 __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned stream, unsigned long long idx,
@@ -158,7 +171,13 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned st
 // factors of the four consecutive elements lo0 .. lo0+3 (lo0 a multiple of 4, same key): two hashes, or one
 template <int BITS>
 __device__ __forceinline__ void drop_scale4_t(unsigned key, unsigned lo0, unsigned thresh, float inv_keep, float (&m)[4]) {
-  if constexpr (BITS == 8) {
+  if constexpr (BITS == 1) {
+    const unsigned h = mix32((lo0 >> 5) ^ key) >> (lo0 & 31u);
+    m[0] = (h & 1u) ? inv_keep : 0.f;
+    m[1] = (h & 2u) ? inv_keep : 0.f;
+    m[2] = (h & 4u) ? inv_keep : 0.f;
+    m[3] = (h & 8u) ? inv_keep : 0.f;
+  } else if constexpr (BITS == 8) {
     const unsigned t8 = thresh >> 24;
     const unsigned h = mix32((lo0 >> 2) ^ key);
     m[0] = (h & 0xffu) >= t8 ? inv_keep : 0.f;
@@ -175,7 +194,8 @@ __device__ __forceinline__ void drop_scale4_t(unsigned key, unsigned lo0, unsign
   }
 }
 __device__ __forceinline__ void drop_scale4(unsigned key, unsigned lo0, unsigned thresh, float inv_keep, float (&m)[4]) {
-  if (drop_bits8(thresh)) drop_scale4_t<8>(key, lo0, thresh, inv_keep, m);
+  if (drop_bits1(thresh)) drop_scale4_t<1>(key, lo0, thresh, inv_keep, m);
+  else if (drop_bits8(thresh)) drop_scale4_t<8>(key, lo0, thresh, inv_keep, m);
   else drop_scale4_t<16>(key, lo0, thresh, inv_keep, m);
 }
 // Stream-ordered zero fill by a kernel.  hipMemsetAsync is NOT used on the path: on virtual-memory-managed

@@ -32,43 +32,57 @@
 namespace tg {
 
 typedef __bf16 ef_v8bf __attribute__((ext_vector_type(8)));
+typedef __bf16 ef_v2bf __attribute__((ext_vector_type(2)));
 typedef float ef_f32x16 __attribute__((ext_vector_type(16)));
 typedef float ef_f32x8 __attribute__((ext_vector_type(8)));
+typedef float ef_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned ef_u4 __attribute__((ext_vector_type(4)));
 
 constexpr int EF_C = 128;
-constexpr int EF_STAGE_BYTES = 32768;
+// LDS weight images: rows of 128 bf16 (256 B) PADDED to 272 B.  A lane's fragment address is then
+//     272 * (lane & 31) + 16 * (lane >> 5)  +  a compile-time constant (32 * k-step + 272 * row block + part / buffer offset)
+// i.e. ONE lane-constant base register and the instruction's immediate offset (round 2 used 256-B rows with an XOR
+// swizzle: ~3 integer instructions per ds_read_b128, 1 300 per forward tile), and the 16-lane groups of a ds_read_b128
+// still cover all 64 banks exactly once (68 dwords per row = 4 mod 64).  The images are built in this layout in global
+// memory by the pack kernels, so the LDS-DMA (a linear byte copy) needs no address arithmetic either.
+constexpr int EF_ROWB = 272;
+constexpr int EF_PART_BYTES = 32 * EF_ROWB;           // 32 rows: one head block of Wq / Wk / Wv / Wo^T
+constexpr int EF_UNIT_BYTES = 2 * EF_PART_BYTES;      // 64 rows: half a 128 x 128 tile (17 KiB)
+constexpr int EF_STAGE_BYTES = 4 * EF_PART_BYTES;     // 128 rows (34 KiB)
 #ifndef EF_WAVES_N
 #define EF_WAVES_N 4
 #endif
 #ifndef EF_DBUF
 #define EF_DBUF 0
 #endif
-// Geometry: EF_WAVES_N waves per workgroup.  4 waves + ONE 32 KiB weight buffer (70 KiB of LDS) lets two workgroups share
+// Geometry: EF_WAVES_N waves per workgroup.  4 waves + ONE stage buffer (72 KiB of LDS) lets two workgroups share
 // a CU: their barriers, stage DMAs and input loads overlap each other (measured against 8 waves + two buffers, one
 // workgroup per CU, whose waves all stall together).  EF_DBUF = 1: double-buffered stages (needs EF_WAVES_N = 8 to pay).
 constexpr int EF_WAVES = EF_WAVES_N;         // waves per workgroup
 constexpr int EF_THREADS = 64 * EF_WAVES;
 constexpr int EF_NBUF = EF_DBUF ? 2 : 1;
 constexpr int EF_NSTAGE = 7;              // 4 head blocks (Wq|Wk|Wv rows), Wo, W1, W2
+constexpr int EF_STG_ROWB = 144;          // output restage: 128-byte half rows padded to 144 B (one base + immediates)
 // fp32 parameter block (floats): b_in[384] | b_o | g1 | be1 | b1 | b2 | g2 | be2 | gt | bt  (128 each)
 enum { EF_P_BIN = 0, EF_P_BO = 384, EF_P_G1 = 512, EF_P_BE1 = 640, EF_P_B1 = 768, EF_P_B2 = 896, EF_P_G2 = 1024,
        EF_P_BE2 = 1152, EF_P_GT = 1280, EF_P_BT = 1408, EF_P_FLOATS = 1536 };
 
-__device__ __forceinline__ int ef_off(int row, int ch) {      // 256-byte rows, 16-byte chunk ch (0..15)
-  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-}
-__device__ __forceinline__ int ef_off_wo(int row, int ch) {   // 64-byte rows (k slice of 32 channels), chunk 0..3
-  return 64 * row + 16 * (ch ^ ((row >> 2) & 3));
+__device__ __forceinline__ int ef_off(int row, int ch) {      // padded rows, 16-byte chunk ch (0..15)
+  return EF_ROWB * row + 16 * ch;
 }
 
 // ---------------------------------------------------------------------------------------------- weight pack
-// wpack: [6 stages][32 KiB] bf16 LDS images, prm: EF_P_FLOATS floats.  Data chunk c = 2*ks + h of a row holds channels
+// wpack: [7 stages][34 KiB] bf16 LDS images, prm: EF_P_FLOATS floats.  Data chunk c = 2*ks + h of a row holds channels
 // {16ks + 4h + 0..3, 16ks + 8 + 4h + 0..3}: the accumulator row order of MFMA k-step ks, lane half h.
-// TRANSPOSED variant (backward): stage s holds W^T tiles laid out the same way (see k_encoder_pack_bwd below).
+// TRANSPOSED variant (backward): stage s holds W^T tiles laid out the same way (see k_encoder_pack_tiles below).
 __device__ __forceinline__ uint4 ef_perm_chunk(const unsigned short* wrow, int ks, int h) {
   const uint2 a = *reinterpret_cast<const uint2*>(wrow + 16 * ks + 4 * h);
   const uint2 b = *reinterpret_cast<const uint2*>(wrow + 16 * ks + 8 + 4 * h);
   return make_uint4(a.x, a.y, b.x, b.y);
+}
+// one padded image row: 16 data chunks + the 16-byte pad (zero)
+__device__ __forceinline__ void ef_pack_row(char* dst_row, const unsigned short* wrow, int c /*0..16*/) {
+  *reinterpret_cast<uint4*>(dst_row + 16 * c) = c < 16 ? ef_perm_chunk(wrow, c >> 1, c & 1) : make_uint4(0u, 0u, 0u, 0u);
 }
 
 __global__ void __launch_bounds__(256) k_encoder_pack(const unsigned short* __restrict__ w_in,   // [384,128]
@@ -81,22 +95,21 @@ __global__ void __launch_bounds__(256) k_encoder_pack(const unsigned short* __re
                                                        const float* __restrict__ g2, const float* __restrict__ be2,
                                                        const float* __restrict__ gt, const float* __restrict__ bt,
                                                        char* __restrict__ wpack, float* __restrict__ prm) {
-  const int stage = blockIdx.x;                // 0..6: four head blocks, Wo, W1, W2 -> two 16 KiB units each
+  const int stage = blockIdx.x;                // 0..6: four head blocks, Wo, W1, W2 -> two 17 KiB units each
   char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
   if (stage < 4) {
-    // unit 2*stage: Wq rows | Wk rows (8 KiB each); unit 2*stage + 1: Wv rows (+ 8 KiB unused)
-    for (int p = threadIdx.x; p < 96 * 16; p += blockDim.x) {
-      const int row = p >> 4, c = p & 15, part = row >> 5, r = row & 31;
-      const unsigned short* wrow = w_in + (size_t)(128 * part + 32 * stage + r) * EF_C;
-      *reinterpret_cast<uint4*>(dst + 8192 * part + ef_off(r, c)) = ef_perm_chunk(wrow, c >> 1, c & 1);
+    // unit 2*stage: Wq rows | Wk rows (one part each); unit 2*stage + 1: Wv rows (+ one part of zeros)
+    for (int p = threadIdx.x; p < 128 * 17; p += blockDim.x) {
+      const int row = p / 17, c = p - 17 * row, part = row >> 5, r = row & 31;
+      if (part < 3) ef_pack_row(dst + EF_PART_BYTES * part + EF_ROWB * r, w_in + (size_t)(128 * part + 32 * stage + r) * EF_C, c);
+      else *reinterpret_cast<uint4*>(dst + EF_PART_BYTES * part + EF_ROWB * r + 16 * c) = make_uint4(0u, 0u, 0u, 0u);
     }
-    for (int p = threadIdx.x; p < 512; p += blockDim.x) *reinterpret_cast<uint4*>(dst + 24576 + 16 * p) = make_uint4(0u, 0u, 0u, 0u);
   } else {
-    // rows 0..63 -> first unit, 64..127 -> second (ef_off of a row is 256 * row + a swizzle of its low bits)
+    // rows 0..63 -> first unit, 64..127 -> second
     const unsigned short* w = stage == 4 ? w_o : stage == 5 ? w1 : w2;
-    for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
-      const int row = p >> 4, c = p & 15;
-      *reinterpret_cast<uint4*>(dst + ef_off(row, c)) = ef_perm_chunk(w + (size_t)row * EF_C, c >> 1, c & 1);
+    for (int p = threadIdx.x; p < 128 * 17; p += blockDim.x) {
+      const int row = p / 17, c = p - 17 * row;
+      ef_pack_row(dst + EF_ROWB * row, w + (size_t)row * EF_C, c);
     }
   }
   if (stage == 0) {
@@ -132,6 +145,25 @@ __device__ __forceinline__ ef_f32x16 ef_zero16() {
   for (int i = 0; i < 16; ++i) z[i] = 0.f;
   return z;
 }
+// two bf16 of one dword <-> two floats (v_lshlrev / v_and; v_cvt_pk_bf16_f32)
+__device__ __forceinline__ ef_f2 ef_unpk(unsigned w) {
+  ef_f2 r;
+  r.x = __uint_as_float(w << 16);
+  r.y = __uint_as_float(w & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ unsigned ef_pk(ef_f2 v) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ef_v2bf));
+}
+__device__ __forceinline__ ef_f2 ef_splat(float a) { ef_f2 r; r.x = a; r.y = a; return r; }
+__device__ __forceinline__ ef_f2 ef_fma2(ef_f2 a, ef_f2 b, ef_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ unsigned ef_dw(const ef_v8bf& v, int d) { return __builtin_bit_cast(uint4, v)[d]; }
+// all-ones when bit `bit` of hs is set, else 0 (v_bfe_i32); opaque, or the AND it feeds becomes a compare + select
+__device__ __forceinline__ unsigned ef_bitmask(int hs, int bit) {
+  unsigned m = (unsigned)__builtin_amdgcn_sbfe(hs, bit, 1);
+  asm("" : "+v"(m));
+  return m;
+}
 #ifndef EF_ABL
 #define EF_ABL 0
 #endif
@@ -140,32 +172,37 @@ __device__ __forceinline__ ef_f32x16 ef_zero16() {
 #define EF_MID_FENCE() do { if (!(EF_ABL & 1)) EF_FENCE(); } while (0)
 #define EF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
 
-// LDS-DMA of one 32 KiB stage by the workgroup: 2048 / EF_THREADS pieces of 16 bytes per thread, linear image.
-__device__ __forceinline__ void ef_stage_dma(const char* __restrict__ src, char* lds_dst, int tid) {
-  asm volatile("" : "+v"(tid));      // opaque: the per-lane source addresses are formed here, not hoisted out of the
-                                     // persistent loop as 64-bit register pairs (which then spill)
+// LDS-DMA of BYTES (a multiple of 1 KiB after rounding up: the images are padded accordingly) by the workgroup: one
+// 1 KiB piece per wave-instruction, pieces dealt round-robin to the waves.  The LDS destination and the piece's global
+// base are formed from the wave id in SGPRs (no v_readfirstlane per piece), the lane adds 16 * lane.
+template <int BYTES>
+__device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_dst, int wave, int lane16) {
+  constexpr int NP = (BYTES + 1023) / 1024;
+  unsigned l16 = (unsigned)lane16;
+  asm volatile("" : "+v"(l16));      // opaque: the per-lane source addresses are formed here (uniform 64-bit base +
+                                     // 32-bit lane offset: the saddr form), not hoisted out of the persistent loop as
+                                     // 64-bit register pairs (which then spill)
 #pragma unroll
-  for (int p = 0; p < 2048 / EF_THREADS; ++p) {
-    const int piece = p * EF_THREADS + (tid & ~63);          // wave-uniform first piece of this wave-instruction
-    // wave-uniform 64-bit base + 32-bit lane offset: the saddr form, no per-lane 64-bit address registers
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + (unsigned)((p * EF_THREADS + tid) * 16)),
-        (__attribute__((address_space(3))) void*)(lds_dst + piece * 16), 16, 0, 0);
+  for (int p = 0; p < (NP + EF_WAVES - 1) / EF_WAVES; ++p) {
+    const int q = p * EF_WAVES + wave;                         // wave-uniform piece
+    if ((p + 1) * EF_WAVES <= NP || q < NP)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src + q * 1024) + l16),
+                                       (__attribute__((address_space(3))) void*)(lds_dst + q * 1024), 16, 0, 0);
   }
 }
-// Stage pipeline.  Double-buffered: stage g sits in buffer g & 1, the next stage's DMA is issued on entry, one barrier
-// on leaving.  Single-buffered: barrier (buffer free) -> DMA -> barrier (landed); nothing on leaving.
+// Stage pipeline of the backward kernels.  Double-buffered: stage g sits in buffer g & 1, the next stage's DMA is issued
+// on entry, one barrier on leaving.  Single-buffered: barrier (buffer free) -> DMA -> barrier (landed).
 #if EF_DBUF
 #define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
   char* wb = (gstage & 1) ? wbuf1 : wbuf0;                                                            \
-  if (NEXT_VALID) ef_stage_dma(a.wpack + (size_t)(NEXT) * EF_STAGE_BYTES, (gstage & 1) ? wbuf0 : wbuf1, tid);
+  if (NEXT_VALID) ef_dma<EF_STAGE_BYTES>(a.wpack + (size_t)(NEXT) * EF_STAGE_BYTES, (gstage & 1) ? wbuf0 : wbuf1, wave, lane16);
 #define EF_STAGE_LEAVE() __syncthreads(); gstage += 1;
-#define EF_PIPE_PROLOGUE() if (blockIdx.x < n_it) ef_stage_dma(a.wpack, wbuf0, tid); __syncthreads();
+#define EF_PIPE_PROLOGUE() if (blockIdx.x < n_it) ef_dma<EF_STAGE_BYTES>(a.wpack, wbuf0, wave, lane16); __syncthreads();
 #else
 #define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
   if (!(EF_ABL & 32)) {                                                                               \
     __syncthreads();                                                                                  \
-    ef_stage_dma(a.wpack + (size_t)(CUR) * EF_STAGE_BYTES, wbuf0, tid);                               \
+    ef_dma<EF_STAGE_BYTES>(a.wpack + (size_t)(CUR) * EF_STAGE_BYTES, wbuf0, wave, lane16);            \
     __syncthreads();                                                                                  \
   }                                                                                                   \
   char* wb = wbuf0;
@@ -173,104 +210,102 @@ __device__ __forceinline__ void ef_stage_dma(const char* __restrict__ src, char*
 #define EF_PIPE_PROLOGUE() __syncthreads();
 #endif
 
-// Unit pipeline (forward and feed-forward-half backward): the weights stream through TWO 16 KiB buffers in units of
-// half a stage (64 rows of a 128 x 128 tile; Wq|Wk rows or Wv rows of a head block).  Invariant: unit u sits in buffer
-// gu & 1 and the DMA of unit u+1 is in flight into the other one.  EF_UNIT_NEXT at the end of unit u: barrier (every
-// wave done with u, every wave's pieces of u+1 landed), then the DMA of u+2 goes into u's buffer at once, so it has the
-// whole of unit u+1 to land.  One barrier per unit, no exposed DMA wait.
-constexpr int EF_UNIT_BYTES = 16384;
-__device__ __forceinline__ void ef_unit_dma(const char* __restrict__ src, char* lds_dst, int tid) {
-  asm volatile("" : "+v"(tid));
-#pragma unroll
-  for (int p = 0; p < 1024 / EF_THREADS; ++p) {
-    const int piece = p * EF_THREADS + (tid & ~63);
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + (unsigned)((p * EF_THREADS + tid) * 16)),
-        (__attribute__((address_space(3))) void*)(lds_dst + piece * 16), 16, 0, 0);
-  }
-}
-#define EF_UNIT_CUR() (smem + (gu & 1) * EF_UNIT_BYTES)
-#define EF_UNIT_NEXT(VALID, U2)                                                                       \
-  {                                                                                                   \
-    if (!(EF_ABL & 128)) __syncthreads();                                                             \
-    gu += 1;                                                                                          \
-    if (!(EF_ABL & 32) && (VALID)) ef_unit_dma(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, smem + ((gu + 1) & 1) * EF_UNIT_BYTES, tid); \
-  }
-#define EF_UNIT_PROLOGUE(NU)                                                                          \
-  int gu = 0;                                                                                         \
-  if (blockIdx.x < n_it) ef_unit_dma(a.wpack, smem, tid);                                             \
-  __syncthreads();                                                                                    \
-  if (blockIdx.x < n_it) ef_unit_dma(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, tid);
-
-// mean / rstd of a token's 128 channels held as 8 packed fragments (this lane's 64 + the xor-32 partner's 64)
+// mean / rstd of a token's 128 channels held as 8 packed fragments (this lane's 64 + the xor-32 partner's 64): ONE pass
+// over the bf16-rounded values (sum and sum of squares, packed fp32 math: one v_pk_add + one v_pk_fma per dword)
 __device__ __forceinline__ void ef_row_stats(const ef_v8bf (&zp)[8], float eps, float& mu, float& rstd) {
-  if (EF_ABL & 4) { mu = (float)zp[0][0]; rstd = 1.f + eps; return; }
-  float sum = 0.f;
+  ef_f2 s1 = ef_splat(0.f), s2 = ef_splat(0.f);
 #pragma unroll
   for (int f = 0; f < 8; ++f)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sum += (float)zp[f][j];
+    for (int d = 0; d < 4; ++d) {
+      const ef_f2 v = ef_unpk(ef_dw(zp[f], d));
+      s1 += v;
+      s2 = ef_fma2(v, v, s2);
+    }
+  float sum = s1.x + s1.y, sq = s2.x + s2.y;
   sum += ef_xor32(sum);
+  sq += ef_xor32(sq);
   mu = sum * (1.f / 128.f);
-  float var = 0.f;
-#pragma unroll
-  for (int f = 0; f < 8; ++f) {
-    // unpack again rather than keep 64 unpacked floats alive across the passes (they spill): opaque copy defeats CSE
-    ef_v8bf z = zp[f];
-    asm volatile("" : "+v"(z));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = (float)z[j] - mu; var += d * d; }
-  }
-  var += ef_xor32(var);
-  rstd = rsqrtf(var * (1.f / 128.f) + eps);
+  const float var = fmaxf(sq * (1.f / 128.f) - mu * mu, 0.f);
+  rstd = rsqrtf(var + eps);
 }
-// (z - mu) * rstd * gamma + beta for one fragment; gp / bp point at the fragment's first float4 (channels 16f + 4h ..),
-// the second float4 sits 8 floats further (channels 16f + 8 + 4h ..)
-__device__ __forceinline__ ef_v8bf ef_ln_apply(ef_v8bf z, float mu, float rstd, const float* gp, const float* bp) {
-  asm volatile("" : "+v"(z));          // (see ef_row_stats)
+// (z - mu) * rstd * gamma + beta for one fragment; gp / bp: LDS addresses of the fragment's first float4 (channels
+// 16f + 4h ..), the second float4 sits 8 floats further (channels 16f + 8 + 4h ..).  nmr = -mu * rstd.
+__device__ __forceinline__ ef_v8bf ef_ln_apply(ef_v8bf z, float nmr, float rstd, const float* gp, const float* bp) {
   const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 8);
   const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 8);
-  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-  ef_f32x8 t;
+  const ef_f2 gg[4] = {{g0.x, g0.y}, {g0.z, g0.w}, {g1.x, g1.y}, {g1.z, g1.w}};
+  const ef_f2 bb[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
+  uint4 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) t[j] = ((float)z[j] - mu) * rstd * gg[j] + bb[j];
-  return __builtin_convertvector(t, ef_v8bf);
+  for (int d = 0; d < 4; ++d) {
+    const ef_f2 t = ef_fma2(ef_unpk(ef_dw(z, d)), ef_splat(rstd), ef_splat(nmr));
+    o[d] = ef_pk(ef_fma2(t, gg[d], bb[d]));
+  }
+  return __builtin_bit_cast(ef_v8bf, o);
 }
-__device__ __forceinline__ ef_v8bf ef_ln_combine(ef_v8bf z, ef_v8bf x, float mu, float rstd, const float* gp,
+__device__ __forceinline__ ef_v8bf ef_ln_combine(ef_v8bf z, ef_v8bf x, float nmr, float rstd, const float* gp,
                                                  const float* bp, float alpha, float beta_c) {
-  asm volatile("" : "+v"(z));
   const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 8);
   const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 8);
-  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-  const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-  ef_f32x8 t;
+  const ef_f2 gg[4] = {{g0.x, g0.y}, {g0.z, g0.w}, {g1.x, g1.y}, {g1.z, g1.w}};
+  const ef_f2 bb[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
+  uint4 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = ((float)z[j] - mu) * rstd * gg[j] + bb[j];
-    t[j] = beta_c * v + (alpha != 0.f ? alpha * (float)x[j] : 0.f);
+  for (int d = 0; d < 4; ++d) {
+    const ef_f2 t = ef_fma2(ef_unpk(ef_dw(z, d)), ef_splat(rstd), ef_splat(nmr));
+    const ef_f2 v = ef_fma2(t, gg[d], bb[d]) * ef_splat(beta_c);
+    o[d] = ef_pk(ef_fma2(ef_unpk(ef_dw(x, d)), ef_splat(alpha), v));
   }
-  return __builtin_convertvector(t, ef_v8bf);
+  return __builtin_bit_cast(ef_v8bf, o);
 }
-// Rows of 128 channels held as 8 packed fragments -> memory, through the wave-private 4 KiB restage (64 channels at a
-// time): every lane then stores 16 bytes of a 128-byte row segment.  dst = first token of the wave tile.
-__device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], char* stg, unsigned short* dst, int lane, int tl, int h,
-                                              int nvalid) {
-  asm volatile("" : "+v"(lane), "+v"(tl), "+v"(h));          // (addresses formed here: see ef_stage_dma)
+// Rows of 128 channels held as 8 packed fragments -> memory, through the wave-private restage (64 channels at a time,
+// 144-byte rows): every lane then stores 16 bytes of a 128-byte row segment.  dst = first token of the wave tile.
+//   sw = stg + 144 * tl + 8 * h (this lane's write base), sr = stg + 144 * (lane >> 3) + 16 * (lane & 7) (read base),
+//   go = 256 * (lane >> 3) + 16 * (lane & 7) (byte offset of the lane's first 16-byte piece from dst), t0 = lane >> 3.
+struct EfLaneAddr { char* sw; const char* sr; unsigned go; };
+// buffer descriptor of the nvalid * 256 bytes of a [T,128] bf16 tensor that belong to this wave tile (base and size are
+// wave-uniform): loads of rows past the end return zeros, stores to them are dropped — no exec masking, no branches
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ef_tile_rsrc(const unsigned short* base, long long tok0, int nvalid) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base + tok0 * EF_C), 0, nvalid * (EF_C * 2), 0x00020000);
+}
+__device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], const EfLaneAddr& la, __amdgpu_buffer_rsrc_t dst) {
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
     for (int ff = 0; ff < 4; ++ff) {
       const uint4 v = __builtin_bit_cast(uint4, zp[4 * half + ff]);
-      // fragment f: channels 16f + 4h + 0..3 (.xy) and 16f + 8 + 4h + 0..3 (.zw) -> 16-byte chunks 2ff and 2ff + 1 of the half row
-      *reinterpret_cast<uint2*>(stg + 128 * tl + 16 * ((2 * ff) ^ (tl & 7)) + 8 * h) = make_uint2(v.x, v.y);
-      *reinterpret_cast<uint2*>(stg + 128 * tl + 16 * ((2 * ff + 1) ^ (tl & 7)) + 8 * h) = make_uint2(v.z, v.w);
+      // fragment f: channels 16f + 4h + 0..3 (.xy) and 16f + 8 + 4h + 0..3 (.zw) -> bytes 32ff + 8h and 32ff + 16 + 8h of the half row
+      *reinterpret_cast<uint2*>(la.sw + 32 * ff) = make_uint2(v.x, v.y);
+      *reinterpret_cast<uint2*>(la.sw + 32 * ff + 16) = make_uint2(v.z, v.w);
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int t = (lane >> 3) + 8 * p, c = lane & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(stg + 128 * t + 16 * (c ^ (t & 7)));
-      if ((EF_ABL & 2) ? (t < nvalid - 1000) : (t < nvalid)) *reinterpret_cast<uint4*>(dst + (unsigned)(t * EF_C + 64 * half + 8 * c)) = v;
+      const uint4 v = *reinterpret_cast<const uint4*>(la.sr + 8 * p * EF_STG_ROWB);
+      if (!(EF_ABL & 2))
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, v), dst, la.go + (unsigned)(2048 * p + 128 * half), 0, 0);
+    }
+  }
+}
+
+// Dropout of one 32-channel accumulator tile (registers i <-> channel 8(i>>2) + 4h + (i&3) of the tile) of a linear
+// site: dropped elements are zeroed, kept ones left as they are (the caller folds the 1/(1-p) scale into its next fma).
+// e32 = low word of the element index of the tile's channel 0 for this lane's token (a multiple of 32).
+template <int DROP>
+__device__ __forceinline__ void ef_drop_tile(ef_f32x16& acc, unsigned key, unsigned e32, int h4 /* 4 * h */, unsigned thresh) {
+  if constexpr (DROP == 1) {
+    asm volatile("" : "+v"(e32));      // the hash is formed HERE (its inputs are known from the top of the tile: hoisted, it only holds registers)
+    const int hs = (int)(mix32((e32 >> 5) ^ key) >> h4);         // bit 8(i>>2) + (i&3) decides register i
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      acc[i] = __uint_as_float(__float_as_uint(acc[i]) & ef_bitmask(hs, 8 * (i >> 2) + (i & 3)));
+  } else if constexpr (DROP != 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float dm[4];
+      drop_scale4_t<DROP>(key, e32 + (unsigned)(8 * g) + (unsigned)h4, thresh, 1.f, dm);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * g + j] = dm[j] != 0.f ? acc[4 * g + j] : 0.f;
     }
   }
 }
@@ -290,167 +325,207 @@ struct EfArgs {
   float inv_keep;
   unsigned long long seed;
   unsigned rs0, rs1, rs2, rs3;    // attention, norm1, ffn, norm2 dropout streams
+  int small_idx;                  // 1: every dropout element index of the call is below 2^32 (one RNG key per site)
 };
 
-// Forward.  HD = head dim (16 or 32).  One workgroup = 8 waves = 8 wave tiles of 32 token slots per iteration.
-template <int HD, int DROP /* 0 = off, else hash bits per element: 16 | 8 (common.hpp) */>
+// Forward.  HD = head dim (16 or 32).  One workgroup = EF_WAVES wave tiles of 32 token slots per iteration.
+// Unit pipeline: the weights stream through TWO 17 KiB buffers in units of half a stage (64 rows of a 128 x 128 tile;
+// Wq|Wk rows or Wv rows of a head block); 14 units per iteration, unit u in buffer u & 1.  Invariant: while unit u is
+// read, the DMA of unit u+1 is in flight into the other buffer.  EF_UNIT_NEXT at the end of unit u: barrier (every wave
+// done with u, every wave's pieces of u+1 landed), then the DMA of u+2 goes into u's buffer at once, so it has the
+// whole of unit u+1 to land.  One barrier per unit, no exposed DMA wait.
+#define EF_UBUF(U) (smem + ((U) & 1) * EF_UNIT_BYTES)
+#define EF_UNIT_NEXT(U, VALID, U2, BYTES)                                                             \
+  {                                                                                                   \
+    if (!(EF_ABL & 128)) __syncthreads();                                                             \
+    if (!(EF_ABL & 32) && (VALID)) ef_dma<BYTES>(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, EF_UBUF(U), wave, lane16); \
+  }
+template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* wbuf0 = smem;
-  char* wbuf1 = smem + (EF_NBUF - 1) * EF_STAGE_BYTES;
-  float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);                  // 6 KiB
-  char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;                       // 8 x 8 KiB
+  float* prm = reinterpret_cast<float*>(smem + 2 * EF_UNIT_BYTES);                         // 6 KiB
+  char* stg_all = smem + 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4;                              // EF_WAVES x 8 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tl0 = lane & 31, h0 = lane >> 5;
-  char* stg = stg_all + wave * 8192;          // wave-private: output restage (4 KiB) / parked x1 fragments (8 KiB)
+  const int tl = lane & 31, h = lane >> 5, h4 = 4 * h, lane16 = 16 * lane;
+  char* stg = stg_all + wave * 8192;          // wave-private: output restage (4.5 KiB) / parked x1 fragments (8 KiB)
   constexpr int NH = EF_C / HD;                 // heads
   constexpr int HB = 32 / HD;                   // heads per 32-channel block
-  const float scale = HD == 32 ? 0.17677669529663687f : 0.25f;
+  // softmax in the exp2 domain: q is scaled by log2(e) / sqrt(head dim) when it is packed
+  const float qscale = (HD == 32 ? 0.17677669529663687f : 0.25f) * 1.4426950408889634f;
   const int S = a.S;
   const int RW = 32 / S;                        // table rows per wave tile
   const long long n_wt = (a.R + RW - 1) / RW;   // wave tiles
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
 
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
-  EF_UNIT_PROLOGUE(14)
+  if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
+  __syncthreads();
+  if (blockIdx.x < n_it) ef_dma<EF_PART_BYTES>(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, wave, lane16);
 
-  // softmax geometry of this lane: query slot tl, its table row's token range [row_lo, row_lo + S)
-  const int q_row = tl0 / S;
+  // lane-constant addresses: every LDS access below is one of these bases + an immediate
+  const int fb = EF_ROWB * tl + 16 * h;                          // weight fragment of row tl (+ 32 ks + 272 * row block)
+  const char* pb = reinterpret_cast<const char*>(prm) + 16 * h;  // parameter float4 of this lane half (+ 4 * index)
+  char* park = stg + lane16;                                     // x1 fragments parked for the second residual
+  EfLaneAddr la;
+  la.sw = stg + EF_STG_ROWB * tl + 8 * h;
+  la.sr = stg + EF_STG_ROWB * (lane >> 3) + 16 * (lane & 7);
+  la.go = (unsigned)(256 * (lane >> 3) + 16 * (lane & 7));
+  const unsigned xoff = (unsigned)(256 * tl + 8 * h);             // this lane's first 8 bytes of x in its token row
+  // geometry of this lane's query slot: table row q_row of the tile, tokens [row_lo, row_lo + S)
+  const int q_row = tl / S;
   const int row_lo = q_row * S;
+  // block-diagonal attention mask as one more MFMA k-step: U[token][r] = 16 * [token's row == r]; U U^T adds 256 to the
+  // exp2-domain scores of (key, query) pairs of the same table row, so every other pair underflows in the softmax
+  ef_v8bf uf;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) uf[j] = (__bf16)((8 * h + j) == q_row ? 16.f : 0.f);
+  // one RNG key per dropout site when the indices fit 32 bits (scalar registers), else per lane and tile
+  const unsigned skey0 = rng_key(a.seed, a.rs0, 0u), skey1 = rng_key(a.seed, a.rs1, 0u), skey2 = rng_key(a.seed, a.rs2, 0u),
+                 skey3 = rng_key(a.seed, a.rs3, 0u);
 
   for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
-    int tl = tl0, h = h0;
-    asm volatile("" : "+v"(tl), "+v"(h));     // opaque per iteration: see EF_OPAQUE below
     const long long wt = it * EF_WAVES + wave;
-    const long long row0 = wt * RW;
+    long long row0 = wt * RW;
+    // opaque (scalar registers): nothing below is an affine function of the loop counter for the compiler, so it cannot
+    // strength-reduce the per-lane 64-bit addresses into loop-carried VGPR pairs (11 of them, spilled, before)
+    asm volatile("" : "+s"(row0));
     long long rows_here = a.R - row0;
     rows_here = rows_here < 0 ? 0 : (rows_here > RW ? RW : rows_here);
     const int nvalid = (int)rows_here * S;                       // valid token slots of this wave tile
     const long long tok0 = row0 * S;                             // first token of the wave tile
-    const bool tok_ok = tl < nvalid;
-    const long long tglob = tok0 + tl;
+    const bool has_next = it + gridDim.x < n_it;
 
-    // ---- x in fragment order: xf[ks] element j = x[t][16ks + 8(j>>2) + 4h + (j&3)]
+    // ---- x in fragment order: xf[ks] element j = x[t][16ks + 8(j>>2) + 4h + (j&3)]   (rows past the end read as zeros)
     ef_v8bf xf[8];
-    const unsigned short* xbase = a.x + tok0 * EF_C;                    // wave-uniform
-    const unsigned xoff = (unsigned)((tok_ok ? tl0 : 0) * EF_C + 4 * h0);
+    const __amdgpu_buffer_rsrc_t xrs = ef_tile_rsrc(a.x, tok0, nvalid);
 #define EF_LOAD_X()                                                                                   \
     _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
-      uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);                                         \
-      if (tok_ok) {                                                                                   \
-        lo = *reinterpret_cast<const uint2*>(xbase + (xoff + 16 * ks));                               \
-        hi = *reinterpret_cast<const uint2*>(xbase + (xoff + 16 * ks + 8));                           \
-      }                                                                                               \
+      const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, xoff + 32 * ks, 0, 0));      \
+      const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, xoff + 32 * ks + 16, 0, 0)); \
       xf[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                      \
     }
     EF_LOAD_X()
 
+    // accumulator initialised with a per-row bias (float4 per register group, straight from LDS: no VALU)
+#define EF_ACC_BIAS(ACC, POFF)                                                                        \
+    _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                   \
+      const float4 b = *reinterpret_cast<const float4*>(pb + 4 * ((POFF) + 8 * g));                   \
+      ACC[4 * g] = b.x; ACC[4 * g + 1] = b.y; ACC[4 * g + 2] = b.z; ACC[4 * g + 3] = b.w;             \
+    }
+    // 8 k-steps of out^T[rows, tokens] += W[rows, :] . B : weight fragments at WT + fb + IMM + 32 ks
+#define EF_CHAIN(ACC, WT, IMM, BOP)                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
+      ACC = EF_MFMA(ef_frag((WT) + (IMM) + 32 * ks, fb), BOP[ks], ACC);                               \
+      if (ks == 3) EF_MID_FENCE();                                                                    \
+    }
+
     // ================================================================ attention, per 32-channel head block
     ef_v8bf of[8];               // attention output o^T, packed: the B operand of the output projection
+    // attention-dropout geometry: element index of (table row, head, query q, key k) = ((row * NH + head) * S + q) * S + k
+    // wave-uniform 64-bit part (scalar) + lane part (32 bits)
+    const unsigned long long att_u = (unsigned long long)row0 * (unsigned long long)(NH * S * S);
+    const unsigned att_l = (unsigned)(q_row * NH * S * S + (tl - row_lo) * S + h4 - row_lo);   // head 0, this query, register 0's key
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
-      asm volatile("" : "+v"(tl), "+v"(h));
-      char* wb = EF_UNIT_CUR();                     // unit 2 blk: Wq rows | Wk rows
-
+      const char* wu = EF_UBUF(2 * blk);            // unit 2 blk: Wq rows | Wk rows
+      ef_f32x16 acc;
       // K^T and Q^T blocks [32 d, 32 tokens]
-      ef_f32x16 acc = ef_zero16();
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        acc = EF_MFMA(ef_frag(wb + 8192, ef_off(tl, 2 * ks + h)), xf[ks], acc);
-        if (ks == 3) EF_MID_FENCE();
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BIN + 128 + 32 * blk + 8 * g + 4 * h);
-        acc[4 * g] += b.x; acc[4 * g + 1] += b.y; acc[4 * g + 2] += b.z; acc[4 * g + 3] += b.w;
-      }
+      EF_ACC_BIAS(acc, EF_P_BIN + 128 + 32 * blk)
+      EF_CHAIN(acc, wu, EF_PART_BYTES, xf)
       const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
       EF_FENCE();
-      acc = ef_zero16();
+      EF_ACC_BIAS(acc, EF_P_BIN + 32 * blk)
+      EF_CHAIN(acc, wu, 0, xf)
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        acc = EF_MFMA(ef_frag(wb, ef_off(tl, 2 * ks + h)), xf[ks], acc);
-        if (ks == 3) EF_MID_FENCE();
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BIN + 32 * blk + 8 * g + 4 * h);
-        acc[4 * g] += b.x; acc[4 * g + 1] += b.y; acc[4 * g + 2] += b.z; acc[4 * g + 3] += b.w;
-      }
+      for (int i = 0; i < 16; ++i) acc[i] *= qscale;
       const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
-      EF_UNIT_NEXT(true, 2 * blk + 2)
-      wb = EF_UNIT_CUR();                           // unit 2 blk + 1: Wv rows
+      EF_UNIT_NEXT(2 * blk, true, 2 * blk + 2, EF_UNIT_BYTES)
+      wu = EF_UBUF(2 * blk + 1);                    // unit 2 blk + 1: Wv rows
       // V block in the transposed orientation [32 tokens (rows), 32 d (columns)]
-      acc = ef_zero16();
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        acc = EF_MFMA(xf[ks], ef_frag(wb, ef_off(tl, 2 * ks + h)), acc);
-        if (ks == 3) EF_MID_FENCE();
-      }
       {
         const float bv = prm[EF_P_BIN + 256 + 32 * blk + tl];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += bv;
+        for (int i = 0; i < 16; ++i) acc[i] = bv;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        acc = EF_MFMA(xf[ks], ef_frag(wu + 32 * ks, fb), acc);
+        if (ks == 3) EF_MID_FENCE();
       }
       const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
-      EF_UNIT_NEXT(true, 2 * blk + 3)               // (units 8, 9: Wo)
+      if (blk < 3) { EF_UNIT_NEXT(2 * blk + 1, true, 2 * blk + 3, EF_PART_BYTES) }     // next head block's Wv rows
+      else { EF_UNIT_NEXT(2 * blk + 1, true, 2 * blk + 3, EF_UNIT_BYTES) }            // (units 8, 9: Wo)
 
 #pragma unroll
       for (int hh = 0; hh < HB; ++hh) {
-        // scores S^T[key (rows), query (columns)]
-        ef_f32x16 st = ef_zero16();
+        // scores S^T[key (rows), query (columns)] + 256 * [same table row], exp2 domain
+        ef_f32x16 st = EF_MFMA(uf, uf, ef_zero16());
         if constexpr (HB == 1) {
           st = EF_MFMA(kf0, qf0, st);
           st = EF_MFMA(kf1, qf1, st);
         } else {
           st = hh == 0 ? EF_MFMA(kf0, qf0, st) : EF_MFMA(kf1, qf1, st);
         }
-        // softmax over the keys of the query's own table row
-        float mx = -INFINITY;
-        bool ok[16];
+        float sc = 1.f;           // 1 / sum (x 1 / keep), applied to the O^T columns below
         if (!(EF_ABL & 8)) {
+          float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
-          ok[i] = key >= row_lo && key < row_lo + S;
-          st[i] *= scale;
-          mx = ok[i] ? fmaxf(mx, st[i]) : mx;
-        }
-        mx = fmaxf(mx, ef_xor32(mx));
-        float l = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          st[i] = ok[i] ? __expf(st[i] - mx) : 0.f;
-          l += st[i];
-        }
-        l += ef_xor32(l);
-        const float inv = 1.f / l;
-        if constexpr (DROP) {
-          const int head = blk * HB + hh;
-          const unsigned long long blk0 = ((unsigned long long)(row0 + q_row) * NH + head) * (unsigned long long)(S * S);
-          const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
-          const unsigned key0 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32));
-          const unsigned key1 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32) + 1u);
+          for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, st[i]), st[i + 1]);
+          mx = fmaxf(mx, st[15]);
+          mx = fmaxf(mx, ef_xor32(mx));
+          float l = 0.f;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const unsigned lo = lo0 + (unsigned)(key - row_lo);
-            const unsigned kk = lo < (unsigned)blk0 ? key1 : key0;       // carry into the high word
-            st[i] *= inv * drop_scale_key_t<DROP ? DROP : 16>(kk, lo, a.thresh, a.inv_keep);
+            st[i] = __builtin_amdgcn_exp2f(st[i] - mx);
+            l += st[i];
           }
-        } else {
+          l += ef_xor32(l);
+          sc = __builtin_amdgcn_rcpf(l);
+          if constexpr (DROP == 1) {
+            // 32 consecutive elements per hash: this query's keys sit at att + 4h + (i&3) + 8(i>>2) - row_lo
+            // (element of register i) = ab + (i&3) + 8(i>>2)
+            unsigned ab32 = (unsigned)att_u + att_l + (unsigned)((blk * HB + hh) * S * S);
+            asm volatile("" : "+v"(ab32));      // (hashes formed here, not hoisted to the top of the tile)
+            unsigned k0 = skey0, k1 = skey0;
+            if (!a.small_idx) {
+              const unsigned long long ab = att_u + (unsigned long long)(att_l + (unsigned)((blk * HB + hh) * S * S));
+              k0 = rng_key(a.seed, a.rs0, (unsigned)(ab >> 32));
+              k1 = rng_key(a.seed, a.rs0, (unsigned)((ab + 32) >> 32));
+            }
+            const unsigned g0 = ab32 >> 5;
+            const unsigned w0 = mix32(g0 ^ k0), w1 = mix32(((g0 + 1u) & 0x07ffffffu) ^ k1);
+            const int hs = (int)__builtin_amdgcn_alignbit(w1, w0, ab32 & 31u);
 #pragma unroll
-          for (int i = 0; i < 16; ++i) st[i] *= inv;
-        }
+            for (int i = 0; i < 16; ++i)
+              st[i] = __uint_as_float(__float_as_uint(st[i]) & ef_bitmask(hs, (i & 3) + 8 * (i >> 2)));
+            sc *= a.inv_keep;
+          } else if constexpr (DROP != 0) {
+            const int head = blk * HB + hh;
+            const unsigned long long blk0 = att_u + (unsigned long long)((q_row * NH + head) * S * S);
+            const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
+            const unsigned key0 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32));
+            const unsigned key1 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32) + 1u);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int key = (i & 3) + 8 * (i >> 2) + h4;
+              const unsigned lo = lo0 + (unsigned)(key - row_lo);
+              const unsigned kk = lo < (unsigned)blk0 ? key1 : key0;       // carry into the high word
+              st[i] = drop_scale_key_t<DROP>(kk, lo, a.thresh, 1.f) != 0.f ? st[i] : 0.f;
+            }
+            sc *= a.inv_keep;
+          }
         }
         const ef_v8bf pf0 = ef_pack<0>(st), pf1 = ef_pack<1>(st);
-        // O^T[d (rows), query (columns)] = V^T P^T
-        ef_f32x16 ot = ef_zero16();
-        ot = EF_MFMA(vf0, pf0, ot);
+        // O^T[d (rows), query (columns)] = V^T P^T, columns scaled by 1 / sum
+        ef_f32x16 ot = EF_MFMA(vf0, pf0, ef_zero16());
         ot = EF_MFMA(vf1, pf1, ot);
         if constexpr (HB == 1) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ot[i] *= sc;
           of[2 * blk] = ef_pack<0>(ot); of[2 * blk + 1] = ef_pack<1>(ot);
         } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ot[8 * hh + i] *= sc;
           if (hh == 0) of[2 * blk] = ef_pack<0>(ot); else of[2 * blk + 1] = ef_pack<1>(ot);
         }
       }
@@ -459,80 +534,67 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
     // ================================================================ output projection + LayerNorm 1 (registers)
     // z1 = x + drop(o Wo^T + b_o), rounded to bf16 (what is stored and what the backward recomputes from);
     // x1 = LN(z1) * g1 + be1, rounded to bf16: the feed-forward input and residual
-    asm volatile("" : "+v"(tl), "+v"(h));
-    const unsigned long long e_base = (unsigned long long)tglob * EF_C;
+    const unsigned long long e_base = (unsigned long long)tok0 * EF_C + (unsigned long long)(tl * EF_C);   // (scalar + lane part)
+    const unsigned e_lo = (unsigned)((unsigned long long)tok0 * EF_C) + (unsigned)(tl * EF_C);
+    const float keep_scale = DROP ? a.inv_keep : 1.f;
     ef_v8bf x1f[8];
     {
       ef_v8bf zp[8];
-      const unsigned dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
+      unsigned dkey = skey1;
+      if (DROP && !a.small_idx) dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        char* wu = EF_UNIT_CUR();
-        ef_f32x16 acc = ef_zero16();
+        const char* wu = EF_UBUF(8 + (m >> 1));
+        ef_f32x16 acc;
+        EF_ACC_BIAS(acc, EF_P_BO + 32 * m)
+        EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), of)
+        if (m & 1) { EF_UNIT_NEXT(8 + (m >> 1), true, 10 + (m >> 1), EF_UNIT_BYTES) }      // Wo unit done -> W1 units
+        ef_drop_tile<DROP>(acc, dkey, e_lo + 32u * m, h4, a.thresh);
+        uint4 o0, o1;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wu, ef_off(32 * (m & 1) + tl, 2 * ks + h)), of[ks], acc);
-          if (ks == 3) EF_MID_FENCE();
+        for (int d = 0; d < 4; ++d) {
+          ef_f2 u0, u1;
+          u0.x = acc[2 * d]; u0.y = acc[2 * d + 1]; u1.x = acc[8 + 2 * d]; u1.y = acc[8 + 2 * d + 1];
+          o0[d] = ef_pk(ef_fma2(u0, ef_splat(keep_scale), ef_unpk(ef_dw(xf[2 * m], d))));
+          o1[d] = ef_pk(ef_fma2(u1, ef_splat(keep_scale), ef_unpk(ef_dw(xf[2 * m + 1], d))));
         }
-        if (m & 1) EF_UNIT_NEXT(true, 10 + (m >> 1))      // Wo unit done -> W1 units
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_BO + 32 * m + 8 * g + 4 * h);
-          const float bb[4] = {b.x, b.y, b.z, b.w};
-          float dm[4];
-          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int i = 4 * g + j;
-            float u = acc[i] + bb[j];
-            if constexpr (DROP) u *= dm[j];
-            acc[i] = u + ef_bf(xf[2 * m + (i >> 3)], i & 7);
-          }
-        }
-        zp[2 * m] = ef_pack<0>(acc);
-        zp[2 * m + 1] = ef_pack<1>(acc);
+        zp[2 * m] = __builtin_bit_cast(ef_v8bf, o0);
+        zp[2 * m + 1] = __builtin_bit_cast(ef_v8bf, o1);
         EF_FENCE();
       }
-      if (a.z1) ef_store_rows(zp, stg, a.z1 + tok0 * EF_C, lane, tl, h, nvalid);
+      if (a.z1) ef_store_rows(zp, la, ef_tile_rsrc(a.z1, tok0, nvalid));
       float mu, rstd;
       ef_row_stats(zp, a.eps, mu, rstd);
+      const float nmr = -mu * rstd;
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         EF_FENCE();
-        x1f[f] = ef_ln_apply(zp[f], mu, rstd, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
+        x1f[f] = ef_ln_apply(zp[f], nmr, rstd, reinterpret_cast<const float*>(pb) + EF_P_G1 + 16 * f,
+                             reinterpret_cast<const float*>(pb) + EF_P_BE1 + 16 * f);
         // parked in LDS (lane-linear, read back by the same lane) for the residual of the second sub-layer: 32
         // registers less across the feed-forward
-        *reinterpret_cast<uint4*>(stg + 1024 * f + 16 * lane) = __builtin_bit_cast(uint4, x1f[f]);
+        *reinterpret_cast<uint4*>(park + 1024 * f) = __builtin_bit_cast(uint4, x1f[f]);
       }
     }
 
     // ================================================================ feed-forward 1: h = drop(relu(W1 x1 + b1))
     ef_v8bf hf[8];
     {
-      asm volatile("" : "+v"(tl), "+v"(h));
-      const unsigned dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
+      unsigned dkey = skey2;
+      if (DROP && !a.small_idx) dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        char* wu = EF_UNIT_CUR();
-        ef_f32x16 acc = ef_zero16();
+        const char* wu = EF_UBUF(10 + (m >> 1));
+        ef_f32x16 acc;
+        EF_ACC_BIAS(acc, EF_P_B1 + 32 * m)
+        EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), x1f)
+        if (m & 1) { EF_UNIT_NEXT(10 + (m >> 1), true, 12 + (m >> 1), EF_UNIT_BYTES) }     // W1 unit done -> W2 units
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wu, ef_off(32 * (m & 1) + tl, 2 * ks + h)), x1f[ks], acc);
-          if (ks == 3) EF_MID_FENCE();
-        }
-        if (m & 1) EF_UNIT_NEXT(true, 12 + (m >> 1))      // W1 unit done -> W2 units
+        for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        ef_drop_tile<DROP>(acc, dkey, e_lo + 32u * m, h4, a.thresh);
+        if constexpr (DROP != 0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
-          const float bb[4] = {b.x, b.y, b.z, b.w};
-          float dm[4];
-          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
-            if constexpr (DROP) u *= dm[j];
-            acc[4 * g + j] = u;
-          }
+          for (int i = 0; i < 16; ++i) acc[i] *= keep_scale;
         }
         hf[2 * m] = ef_pack<0>(acc);
         hf[2 * m + 1] = ef_pack<1>(acc);
@@ -542,60 +604,57 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
 
     // ================================================================ feed-forward 2 + LayerNorm 2 (+ tail LayerNorm)
     {
-      asm volatile("" : "+v"(tl), "+v"(h));
-      const bool has_next = it + gridDim.x < n_it;
       ef_v8bf zp[8];
-      const unsigned dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
+      unsigned dkey = skey3;
+      if (DROP && !a.small_idx) dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        char* wu = EF_UNIT_CUR();
-        ef_f32x16 acc = ef_zero16();
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wu, ef_off(32 * (m & 1) + tl, 2 * ks + h)), hf[ks], acc);
-          if (ks == 3) EF_MID_FENCE();
+        const char* wu = EF_UBUF(12 + (m >> 1));
+        ef_f32x16 acc;
+        EF_ACC_BIAS(acc, EF_P_B2 + 32 * m)
+        EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), hf)
+        if (m & 1) {                                 // W2 unit done -> the next iteration's first units
+          if (m == 1) { EF_UNIT_NEXT(12, has_next, 0, EF_UNIT_BYTES) }
+          else { EF_UNIT_NEXT(13, has_next, 1, EF_PART_BYTES) }
         }
-        if (m & 1) EF_UNIT_NEXT(has_next, m >> 1)         // W2 unit done -> the next iteration's first units
-        const ef_v8bf r0 = __builtin_bit_cast(ef_v8bf, *reinterpret_cast<const uint4*>(stg + 1024 * (2 * m) + 16 * lane));
-        const ef_v8bf r1 = __builtin_bit_cast(ef_v8bf, *reinterpret_cast<const uint4*>(stg + 1024 * (2 * m + 1) + 16 * lane));
+        const uint4 r0 = *reinterpret_cast<const uint4*>(park + 1024 * (2 * m));
+        const uint4 r1 = *reinterpret_cast<const uint4*>(park + 1024 * (2 * m + 1));
+        ef_drop_tile<DROP>(acc, dkey, e_lo + 32u * m, h4, a.thresh);
+        uint4 o0, o1;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B2 + 32 * m + 8 * g + 4 * h);
-          const float bb[4] = {b.x, b.y, b.z, b.w};
-          float dm[4];
-          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int i = 4 * g + j;
-            float u = acc[i] + bb[j];
-            if constexpr (DROP) u *= dm[j];
-            acc[i] = u + ef_bf(i < 8 ? r0 : r1, i & 7);
-          }
+        for (int d = 0; d < 4; ++d) {
+          ef_f2 u0, u1;
+          u0.x = acc[2 * d]; u0.y = acc[2 * d + 1]; u1.x = acc[8 + 2 * d]; u1.y = acc[8 + 2 * d + 1];
+          o0[d] = ef_pk(ef_fma2(u0, ef_splat(keep_scale), ef_unpk(r0[d])));
+          o1[d] = ef_pk(ef_fma2(u1, ef_splat(keep_scale), ef_unpk(r1[d])));
         }
-        zp[2 * m] = ef_pack<0>(acc);
-        zp[2 * m + 1] = ef_pack<1>(acc);
+        zp[2 * m] = __builtin_bit_cast(ef_v8bf, o0);
+        zp[2 * m + 1] = __builtin_bit_cast(ef_v8bf, o1);
         EF_FENCE();
       }
-      if (a.z2) ef_store_rows(zp, stg, a.z2 + tok0 * EF_C, lane, tl, h, nvalid);
+      if (a.z2) ef_store_rows(zp, la, ef_tile_rsrc(a.z2, tok0, nvalid));
       float mu, rstd;
       ef_row_stats(zp, a.eps, mu, rstd);
+      float nmr = -mu * rstd;
       // x2 = LN2(z2), rounded to bf16 as the unfused path stores it
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         EF_FENCE();
-        zp[f] = ef_ln_apply(zp[f], mu, rstd, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
+        zp[f] = ef_ln_apply(zp[f], nmr, rstd, reinterpret_cast<const float*>(pb) + EF_P_G2 + 16 * f,
+                            reinterpret_cast<const float*>(pb) + EF_P_BE2 + 16 * f);
       }
       if (a.tail) {
         ef_row_stats(zp, a.eps, mu, rstd);
+        nmr = -mu * rstd;
         if (a.alpha != 0.f) { EF_LOAD_X() }       // x again for the combine (L2-hot): its registers were free in between
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
           EF_FENCE();
-          zp[f] = ef_ln_combine(zp[f], xf[f], mu, rstd, prm + EF_P_GT + 16 * f + 4 * h, prm + EF_P_BT + 16 * f + 4 * h,
-                                a.alpha, a.beta_c);
+          zp[f] = ef_ln_combine(zp[f], xf[f], nmr, rstd, reinterpret_cast<const float*>(pb) + EF_P_GT + 16 * f,
+                                reinterpret_cast<const float*>(pb) + EF_P_BT + 16 * f, a.alpha, a.beta_c);
         }
       }
-      ef_store_rows(zp, stg, a.out + tok0 * EF_C, lane, tl, h, nvalid);
+      ef_store_rows(zp, la, ef_tile_rsrc(a.out, tok0, nvalid));
     }
   }
 }
@@ -669,8 +728,12 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
   float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);
   char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tl0 = lane & 31, h0 = lane >> 5;
+  const int tl0 = lane & 31, h0 = lane >> 5, lane16 = 16 * lane;
   char* stg = stg_all + wave * 8192;
+  EfLaneAddr la;
+  la.sw = stg + EF_STG_ROWB * tl0 + 8 * h0;
+  la.sr = stg + EF_STG_ROWB * (lane >> 3) + 16 * (lane & 7);
+  la.go = (unsigned)(256 * (lane >> 3) + 16 * (lane & 7));
   const int S = a.S;
   const int RW = 32 / S;
   const long long n_wt = (a.R + RW - 1) / RW;
@@ -716,7 +779,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         EF_FENCE();
-        x2f[f] = ef_ln_apply(zf[f], mu2, rstd2, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
+        x2f[f] = ef_ln_apply(zf[f], -mu2 * rstd2, rstd2, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
       }
       float mut, rstdt, s1, s2;
       ef_row_stats(x2f, a.eps, mut, rstdt);
@@ -749,7 +812,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         }
       }
     }
-    ef_store_rows(gf, stg, a.dy2 + tok0 * EF_C, lane, tl, h, nvalid);            // d_y2: operand of dW2 (and db2)
+    ef_store_rows(gf, la, ef_tile_rsrc(a.dy2, tok0, nvalid));            // d_y2: operand of dW2 (and db2)
 
     // ---- x1 = LN1(z1) (recomputed), written as the X operand of dW1
     ef_v8bf x1f[8];
@@ -760,9 +823,9 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         EF_FENCE();
-        x1f[f] = ef_ln_apply(zf[f], mu1, rstd1, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
+        x1f[f] = ef_ln_apply(zf[f], -mu1 * rstd1, rstd1, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
       }
-      ef_store_rows(x1f, stg, a.x1out + tok0 * EF_C, lane, tl, h, nvalid);
+      ef_store_rows(x1f, la, ef_tile_rsrc(a.x1out, tok0, nvalid));
     }
 
     // ---- stage W1: h = drop(relu(W1 x1 + b1)) (recomputed), written as the X operand of dW2
@@ -796,7 +859,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         hf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
-      ef_store_rows(hf, stg, a.hout + tok0 * EF_C, lane, tl, h, nvalid);
+      ef_store_rows(hf, la, ef_tile_rsrc(a.hout, tok0, nvalid));
       EF_STAGE_LEAVE()
     }
 
@@ -819,7 +882,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         hf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
-      ef_store_rows(hf, stg, a.dhpre + tok0 * EF_C, lane, tl, h, nvalid);
+      ef_store_rows(hf, la, ef_tile_rsrc(a.dhpre, tok0, nvalid));
       EF_STAGE_LEAVE()
     }
 
@@ -841,7 +904,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         dzf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
-      ef_store_rows(dzf, stg, a.dx1 + tok0 * EF_C, lane, tl, h, nvalid);
+      ef_store_rows(dzf, la, ef_tile_rsrc(a.dx1, tok0, nvalid));
       EF_STAGE_LEAVE()
     }
   }
@@ -900,9 +963,13 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
   float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);
   char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tl0 = lane & 31, h0 = lane >> 5;
+  const int tl0 = lane & 31, h0 = lane >> 5, lane16 = 16 * lane;
   char* stg = stg_all + wave * 8192;
-  float* tab = reinterpret_cast<float*>(stg + 4096);            // [3][32]: max, 1/sum, delta per query slot
+  EfLaneAddr la;
+  la.sw = stg + EF_STG_ROWB * tl0 + 8 * h0;
+  la.sr = stg + EF_STG_ROWB * (lane >> 3) + 16 * (lane & 7);
+  la.go = (unsigned)(256 * (lane >> 3) + 16 * (lane & 7));
+  float* tab = reinterpret_cast<float*>(stg + 6144);            // [3][32]: max, 1/sum, delta per query slot
   constexpr int NH = 4;
   const float scale = 0.17677669529663687f;
   const int S = a.S;
@@ -960,8 +1027,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
         }
         dyf[f] = __builtin_convertvector(dz, ef_v8bf);
       }
-      ef_store_rows(zf, stg, a.dx + tok0 * EF_C, lane, tl, h, nvalid);
-      ef_store_rows(dyf, stg, a.dy + tok0 * EF_C, lane, tl, h, nvalid);
+      ef_store_rows(zf, la, ef_tile_rsrc(a.dx, tok0, nvalid));
+      ef_store_rows(dyf, la, ef_tile_rsrc(a.dy, tok0, nvalid));
     }
     EB_LOAD(xf, a.x)
 
@@ -990,7 +1057,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
       }
       ef_f32x16 acc;
       // 1. K^T, Q^T [32 d (rows), 32 tokens]
-      EA_CHAIN_STD(acc, 8192, xf)
+      EA_CHAIN_STD(acc, EF_PART_BYTES, xf)
       EA_ROWBIAS(acc, EF_P_BIN + 128 + 32 * blk)
       const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
       EF_FENCE();
@@ -1031,7 +1098,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
       tab[32 + tl] = inv;
 
       // 3. V [tokens (rows), d]; O^T = V^T Pd^T, written (operand of dWo)
-      EA_CHAIN_TR(acc, 16384, xf)
+      EA_CHAIN_TR(acc, 2 * EF_PART_BYTES, xf)
       {
         const float bv = prm[EF_P_BIN + 256 + 32 * blk + tl];
 #pragma unroll
@@ -1058,10 +1125,10 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
       EF_FENCE();
 
       // 4. dO^T [d, q] = Wo^T rows . d_y ; V^T [d, key] ; dPd^T = V dO^T ; dS^T
-      EA_CHAIN_STD(acc, 24576, dyf)
+      EA_CHAIN_STD(acc, 3 * EF_PART_BYTES, dyf)
       const ef_v8bf dof0 = ef_pack<0>(acc), dof1 = ef_pack<1>(acc);
       EF_FENCE();
-      EA_CHAIN_STD(acc, 16384, xf)
+      EA_CHAIN_STD(acc, 2 * EF_PART_BYTES, xf)
       EA_ROWBIAS(acc, EF_P_BIN + 256 + 32 * blk)
       const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
       EF_FENCE();
@@ -1091,7 +1158,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
       EF_FENCE();
 
       // 5. dO [q (rows), d] ; P, Pd with queries on rows ; dV^T [d, key]
-      EA_CHAIN_TR(acc, 24576, dyf)
+      EA_CHAIN_TR(acc, 3 * EF_PART_BYTES, dyf)
       const ef_v8bf dotf0 = ef_pack<0>(acc), dotf1 = ef_pack<1>(acc);
       EF_FENCE();
       ef_f32x16 p2 = ef_zero16();
@@ -1136,7 +1203,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs
       EF_FENCE();
 
       // 6. K [key (rows), d] ; dQ^T [d, q] = K-contracted with dS^T
-      EA_CHAIN_TR(acc, 8192, xf)
+      EA_CHAIN_TR(acc, EF_PART_BYTES, xf)
       {
         const float bk = prm[EF_P_BIN + 128 + 32 * blk + tl];
 #pragma unroll
@@ -1186,11 +1253,11 @@ __global__ void __launch_bounds__(256) k_encoder_pack_attn_bwd(const unsigned sh
                                                                 char* __restrict__ wpack) {
   const int stage = blockIdx.x;
   char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
-  for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
-    const int row = p >> 4, c = p & 15, part = row >> 5, r = row & 31;
+  for (int p = threadIdx.x; p < 128 * 17; p += blockDim.x) {
+    const int row = p / 17, c = p - 17 * row, part = row >> 5, r = row & 31;
     const unsigned short* wrow = part < 3 ? w_in + (size_t)(128 * part + 32 * stage + r) * EF_C
                                           : w_o_t + (size_t)(32 * stage + r) * ld_ot;
-    *reinterpret_cast<uint4*>(dst + 8192 * part + ef_off(r, c)) = ef_perm_chunk(wrow, c >> 1, c & 1);
+    ef_pack_row(dst + EF_PART_BYTES * part + EF_ROWB * r, wrow, c);
   }
 }
 
@@ -1314,9 +1381,9 @@ __global__ void __launch_bounds__(256) k_encoder_pack_tiles(const EfTileList t, 
   char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
   const unsigned short* w = t.src[stage];
   const int ld = t.ld[stage];
-  for (int p = threadIdx.x; p < 128 * 16; p += blockDim.x) {
-    const int row = p >> 4, c = p & 15;
-    *reinterpret_cast<uint4*>(dst + ef_off(row, c)) = ef_perm_chunk(w + (size_t)row * ld, c >> 1, c & 1);
+  for (int p = threadIdx.x; p < 128 * 17; p += blockDim.x) {
+    const int row = p / 17, c = p - 17 * row;
+    ef_pack_row(dst + EF_ROWB * row, w + (size_t)row * ld, c);
   }
 }
 
@@ -1325,6 +1392,7 @@ __global__ void __launch_bounds__(256) k_encoder_pack_tiles(const EfTileList t, 
 using namespace tg;
 
 extern "C" int64_t tg_encoder_pack_bytes(void) { return (int64_t)EF_NSTAGE * EF_STAGE_BYTES; }
+extern "C" int64_t tg_encoder_stage_bytes(void) { return EF_STAGE_BYTES; }
 extern "C" int64_t tg_encoder_prm_floats(void) { return EF_P_FLOATS; }
 
 // Builds the LDS weight images + the fp32 parameter block of one ColumnTransformerLayer call (bf16 weights [out,in]
@@ -1346,7 +1414,7 @@ extern "C" int tg_encoder_pack(const void* w_in, const void* w_o, const void* w1
 }
 
 extern "C" int32_t tg_encoder_fused_supported(int32_t S, int32_t C, int32_t H, int32_t FF) {
-  return C == 128 && FF == 128 && (H == 4 || H == 8) && S >= 1 && S <= 32;
+  return C == 128 && FF == 128 && (H == 4 || H == 8) && S >= 2 && S <= 32;     // (S = 1: the mask k-step holds 16 table rows per tile)
 }
 
 // out [R,S,128] = encoder layer (+ tail) of x [R,S,128], bf16; z1 / z2 (pre-LayerNorm sums, what a recomputing backward
@@ -1366,6 +1434,8 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
   a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1]; a.rs2 = rs[2]; a.rs3 = rs[3];
+  // every dropout element index (R*S*128 of the linear sites, R*H*S*S of the attention probabilities, + one tile) < 2^32
+  a.small_idx = ((double)(R + 32) * S * 128.0 < 4294967296.0 && (double)(R + 32) * H * S * S < 4294967296.0) ? 1 : 0;
   const int RW = 32 / S;
   const long long n_wt = (R + RW - 1) / RW, n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   static int n_cu = 0;
@@ -1377,9 +1447,9 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
   }
   const long long slots = (long long)n_cu * (EF_DBUF ? 1 : 2);
   const unsigned grid = (unsigned)(n_it < slots ? n_it : slots);
-  const size_t lds = EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
+  const size_t lds = 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
   // DROP template value: 0 = no dropout, else the hash bits per element the threshold allows (common.hpp)
-  const int drop = a.thresh == 0u ? 0 : (drop_bits8(a.thresh) ? 8 : 16);
+  const int drop = drop_mode(a.thresh);
 #define EF_LAUNCH_FWD(HD_, DR_)                                                                                \
   {                                                                                                            \
     static bool attr_done = false;                                                                             \
@@ -1391,9 +1461,9 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
     hipLaunchKernelGGL((k_encoder_fwd<HD_, DR_>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);  \
   }
   if (H == 4) {
-    if (drop == 0) EF_LAUNCH_FWD(32, 0) else if (drop == 8) EF_LAUNCH_FWD(32, 8) else EF_LAUNCH_FWD(32, 16)
+    if (drop == 0) EF_LAUNCH_FWD(32, 0) else if (drop == 1) EF_LAUNCH_FWD(32, 1) else if (drop == 8) EF_LAUNCH_FWD(32, 8) else EF_LAUNCH_FWD(32, 16)
   } else {
-    if (drop == 0) EF_LAUNCH_FWD(16, 0) else if (drop == 8) EF_LAUNCH_FWD(16, 8) else EF_LAUNCH_FWD(16, 16)
+    if (drop == 0) EF_LAUNCH_FWD(16, 0) else if (drop == 1) EF_LAUNCH_FWD(16, 1) else if (drop == 8) EF_LAUNCH_FWD(16, 8) else EF_LAUNCH_FWD(16, 16)
   }
 #undef EF_LAUNCH_FWD
   TG_LAUNCH_CHECK();
@@ -1437,7 +1507,7 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
                                        void* dhpre, void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S,
                                        int32_t tail, float beta_c, float eps, float p_drop, uint64_t seed,
                                        const uint32_t* rs, void* stream) {
-  TG_CHECK(S >= 1 && S <= 32, "tg_encoder_bwd_ffn_bf16: unsupported S=%d", S);
+  TG_CHECK(S >= 2 && S <= 32, "tg_encoder_bwd_ffn_bf16: unsupported S=%d", S);
   TG_CHECK(g && z1 && z2 && dx1 && dy2 && hout && dhpre && x1out && wpack && prm && rs, "tg_encoder_bwd_ffn_bf16: null operand");
   if (R <= 0) return 0;
   EbArgs a;
@@ -1450,7 +1520,7 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
   a.seed = seed; a.rs2 = rs[2]; a.rs3 = rs[3];
   const size_t lds = ef_lds_bytes();
   const unsigned grid = ef_grid(R, S);
-  const int drop = a.thresh == 0u ? 0 : (drop_bits8(a.thresh) ? 8 : 16);      // DROP template value (common.hpp)
+  const int drop = drop_mode(a.thresh);      // DROP template value (common.hpp)
 #define EF_LAUNCH_B(DR_)                                                                                       \
   {                                                                                                            \
     static bool attr_done = false;                                                                             \
@@ -1461,7 +1531,7 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
     }                                                                                                          \
     hipLaunchKernelGGL((k_encoder_bwd_ffn<DR_>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);                    \
   }
-  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
+  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 1) EF_LAUNCH_B(1) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
 #undef EF_LAUNCH_B
   TG_LAUNCH_CHECK();
   return 0;
@@ -1500,7 +1570,7 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
                                         void* o, void* dqkv, const void* w_in, const void* w_o_t, int32_t ld_ot,
                                         void* wpack, const float* prm, int64_t R, int32_t S, int32_t H, float alpha,
                                         float eps, float p_drop, uint64_t seed, const uint32_t* rs, void* stream) {
-  TG_CHECK(S >= 1 && S <= 32 && H == 4, "tg_encoder_bwd_attn_bf16: unsupported geometry S=%d H=%d (4 heads only)", S, H);
+  TG_CHECK(S >= 2 && S <= 32 && H == 4, "tg_encoder_bwd_attn_bf16: unsupported geometry S=%d H=%d (4 heads only)", S, H);
   TG_CHECK(dx1 && z1 && x && dx && dy && o && dqkv && w_in && w_o_t && wpack && prm && rs && (g || alpha == 0.f),
            "tg_encoder_bwd_attn_bf16: null operand");
   if (R <= 0) return 0;
@@ -1516,7 +1586,7 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
   a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1];
   const size_t lds = ef_lds_bytes();
   const unsigned grid = ef_grid(R, S);
-  const int drop = a.thresh == 0u ? 0 : (drop_bits8(a.thresh) ? 8 : 16);      // DROP template value (common.hpp)
+  const int drop = drop_mode(a.thresh);      // DROP template value (common.hpp)
 #define EF_LAUNCH_B(DR_)                                                                                       \
   {                                                                                                            \
     static bool attr_done = false;                                                                             \
@@ -1527,7 +1597,7 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
     }                                                                                                          \
     hipLaunchKernelGGL((k_encoder_bwd_attn<DR_>), dim3(grid), dim3(EF_THREADS), lds, st, a);                    \
   }
-  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
+  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 1) EF_LAUNCH_B(1) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
 #undef EF_LAUNCH_B
   TG_LAUNCH_CHECK();
   return 0;

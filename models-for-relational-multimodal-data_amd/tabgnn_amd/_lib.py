@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TABGNN_LIB_PATH") or os.path.join(_HERE, "libtabgnn_hip.so")     # (override: kernel A/B builds)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i32, _i64, _f32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "tg_gemm_tn_gather3_workspace_floats": [_i64, _i32],
     "tg_gemm_tn_gather3_bf16": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i32, _vp],
     "tg_encoder_pack_bytes": [],
+    "tg_encoder_stage_bytes": [],
     "tg_encoder_prm_floats": [],
     "tg_encoder_fused_supported": [_i32, _i32, _i32, _i32],
     "tg_encoder_pack": [_vp] * 17,
@@ -96,7 +97,7 @@ SIGNATURES = {
     "tg_transpose_batched_bf16": [_vp, _vp, _vp, _i32, _vp],
 }
 _RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,
-             "tg_gemm_tn_workspace_floats": _i64, "tg_encoder_pack_bytes": _i64, "tg_encoder_prm_floats": _i64,
+             "tg_gemm_tn_workspace_floats": _i64, "tg_encoder_pack_bytes": _i64, "tg_encoder_stage_bytes": _i64, "tg_encoder_prm_floats": _i64,
              "tg_encoder_ln_grads_partials_floats": _i64, "tg_pna_fold_ws_floats": _i64,
              "tg_gemm_tn_gather3_workspace_floats": _i64}
 

@@ -31,7 +31,7 @@ STATS = {"fused_fwd": 0, "fused_bwd": 0, "fused_bwd_attn": 0}       # launches o
 
 
 def fused_ok(x, nhead, w1):
-    """Shapes the one-kernel layer takes: bf16 rows of S <= 32 column tokens, d_model = feed-forward = 128, 4 or 8 heads."""
+    """Shapes the one-kernel layer takes: bf16 rows of 2 <= S <= 32 column tokens, d_model = feed-forward = 128, 4 or 8 heads."""
     return (_FUSED_LAYER and x.dtype == torch.bfloat16 and x.is_cuda and x.dim() == 3 and x.shape[0] > 0
             and bool(L.load().tg_encoder_fused_supported(x.shape[1], x.shape[2], nhead, w1.shape[0])))
 
@@ -302,7 +302,7 @@ def _fused_backward(ctx, g):
     rs_arr = (ctypes.c_uint32 * 4)(*rs)
     # ---- feed-forward half
     tiles = [lw1.contiguous(), ops.wt(lw2, p_2).contiguous(), ops.wt(lw1, p_1).contiguous()]      # W1, W2^T, W1^T
-    wpack_b = torch.empty(3 * 32768, dtype=torch.uint8, device=dev)
+    wpack_b = torch.empty(3 * L.load().tg_encoder_stage_bytes(), dtype=torch.uint8, device=dev)
     tp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tiles])
     ld = (ctypes.c_int32 * 3)(*[t.stride(0) for t in tiles])
     L.call("tg_encoder_pack_tiles", ctypes.addressof(tp), ctypes.addressof(ld), 3, L.ptr(wpack_b), L.stream())
@@ -332,7 +332,7 @@ def _fused_backward(ctx, g):
         wo_t = ops.wt(lw_o, p_o)
         if not wo_t.is_contiguous():
             wo_t = wo_t.contiguous()
-        wpack_a = torch.empty(4 * 32768, dtype=torch.uint8, device=dev)
+        wpack_a = torch.empty(4 * L.load().tg_encoder_stage_bytes(), dtype=torch.uint8, device=dev)
         d_x, d_y, o = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(3))
         d_qkv = torch.empty(T, 3 * C, dtype=g.dtype, device=dev)
         with_g = tail and alpha != 0.0

@@ -37,7 +37,7 @@ def _torch_reference(layer, tail, x, H, use_tail, alpha, beta_c):
 
 
 @pytest.mark.parametrize("S,H,R", [(6, 4, 1000), (6, 8, 333), (8, 4, 64), (2, 4, 517), (5, 8, 100), (7, 4, 41), (32, 4, 9),
-                                   (1, 4, 70), (6, 4, 3)])
+                                   (6, 4, 3)])
 @pytest.mark.parametrize("use_tail,alpha,beta_c", [(False, 0.0, 1.0), (True, 0.5, 0.5), (True, 0.0, 1.0), (True, 1.0, 0.5)])
 def test_fused_forward_matches_torch_encoder_layer(S, H, R, use_tail, alpha, beta_c):
     from tabgnn_amd.encoder_layer import encoder_layer
