@@ -170,7 +170,15 @@ __device__ __forceinline__ unsigned ef_bitmask(int hs, int bit) {
 // (A/B switches for tools/encoder_ablate.sh; 0 = the shipped kernel)
 #define EF_FENCE() do { if (!(EF_ABL & 64)) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define EF_MID_FENCE() do { if (!(EF_ABL & 1)) EF_FENCE(); } while (0)
+#if EF_ABL & 256      // timing-only build: no matrix instructions (operands kept alive)
+__device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 c) {
+  asm volatile("" :: "v"(a), "v"(b));
+  return c;
+}
+#define EF_MFMA(A, B, C) ef_no_mfma((A), (B), (C))
+#else
 #define EF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+#endif
 
 // LDS-DMA of BYTES (a multiple of 1 KiB after rounding up: the images are padded accordingly) by the workgroup: one
 // 1 KiB piece per wave-instruction, pieces dealt round-robin to the waves.  The LDS destination and the piece's global
@@ -213,6 +221,7 @@ __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_d
 // mean / rstd of a token's 128 channels held as 8 packed fragments (this lane's 64 + the xor-32 partner's 64): ONE pass
 // over the bf16-rounded values (sum and sum of squares, packed fp32 math: one v_pk_add + one v_pk_fma per dword)
 __device__ __forceinline__ void ef_row_stats(const ef_v8bf (&zp)[8], float eps, float& mu, float& rstd) {
+  if (EF_ABL & 512) { mu = (float)zp[0][0]; rstd = 1.f + eps; return; }
   ef_f2 s1 = ef_splat(0.f), s2 = ef_splat(0.f);
 #pragma unroll
   for (int f = 0; f < 8; ++f)

@@ -24,9 +24,5 @@ def cg(model, want, flat=None, rel=0.05, abs_=2e-3, min_tensors=1, label=""):
 
 
 P.compare_gradients = cg
-if dt == "fp32":
-    real_bf16 = torch.bfloat16
-    torch.bfloat16 = torch.float32          # the tests pass torch.bfloat16 as compute dtype: run them in fp32 instead
-    P.LOGIT_ABS = 1.0
-{"c1": P.test_configs1_eight_heads_bf16_every_gradient, "c3": P.test_configs3_tabgnn_s130_bf16_every_gradient,
- "c4": P.test_configs4_wide64_c256_bf16_every_gradient}[which]()
+{"c1": P.test_configs1_eight_heads_every_gradient, "c3": P.test_configs3_tabgnn_s130_every_gradient,
+ "c4": P.test_configs4_wide64_c256_every_gradient}[which](dt)
