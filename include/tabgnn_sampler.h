@@ -42,6 +42,13 @@ int tg_negative_sample(const int64_t* src, const int64_t* dst, int64_t E, const 
  * (all zero, graph.py:70); equal timestamps are ordered by edge position. */
 int tg_edge_ports(const int64_t* src, const int64_t* dst, const int64_t* ts, int64_t E, int64_t num_nodes,
                   int32_t num_threads, int32_t* in_port, int32_t* out_port);
+/* Every index structure the fused model reads from one sampled batch ("emitting CSR-by-dst
+ * directly for the aggregation kernel"), in one call and one int32 buffer: int32 endpoints of the neighbour edges, the
+ * stable CSR by destination and by source, the CSR of the 2B seed endpoints, and the destination-sorted message layout
+ * (parts and their order: csrc/sampler.cpp).  edge_index = int64 [2, ld] LOCAL ids, columns [0, n_seed) the seed edges.
+ * offsets[14]: first int of each of the 13 parts and the total; out == NULL only fills the offsets. */
+int tg_host_batch_index(const int64_t* edge_index, int64_t ld, int64_t E, int64_t n_seed, int64_t N, int32_t* out,
+                        int64_t* offsets);
 #ifdef __cplusplus
 }
 #endif

@@ -16,8 +16,6 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
-#include <unordered_map>
-#include <unordered_set>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -25,16 +23,17 @@
 
 namespace {
 
+struct InEdge { int32_t src, eid; };      // one in-edge: 8 bytes, so the in-edges of a node share cache lines
 struct Graph {
   int64_t num_nodes = 0, num_edges = 0;
   std::vector<int64_t> colptr;   // [num_nodes+1]  in-edges of node v: colptr[v]..colptr[v+1]
-  std::vector<int64_t> in_src;   // source node of each in-edge (CSC order)
-  std::vector<int64_t> in_eid;   // original edge id of each in-edge
-  // per-handle scratch (one sample() call at a time per handle): visited stamps and local ids, O(1) per touch
-  std::vector<uint32_t> emark;   // [num_edges]  emark[e] == stamp <=> e is a seed edge of the current call
-  std::vector<uint32_t> mark;    // [num_nodes]  mark[v] == stamp  <=>  v is in the current subgraph
-  std::vector<int64_t> local;    // [num_nodes]  local id of v (valid where marked)
-  uint32_t stamp = 0;
+  std::vector<InEdge> in;        // (source node, original edge id) of each in-edge, CSC order (ids < 2^31)
+  // per-handle scratch (one sample() call at a time per handle), O(1) per touch, reset at the end of every call
+  std::vector<uint64_t> seedbit; // [num_edges / 64]  bit e set <=> e is a seed edge of the current call (635 KB for
+                                 //                   HI-Small: cache resident, where a stamp word per edge was 20 MB)
+  std::vector<int32_t> local;    // [num_nodes]  -1 = not in the current subgraph, else its local id (0 until relabelled)
+  // reused output staging (capacity grows to the largest batch seen)
+  std::vector<int32_t> e_src, e_dst, e_id, touched, frontier, next;
 };
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -54,13 +53,11 @@ void sample_positions(int64_t deg, int64_t k, uint64_t& rng, std::vector<int64_t
     for (int64_t i = 0; i < deg; ++i) out.push_back(i);
     return;
   }
-  std::unordered_set<int64_t> chosen;
-  chosen.reserve((size_t)k * 2);
-  for (int64_t j = deg - k; j < deg; ++j) {
+  for (int64_t j = deg - k; j < deg; ++j) {      // Floyd: k distinct values; membership by a scan of the <= k chosen so far
     int64_t t = (int64_t)bounded(rng, (uint64_t)j + 1);
-    if (!chosen.insert(t).second) chosen.insert(j);
+    if (std::find(out.begin(), out.end(), t) != out.end()) t = j;
+    out.push_back(t);
   }
-  out.assign(chosen.begin(), chosen.end());
   std::sort(out.begin(), out.end());
 }
 
@@ -74,8 +71,8 @@ const char* tg_sampler_last_error(void) { return g_err; }
 
 // src/dst: int64 [E] global node ids in [0, num_nodes); edge id = position.  Returns an opaque handle (NULL on error).
 void* tg_sampler_create(const int64_t* src, const int64_t* dst, int64_t E, int64_t num_nodes) {
-  if (E < 0 || num_nodes <= 0) {
-    snprintf(g_err, sizeof(g_err), "tg_sampler_create: bad sizes E=%lld N=%lld", (long long)E, (long long)num_nodes);
+  if (E < 0 || num_nodes <= 0 || E > 2147483647LL || num_nodes > 2147483647LL) {
+    snprintf(g_err, sizeof(g_err), "tg_sampler_create: bad sizes E=%lld N=%lld (ids must fit 31 bits)", (long long)E, (long long)num_nodes);
     return nullptr;
   }
   for (int64_t e = 0; e < E; ++e)
@@ -90,15 +87,14 @@ void* tg_sampler_create(const int64_t* src, const int64_t* dst, int64_t E, int64
   g->colptr.assign((size_t)num_nodes + 1, 0);
   for (int64_t e = 0; e < E; ++e) g->colptr[(size_t)dst[e] + 1]++;
   for (int64_t v = 0; v < num_nodes; ++v) g->colptr[(size_t)v + 1] += g->colptr[(size_t)v];
-  g->in_src.resize((size_t)E);
-  g->in_eid.resize((size_t)E);
-  g->mark.assign((size_t)num_nodes, 0u);
-  g->local.assign((size_t)num_nodes, 0);
+  g->in.resize((size_t)E);
+  g->seedbit.assign((size_t)(E + 63) / 64, 0ull);
+  g->local.assign((size_t)num_nodes, -1);
   std::vector<int64_t> cur(g->colptr.begin(), g->colptr.end() - 1);
   for (int64_t e = 0; e < E; ++e) {   // stable: in-edges of a node stay in edge-id order
     int64_t p = cur[(size_t)dst[e]]++;
-    g->in_src[(size_t)p] = src[e];
-    g->in_eid[(size_t)p] = e;
+    g->in[(size_t)p].src = (int32_t)src[e];
+    g->in[(size_t)p].eid = (int32_t)e;
   }
   return g;
 }
@@ -133,103 +129,127 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
              (long long)cap);
     return 1;
   }
-  std::vector<int64_t> e_src, e_dst, e_id;
-  if (++g.stamp == 0) {            // stamp wrapped: clear the marks once every 2^32 calls
-    std::fill(g.mark.begin(), g.mark.end(), 0u);
-    std::fill(g.emark.begin(), g.emark.end(), 0u);
-    g.stamp = 1;
-  }
-  const uint32_t stamp = g.stamp;
-  if (g.emark.size() != (size_t)g.num_edges) g.emark.assign((size_t)g.num_edges, 0u);
+  std::vector<int32_t>&e_src = g.e_src, &e_dst = g.e_dst, &e_id = g.e_id, &touched = g.touched, &frontier = g.frontier,
+                      &next = g.next;
+  e_src.clear(); e_dst.clear(); e_id.clear(); touched.clear(); frontier.clear();
+  int rc = 0;
   for (int64_t i = 0; i < B; ++i) {
     if (seed_src[i] < 0 || seed_src[i] >= g.num_nodes || seed_dst[i] < 0 || seed_dst[i] >= g.num_nodes) {
       snprintf(g_err, sizeof(g_err), "tg_sampler_sample: seed edge %lld has a node id out of range", (long long)i);
+      for (int64_t q = 0; q < i; ++q)
+        if (seed_eid[q] >= 0 && seed_eid[q] < g.num_edges) g.seedbit[(size_t)seed_eid[q] >> 6] = 0ull;
       return 1;
     }
-    e_src.push_back(seed_src[i]); e_dst.push_back(seed_dst[i]); e_id.push_back(seed_eid[i]);
-    if (seed_eid[i] >= 0 && seed_eid[i] < g.num_edges) g.emark[(size_t)seed_eid[i]] = stamp;
+    e_src.push_back((int32_t)seed_src[i]); e_dst.push_back((int32_t)seed_dst[i]); e_id.push_back((int32_t)seed_eid[i]);
+    if (seed_eid[i] >= 0 && seed_eid[i] < g.num_edges) g.seedbit[(size_t)seed_eid[i] >> 6] |= 1ull << (seed_eid[i] & 63);
   }
   // frontier 0 = sorted unique seed endpoints (torch.cat([src, dst]).unique())
-  std::vector<int64_t> frontier(e_src.begin(), e_src.end());
+  frontier.assign(e_src.begin(), e_src.end());
   frontier.insert(frontier.end(), e_dst.begin(), e_dst.end());
   std::sort(frontier.begin(), frontier.end());
   frontier.erase(std::unique(frontier.begin(), frontier.end()), frontier.end());
-  std::vector<int64_t> touched(frontier);          // every node of the subgraph, in first-appearance order
-  for (int64_t v : frontier) g.mark[(size_t)v] = stamp;
+  touched.assign(frontier.begin(), frontier.end());          // every node of the subgraph, in first-appearance order
+  for (int32_t v : frontier) g.local[(size_t)v] = 0;
+  const uint64_t* seedbit = g.seedbit.data();
+  int32_t* local = g.local.data();
+  const InEdge* in = g.in.data();
 
 #ifdef _OPENMP
   const int nthreads = num_threads > 0 ? num_threads : omp_get_max_threads();
 #else
   const int nthreads = 1;
 #endif
-  for (int hop = 0; hop < hops; ++hop) {
+  std::vector<int64_t> pos;
+  for (int hop = 0; hop < hops && rc == 0; ++hop) {
     const int64_t nf = (int64_t)frontier.size();
     const int64_t k = fanout[hop];
-    // pass 1: counts -> offsets (deterministic layout in frontier order)
-    std::vector<int64_t> off((size_t)nf + 1, 0);
-    for (int64_t i = 0; i < nf; ++i) {
-      int64_t deg = g.colptr[(size_t)frontier[(size_t)i] + 1] - g.colptr[(size_t)frontier[(size_t)i]];
-      off[(size_t)i + 1] = off[(size_t)i] + (k < 0 ? deg : std::min(deg, k));
-    }
-    const int64_t tot = off[(size_t)nf];
-    std::vector<int64_t> h_src((size_t)tot), h_dst((size_t)tot), h_id((size_t)tot);
-#pragma omp parallel num_threads(nthreads) if (nf >= 4096)
-    {
-      std::vector<int64_t> pos;
-#pragma omp for schedule(dynamic, 64)
-      for (int64_t i = 0; i < nf; ++i) {
-        const int64_t v = frontier[(size_t)i];
-        const int64_t base = g.colptr[(size_t)v], deg = g.colptr[(size_t)v + 1] - base;
-        uint64_t rng = rng_seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(v + 1));
-        sample_positions(deg, k < 0 ? deg : k, rng, pos);
-        int64_t o = off[(size_t)i];
-        for (int64_t p : pos) {
-          h_src[(size_t)o] = g.in_src[(size_t)(base + p)];
-          h_dst[(size_t)o] = v;
-          h_id[(size_t)o] = g.in_eid[(size_t)(base + p)];
-          ++o;
-        }
+    next.clear();
+    // one edge of the hop: drop it when it is a seed edge, grow the next frontier in first-appearance order
+    auto take = [&](int32_t u, int32_t v, int32_t eid) {
+      if (!((seedbit[(size_t)eid >> 6] >> (eid & 63)) & 1ull)) {
+        e_src.push_back(u); e_dst.push_back(v); e_id.push_back(eid);
       }
-    }
-    // serial merge: drop seed edges, grow the next frontier in first-appearance order
-    std::vector<int64_t> next;
-    for (int64_t j = 0; j < tot; ++j) {
-      if (g.emark[(size_t)h_id[(size_t)j]] != stamp) {
-        if ((int64_t)e_id.size() >= cap) {
-          snprintf(g_err, sizeof(g_err), "tg_sampler_sample: output capacity %lld exceeded", (long long)cap);
-          return 2;
-        }
-        e_src.push_back(h_src[(size_t)j]); e_dst.push_back(h_dst[(size_t)j]); e_id.push_back(h_id[(size_t)j]);
-      }
-      const int64_t u = h_src[(size_t)j];
-      if (g.mark[(size_t)u] != stamp) {
-        g.mark[(size_t)u] = stamp;
+      if (local[(size_t)u] < 0) {
+        local[(size_t)u] = 0;
         next.push_back(u);
         touched.push_back(u);
       }
+    };
+    if (nthreads > 1 && nf >= 4096) {
+      // parallel draw into a deterministic layout (frontier order), then the serial merge above
+      std::vector<int64_t> off((size_t)nf + 1, 0);
+      for (int64_t i = 0; i < nf; ++i) {
+        int64_t deg = g.colptr[(size_t)frontier[(size_t)i] + 1] - g.colptr[(size_t)frontier[(size_t)i]];
+        off[(size_t)i + 1] = off[(size_t)i] + (k < 0 ? deg : std::min(deg, k));
+      }
+      const int64_t tot = off[(size_t)nf];
+      std::vector<InEdge> h_e((size_t)tot);
+      std::vector<int32_t> h_dst((size_t)tot);
+#pragma omp parallel num_threads(nthreads)
+      {
+        std::vector<int64_t> tpos;
+#pragma omp for schedule(dynamic, 64)
+        for (int64_t i = 0; i < nf; ++i) {
+          const int64_t v = frontier[(size_t)i];
+          const int64_t base = g.colptr[(size_t)v], deg = g.colptr[(size_t)v + 1] - base;
+          int64_t o = off[(size_t)i];
+          if (k < 0 || deg <= k) {
+            for (int64_t p = 0; p < deg; ++p, ++o) { h_e[(size_t)o] = in[base + p]; h_dst[(size_t)o] = (int32_t)v; }
+          } else {
+            uint64_t rng = rng_seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(v + 1));
+            sample_positions(deg, k, rng, tpos);
+            for (int64_t p : tpos) { h_e[(size_t)o] = in[base + p]; h_dst[(size_t)o] = (int32_t)v; ++o; }
+          }
+        }
+      }
+      for (int64_t j = 0; j < tot; ++j) take(h_e[(size_t)j].src, h_dst[(size_t)j], h_e[(size_t)j].eid);
+    } else {
+      // single pass: draw and merge node by node (same edge order as the parallel layout)
+      for (int64_t i = 0; i < nf; ++i) {
+        const int32_t v = frontier[(size_t)i];
+        const int64_t base = g.colptr[(size_t)v], deg = g.colptr[(size_t)v + 1] - base;
+        if (i + 4 < nf) __builtin_prefetch(&in[g.colptr[(size_t)frontier[(size_t)i + 4]]]);
+        if (k < 0 || deg <= k) {
+          for (int64_t p = 0; p < deg; ++p) take(in[base + p].src, v, in[base + p].eid);
+        } else {
+          uint64_t rng = rng_seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(v + 1));
+          sample_positions(deg, k, rng, pos);
+          for (int64_t p : pos) take(in[base + p].src, v, in[base + p].eid);
+        }
+      }
+    }
+    if ((int64_t)e_id.size() > cap) {
+      snprintf(g_err, sizeof(g_err), "tg_sampler_sample: output capacity %lld exceeded", (long long)cap);
+      rc = 2;
     }
     frontier.swap(next);
   }
 
   // relabel: every endpoint is a touched node (seed endpoints, expanded destinations, sampled sources);
-  // sorted unique endpoints (torch.unique) = sorted touched list, local id = rank, looked up through g.local
+  // sorted unique endpoints (torch.unique) = sorted touched list, local id = rank
   const int64_t ne = (int64_t)e_id.size();
   const int64_t nn = (int64_t)touched.size();
-  if (nn * 16 > g.num_nodes) {     // dense subgraph: one pass over the mark array beats sorting
-    int64_t w = 0;
-    for (int64_t v = 0; v < g.num_nodes; ++v)
-      if (g.mark[(size_t)v] == stamp) touched[(size_t)w++] = v;
-  } else {
-    std::sort(touched.begin(), touched.end());
+  if (rc == 0) {
+    if (nn * 16 > g.num_nodes) {     // dense subgraph: one pass over the local-id array beats sorting
+      int64_t w = 0;
+      for (int64_t v = 0; v < g.num_nodes; ++v)
+        if (local[(size_t)v] >= 0) touched[(size_t)w++] = (int32_t)v;
+    } else {
+      std::sort(touched.begin(), touched.end());
+    }
+    for (int64_t i = 0; i < nn; ++i) { local[(size_t)touched[(size_t)i]] = (int32_t)i; out_nodes[i] = touched[(size_t)i]; }
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1 && ne >= 65536)
+    for (int64_t j = 0; j < ne; ++j) {
+      out_eid[j] = e_id[(size_t)j];
+      out_edge_index[j] = local[(size_t)e_src[(size_t)j]];
+      out_edge_index[cap + j] = local[(size_t)e_dst[(size_t)j]];
+    }
   }
-  for (int64_t i = 0; i < nn; ++i) g.local[(size_t)touched[(size_t)i]] = i;
-#pragma omp parallel for num_threads(nthreads) schedule(static) if (ne >= 65536)
-  for (int64_t j = 0; j < ne; ++j) {
-    out_eid[j] = e_id[(size_t)j];
-    out_edge_index[j] = g.local[(size_t)e_src[(size_t)j]];
-    out_edge_index[cap + j] = g.local[(size_t)e_dst[(size_t)j]];
-  }
-  std::memcpy(out_nodes, touched.data(), (size_t)nn * sizeof(int64_t));
+  // reset the per-call scratch
+  for (int64_t i = 0; i < nn; ++i) local[(size_t)touched[(size_t)i]] = -1;
+  for (int64_t i = 0; i < B; ++i)
+    if (seed_eid[i] >= 0 && seed_eid[i] < g.num_edges) g.seedbit[(size_t)seed_eid[i] >> 6] = 0ull;
+  if (rc) return rc;
   *n_edges = ne;
   *n_nodes = nn;
   return 0;
@@ -398,5 +418,63 @@ extern "C" int tg_host_csr(const int64_t* key, int64_t M, int64_t N, int32_t* ro
   for (int64_t n = 0; n < N; ++n) rowptr[n + 1] += rowptr[n];
   std::vector<int32_t> pos(rowptr, rowptr + N);
   for (int64_t i = 0; i < M; ++i) perm[pos[(size_t)key[i]]++] = (int32_t)i;
+  return 0;
+}
+
+// Every index structure the fused model reads from one sampled batch, in ONE call and ONE int32 buffer (what
+// tabgnn_amd.sampler.batch_index used to assemble from three tg_host_csr calls and a dozen numpy passes):
+// edge_index = int64 [2, ld] local ids, columns [0, n_seed) = seed edges, [n_seed, E) = neighbour edges (En of them).
+// Parts, in order (offsets[i] = first int of part i, offsets[13] = total):
+//   0 src32 [En] | 1 dst32 [En] | 2 rowptr by dst [N+1] | 3 perm by dst [max(En,1)] | 4 rowptr by src [N+1] |
+//   5 perm by src [max(En,1)] | 6 seed endpoints [2B] (sources then destinations) | 7 rowptr of 6 [N+1] |
+//   8 perm of 6 [max(2B,1)] | 9 dst32[perm by dst] [En] | 10 src32[perm by dst] [En] | 11 inverse of perm by dst [En] |
+//   12 position in the dst-sorted layout of the edges in by-src order [En]
+// (stable counting sorts: the structures tg_csr_build makes on the device).  out == NULL: only the offsets.
+extern "C" int tg_host_batch_index(const int64_t* edge_index, int64_t ld, int64_t E, int64_t n_seed, int64_t N,
+                                   int32_t* out, int64_t* offsets) {
+  if (!edge_index || !offsets || E < 0 || n_seed < 0 || n_seed > E || ld < E || N <= 0 || E > 2147483647LL ||
+      N > 2147483646LL) {
+    snprintf(g_err, sizeof(g_err), "tg_host_batch_index: bad arguments E=%lld n_seed=%lld N=%lld", (long long)E,
+             (long long)n_seed, (long long)N);
+    return 1;
+  }
+  const int64_t En = E - n_seed, B2 = 2 * n_seed, En1 = En > 0 ? En : 1, B21 = B2 > 0 ? B2 : 1;
+  const int64_t sizes[13] = {En, En, N + 1, En1, N + 1, En1, B2, N + 1, B21, En, En, En, En};
+  offsets[0] = 0;
+  for (int i = 0; i < 13; ++i) offsets[i + 1] = offsets[i] + sizes[i];
+  if (!out) return 0;
+  int32_t *src32 = out + offsets[0], *dst32 = out + offsets[1], *rp_d = out + offsets[2], *pm_d = out + offsets[3],
+          *rp_s = out + offsets[4], *pm_s = out + offsets[5], *tei = out + offsets[6], *rp_t = out + offsets[7],
+          *pm_t = out + offsets[8], *dst_sorted = out + offsets[9], *src_sorted = out + offsets[10],
+          *inv = out + offsets[11], *s2s = out + offsets[12];
+  const int64_t *src = edge_index, *dst = edge_index + ld;
+  std::fill(rp_d, rp_d + N + 1, 0); std::fill(rp_s, rp_s + N + 1, 0); std::fill(rp_t, rp_t + N + 1, 0);
+  pm_d[0] = pm_s[0] = pm_t[0] = 0;
+  for (int64_t j = 0; j < E; ++j)
+    if (src[j] < 0 || src[j] >= N || dst[j] < 0 || dst[j] >= N) {
+      snprintf(g_err, sizeof(g_err), "tg_host_batch_index: edge %lld has a node id outside [0, %lld)", (long long)j, (long long)N);
+      return 1;
+    }
+  for (int64_t j = 0; j < En; ++j) {
+    const int32_t sj = (int32_t)src[n_seed + j], dj = (int32_t)dst[n_seed + j];
+    src32[j] = sj; dst32[j] = dj;
+    ++rp_d[dj + 1]; ++rp_s[sj + 1];
+  }
+  for (int64_t i = 0; i < n_seed; ++i) {
+    tei[i] = (int32_t)src[i]; tei[n_seed + i] = (int32_t)dst[i];
+    ++rp_t[tei[i] + 1]; ++rp_t[tei[n_seed + i] + 1];
+  }
+  for (int64_t n = 0; n < N; ++n) { rp_d[n + 1] += rp_d[n]; rp_s[n + 1] += rp_s[n]; rp_t[n + 1] += rp_t[n]; }
+  std::vector<int32_t> pd(rp_d, rp_d + N), ps(rp_s, rp_s + N), pt(rp_t, rp_t + N);
+  for (int64_t j = 0; j < En; ++j) {
+    pm_d[pd[(size_t)dst32[j]]++] = (int32_t)j;
+    pm_s[ps[(size_t)src32[j]]++] = (int32_t)j;
+  }
+  for (int64_t i = 0; i < B2; ++i) pm_t[pt[(size_t)tei[i]]++] = (int32_t)i;
+  for (int64_t k = 0; k < En; ++k) {
+    const int32_t j = pm_d[k];
+    dst_sorted[k] = dst32[j]; src_sorted[k] = src32[j]; inv[j] = (int32_t)k;
+  }
+  for (int64_t k = 0; k < En; ++k) s2s[k] = inv[pm_s[k]];
   return 0;
 }

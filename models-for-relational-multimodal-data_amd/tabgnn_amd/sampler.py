@@ -43,6 +43,8 @@ def _load():
         lib.tg_sampler_sample.restype = C.c_int
         lib.tg_host_csr.argtypes = [i64p, C.c_int64, C.c_int64, i32p, i32p]
         lib.tg_host_csr.restype = C.c_int
+        lib.tg_host_batch_index.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i32p, i64p]
+        lib.tg_host_batch_index.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -116,31 +118,35 @@ def host_csr(keys, num_nodes):
     return rowptr, perm
 
 
-def batch_index(edge_index, num_nodes, n_seed, device):
-    """The index structures of one sampled batch, built on the host next to the sampler and uploaded once:
-    ``ops.BatchIndex`` with the CSR-by-destination / by-source of the neighbour edges (columns ``n_seed:``) and the CSR
-    of the 2B seed endpoints — what ``SubgraphIndex.build`` / ``SeedIndex`` otherwise rebuild on the device in every
-    forward (the sampler emits the CSR the aggregation kernels read)."""
-    from . import ops
+def host_batch_index(edge_index, num_nodes, n_seed):
+    """The index structures of one sampled batch as ONE host int32 array + part offsets (``tg_host_batch_index``: stable
+    counting sorts, the destination-sorted layout, the seed CSR).  Pure host work that releases the GIL: the sampler's
+    worker thread runs it right after ``sample`` so the training thread only uploads."""
+    lib = _load()
     ei = np.ascontiguousarray(edge_index.numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index),
                               dtype=np.int64)
-    nsrc, ndst = np.ascontiguousarray(ei[0, n_seed:]), np.ascontiguousarray(ei[1, n_seed:])
-    tei = np.ascontiguousarray(np.concatenate([ei[0, :n_seed], ei[1, :n_seed]]))
-    rp_d_h, pm_d_h = host_csr(ndst, num_nodes)
-    rp_s_h, pm_s_h = host_csr(nsrc, num_nodes)
-    En = nsrc.shape[0]
-    # the destination-sorted message layout (SubgraphIndex.sorted_view): row k of the sorted layout is edge perm[k]
-    perm = pm_d_h[:En].astype(np.int64)
-    inv = np.empty(En, dtype=np.int32)
-    inv[perm] = np.arange(En, dtype=np.int32)
-    src32, dst32 = nsrc.astype(np.int32), ndst.astype(np.int32)
-    parts = [src32, dst32, rp_d_h, pm_d_h, rp_s_h, pm_s_h, tei.astype(np.int32), *host_csr(tei, num_nodes),
-             dst32[perm], src32[perm], inv, inv[pm_s_h[:En].astype(np.int64)]]
-    flat = torch.from_numpy(np.concatenate([p.ravel() for p in parts])).to(device, non_blocking=True)   # ONE upload
-    views, off = [], 0
-    for p_ in parts:
-        views.append(flat[off:off + p_.size]); off += p_.size
-    src, dst, rp_d, pm_d, rp_s, pm_s, tei_d, rp_t, pm_t, dst_sorted, src_sorted, inv_d, s2s = views
+    E = ei.shape[1]
+    off = np.zeros(14, dtype=np.int64)
+    args = (_p64(ei), E, E, int(n_seed), int(num_nodes))
+    if lib.tg_host_batch_index(*args, None, _p64(off)) != 0:
+        raise ValueError(lib.tg_sampler_last_error().decode())
+    flat = np.empty(int(off[13]), dtype=np.int32)
+    if lib.tg_host_batch_index(*args, flat.ctypes.data_as(C.POINTER(C.c_int32)), _p64(off)) != 0:
+        raise ValueError(lib.tg_sampler_last_error().decode())
+    return flat, off, ei
+
+
+def batch_index(edge_index, num_nodes, n_seed, device, prebuilt=None):
+    """``ops.BatchIndex`` of one sampled batch: the CSR-by-destination / by-source of the neighbour edges (columns
+    ``n_seed:``) and the CSR of the 2B seed endpoints, built on the host next to the sampler and uploaded in ONE transfer
+    — what ``SubgraphIndex.build`` / ``SeedIndex`` otherwise rebuild on the device in every forward (SURVEY 8f rank 1:
+    the sampler emits the CSR the aggregation kernels read).  ``prebuilt`` = the result of ``host_batch_index`` (made
+    in the sampler thread)."""
+    from . import ops
+    flat_h, off, ei = prebuilt if prebuilt is not None else host_batch_index(edge_index, num_nodes, n_seed)
+    flat = torch.from_numpy(flat_h).to(device, non_blocking=True)                                     # ONE upload
+    v = [flat[int(off[i]):int(off[i + 1])] for i in range(13)]
+    src, dst, rp_d, pm_d, rp_s, pm_s, tei_d, rp_t, pm_t, dst_sorted, src_sorted, inv_d, s2s = v
     graph = ops.SubgraphIndex(src, dst, (rp_d, pm_d), (rp_s, pm_s), int(num_nodes))
     graph._sorted = dict(perm=pm_d, dst=dst_sorted, src=src_sorted, inv=inv_d, src_to_sorted=s2s)
     seeds = ops.SeedIndex.from_parts(tei_d, rp_t, pm_t, int(n_seed), int(num_nodes))
@@ -177,6 +183,8 @@ class ColumnStore:
         return self.batch(eid, edge_index, nodes, len(seed_eids), lazy, index)
 
     def batch(self, eid, edge_index, nodes, n_seed, lazy=None, index=False):
+        """``index``: False (plain ``edge_index``), True (build the ``ops.BatchIndex`` here) or the host-side result of
+        ``host_batch_index`` made by the sampler thread (only the upload happens here)."""
         dev = self.device
         lazy = (dev.type == "cuda") if lazy is None else lazy
         eid_d, nodes_d = eid.to(dev, non_blocking=True), nodes.to(dev, non_blocking=True)
@@ -187,10 +195,11 @@ class ColumnStore:
             edge_tf = TensorFrame({k: v.index_select(0, eid_d) for k, v in self.edge_feats.items()}, self.edge_cols)
             node_tf = TensorFrame({k: v.index_select(0, nodes_d) for k, v in self.node_feats.items()}, self.node_cols)
         y = self.labels.index_select(0, eid_d[:n_seed])
-        if index:                            # index structures built on the host too: the model skips its CSR kernels
+        if index is not False and index is not None:      # index structures built on the host too: the model skips its CSR kernels
             if dev.type != "cuda":
                 raise ValueError("index=True needs a store on the GPU (ops.BatchIndex holds device CSRs)")
-            return node_tf, batch_index(edge_index, nodes.numel(), n_seed, dev), edge_tf, y
+            pre = index if isinstance(index, tuple) else None
+            return node_tf, batch_index(edge_index, nodes.numel(), n_seed, dev, pre), edge_tf, y
         return node_tf, edge_index.to(dev, non_blocking=True), edge_tf, y
 
     def lp_inputs(self, sampler: NeighborSampler, seed_eids, num_neg_samples=64, rng_seed=0):
