@@ -180,22 +180,31 @@ __device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 
 #define EF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
 #endif
 
-// LDS-DMA of BYTES (a multiple of 1 KiB after rounding up: the images are padded accordingly) by the workgroup: one
-// 1 KiB piece per wave-instruction, pieces dealt round-robin to the waves.  The LDS destination and the piece's global
-// base are formed from the wave id in SGPRs (no v_readfirstlane per piece), the lane adds 16 * lane.
+// LDS-DMA of BYTES (rounded up to 1 KiB pieces: the images are padded accordingly) by the workgroup: one 1 KiB piece per
+// wave-instruction, pieces dealt round-robin to the waves.  The LDS destination and the piece's global base are formed
+// from the wave id in SGPRs, the lane adds 16 * lane (saddr form).
+// INLINE ASM on purpose: for the builtin (__builtin_amdgcn_global_load_lds) hipcc assumes that every later LDS access
+// may alias the DMA's destination and puts `s_waitcnt vmcnt(0)` in front of the next ds_read / ds_write — i.e. the wave
+// stalled for the full DMA latency right after issuing it, at every one of the 14 unit boundaries of a tile (the
+// "prefetch" never ran ahead).  Through asm the compiler sees no LDS write; the landing is awaited by the counted
+// `s_waitcnt vmcnt(K)` + barrier of the unit boundary (EF_UNIT_NEXT_K), and the "memory" clobber keeps the compiler from
+// moving or merging LDS reads across the statement.  M0 (the LDS base of the DMA) is saved and restored inside it.
 template <int BYTES>
 __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_dst, int wave, int lane16) {
   constexpr int NP = (BYTES + 1023) / 1024;
   unsigned l16 = (unsigned)lane16;
-  asm volatile("" : "+v"(l16));      // opaque: the per-lane source addresses are formed here (uniform 64-bit base +
-                                     // 32-bit lane offset: the saddr form), not hoisted out of the persistent loop as
-                                     // 64-bit register pairs (which then spill)
+  asm volatile("" : "+v"(l16));      // opaque: not hoisted out of the persistent loop as 64-bit address pairs
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst;
 #pragma unroll
   for (int p = 0; p < (NP + EF_WAVES - 1) / EF_WAVES; ++p) {
     const int q = p * EF_WAVES + wave;                         // wave-uniform piece
-    if ((p + 1) * EF_WAVES <= NP || q < NP)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((src + q * 1024) + l16),
-                                       (__attribute__((address_space(3))) void*)(lds_dst + q * 1024), 16, 0, 0);
+    if ((p + 1) * EF_WAVES <= NP || q < NP) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
+                   : "memory");
+    }
   }
 }
 // Stage pipeline of the backward kernels.  Double-buffered: stage g sits in buffer g & 1, the next stage's DMA is issued
@@ -292,7 +301,7 @@ __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], const EfLa
     for (int p = 0; p < 4; ++p) {
       const uint4 v = *reinterpret_cast<const uint4*>(la.sr + 8 * p * EF_STG_ROWB);
       if (!(EF_ABL & 2))
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, v), dst, la.go + (unsigned)(2048 * p + 128 * half), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, v), dst, la.go + (unsigned)(2048 * p), 128 * half, 0);   // (row in voffset: range-checked)
     }
   }
 }
@@ -344,11 +353,19 @@ struct EfArgs {
 // done with u, every wave's pieces of u+1 landed), then the DMA of u+2 goes into u's buffer at once, so it has the
 // whole of unit u+1 to land.  One barrier per unit, no exposed DMA wait.
 #define EF_UBUF(U) (smem + ((U) & 1) * EF_UNIT_BYTES)
-#define EF_UNIT_NEXT(U, VALID, U2, BYTES)                                                             \
+// Boundary at the end of unit U: wait until this wave's pieces of unit U+1 have landed, barrier, then issue the DMA of
+// unit U+2 into U's buffer.  The wait is COUNTED: K = the vector-memory operations this wave issued AFTER the DMA of
+// unit U+1 (output stores, the next tile's x loads) — they complete in issue order, so "at most K outstanding" means
+// the DMA is done while the stores stay in flight.  (__syncthreads() would wait vmcnt(0): every output store of the tile
+// then stalled the next barrier — stripping the stores saved 0.26 ms of a 1.34 ms launch.)  K must never exceed the real
+// count: each call site states what was issued.
+#define EF_WAIT_VM(K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory")
+#define EF_UNIT_NEXT_K(U, VALID, U2, BYTES, WAIT)                                                     \
   {                                                                                                   \
-    if (!(EF_ABL & 128)) __syncthreads();                                                             \
+    if (!(EF_ABL & 128)) { WAIT; __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }       \
     if (!(EF_ABL & 32) && (VALID)) ef_dma<BYTES>(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, EF_UBUF(U), wave, lane16); \
   }
+#define EF_UNIT_NEXT(U, VALID, U2, BYTES) EF_UNIT_NEXT_K(U, VALID, U2, BYTES, EF_WAIT_VM(0))
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -392,28 +409,37 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
   const unsigned skey0 = rng_key(a.seed, a.rs0, 0u), skey1 = rng_key(a.seed, a.rs1, 0u), skey2 = rng_key(a.seed, a.rs2, 0u),
                  skey3 = rng_key(a.seed, a.rs3, 0u);
 
-  for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
-    const long long wt = it * EF_WAVES + wave;
-    long long row0 = wt * RW;
-    // opaque (scalar registers): nothing below is an affine function of the loop counter for the compiler, so it cannot
-    // strength-reduce the per-lane 64-bit addresses into loop-carried VGPR pairs (11 of them, spilled, before)
-    asm volatile("" : "+s"(row0));
-    long long rows_here = a.R - row0;
-    rows_here = rows_here < 0 ? 0 : (rows_here > RW ? RW : rows_here);
-    const int nvalid = (int)rows_here * S;                       // valid token slots of this wave tile
-    const long long tok0 = row0 * S;                             // first token of the wave tile
-    const bool has_next = it + gridDim.x < n_it;
-
-    // ---- x in fragment order: xf[ks] element j = x[t][16ks + 8(j>>2) + 4h + (j&3)]   (rows past the end read as zeros)
-    ef_v8bf xf[8];
-    const __amdgpu_buffer_rsrc_t xrs = ef_tile_rsrc(a.x, tok0, nvalid);
-#define EF_LOAD_X()                                                                                   \
+  // x of a tile in fragment order: xf[ks] element j = x[t][16ks + 8(j>>2) + 4h + (j&3)]   (rows past the end read as zeros)
+#define EF_LOAD_X(DST, RS)                                                                            \
     _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
-      const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, xoff + 32 * ks, 0, 0));      \
-      const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(xrs, xoff + 32 * ks + 16, 0, 0)); \
-      xf[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                      \
+      /* constant part in soffset: the range check (voffset against the tile's valid bytes) decides per token row */  \
+      const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(RS, xoff, 32 * ks, 0));          \
+      const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(RS, xoff, 32 * ks + 16, 0));     \
+      DST[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                     \
     }
-    EF_LOAD_X()
+  // geometry of the wave tile of iteration IT: first table row (opaque scalar, see below), valid token slots, first token
+#define EF_TILE_GEOM(IT, ROW0, NVALID, TOK0)                                                          \
+    long long ROW0 = ((IT) * EF_WAVES + wave) * RW;                                                   \
+    asm volatile("" : "+s"(ROW0));                                                                    \
+    long long rh_##ROW0 = a.R - ROW0;                                                                 \
+    rh_##ROW0 = rh_##ROW0 < 0 ? 0 : (rh_##ROW0 > RW ? RW : rh_##ROW0);                                \
+    const int NVALID = (int)rh_##ROW0 * S;                                                            \
+    const long long TOK0 = ROW0 * S;
+  ef_v8bf xn[8];                // x of the NEXT tile, loaded while this tile's feed-forward runs
+  if (blockIdx.x < n_it) {
+    EF_TILE_GEOM((long long)blockIdx.x, row0p, nvalidp, tok0p)
+    const __amdgpu_buffer_rsrc_t xrs0 = ef_tile_rsrc(a.x, tok0p, nvalidp);
+    EF_LOAD_X(xn, xrs0)
+  }
+
+  for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
+    // (row0 opaque, in scalar registers: nothing below is an affine function of the loop counter for the compiler, so it
+    // cannot strength-reduce the per-lane 64-bit addresses into loop-carried VGPR pairs — 11 of them, spilled, before)
+    EF_TILE_GEOM(it, row0, nvalid, tok0)
+    const bool has_next = it + gridDim.x < n_it;
+    ef_v8bf xf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xf[ks] = xn[ks];
 
     // accumulator initialised with a per-row bias (float4 per register group, straight from LDS: no VALU)
 #define EF_ACC_BIAS(ACC, POFF)                                                                        \
@@ -448,7 +474,13 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] *= qscale;
       const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
-      EF_UNIT_NEXT(2 * blk, true, 2 * blk + 2, EF_UNIT_BYTES)
+      if (blk == 0) {
+        // issued since the DMA of unit 1 (at the end of the previous tile): its stores of out (8) and of z2 (8, when written)
+        if (a.z2) { EF_UNIT_NEXT_K(0, true, 2, EF_UNIT_BYTES, EF_WAIT_VM(16)) }
+        else { EF_UNIT_NEXT_K(0, true, 2, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
+      } else {
+        EF_UNIT_NEXT(2 * blk, true, 2 * blk + 2, EF_UNIT_BYTES)
+      }
       wu = EF_UBUF(2 * blk + 1);                    // unit 2 blk + 1: Wv rows
       // V block in the transposed orientation [32 tokens (rows), 32 d (columns)]
       {
@@ -493,11 +525,12 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
           if constexpr (DROP == 1) {
             // 32 consecutive elements per hash: this query's keys sit at att + 4h + (i&3) + 8(i>>2) - row_lo
             // (element of register i) = ab + (i&3) + 8(i>>2)
-            unsigned ab32 = (unsigned)att_u + att_l + (unsigned)((blk * HB + hh) * S * S);
-            asm volatile("" : "+v"(ab32));      // (hashes formed here, not hoisted to the top of the tile)
+            unsigned al = att_l;
+            asm volatile("" : "+v"(al));        // (index and hashes formed here: hoisted per head, they were spilled)
+            const unsigned ab32 = (unsigned)att_u + al + (unsigned)((blk * HB + hh) * S * S);
             unsigned k0 = skey0, k1 = skey0;
             if (!a.small_idx) {
-              const unsigned long long ab = att_u + (unsigned long long)(att_l + (unsigned)((blk * HB + hh) * S * S));
+              const unsigned long long ab = att_u + (unsigned long long)(al + (unsigned)((blk * HB + hh) * S * S));
               k0 = rng_key(a.seed, a.rs0, (unsigned)(ab >> 32));
               k1 = rng_key(a.seed, a.rs0, (unsigned)((ab + 32) >> 32));
             }
@@ -597,7 +630,21 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
         ef_f32x16 acc;
         EF_ACC_BIAS(acc, EF_P_B1 + 32 * m)
         EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), x1f)
-        if (m & 1) { EF_UNIT_NEXT(10 + (m >> 1), true, 12 + (m >> 1), EF_UNIT_BYTES) }     // W1 unit done -> W2 units
+        if (m == 1) {                                // W1 units done -> W2 units
+          // issued since the DMA of unit 11: the 8 stores of z1 (when it is written)
+          if (a.z1) { EF_UNIT_NEXT_K(10, true, 12, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
+          else { EF_UNIT_NEXT_K(10, true, 12, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
+          // the next tile's x (its registers are free from here on): 16 loads that the next boundary must not wait for
+          if (has_next) {
+            EF_TILE_GEOM(it + gridDim.x, row0n, nvalidn, tok0n)
+            const __amdgpu_buffer_rsrc_t xrsn = ef_tile_rsrc(a.x, tok0n, nvalidn);
+            EF_LOAD_X(xn, xrsn)
+          }
+        } else if (m == 3) {
+          // issued since the DMA of unit 12: the 16 x loads above (when there is a next tile)
+          if (has_next) { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(16)) }
+          else { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
         ef_drop_tile<DROP>(acc, dkey, e_lo + 32u * m, h4, a.thresh);
@@ -614,6 +661,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
     // ================================================================ feed-forward 2 + LayerNorm 2 (+ tail LayerNorm)
     {
       ef_v8bf zp[8];
+      const bool reload_x = a.tail && a.alpha != 0.f;
+      const __amdgpu_buffer_rsrc_t xrs = ef_tile_rsrc(a.x, tok0, nvalid);
       unsigned dkey = skey3;
       if (DROP && !a.small_idx) dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
 #pragma unroll
@@ -622,9 +671,13 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
         ef_f32x16 acc;
         EF_ACC_BIAS(acc, EF_P_B2 + 32 * m)
         EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), hf)
-        if (m & 1) {                                 // W2 unit done -> the next iteration's first units
-          if (m == 1) { EF_UNIT_NEXT(12, has_next, 0, EF_UNIT_BYTES) }
-          else { EF_UNIT_NEXT(13, has_next, 1, EF_PART_BYTES) }
+        if (m == 1) {                                // W2 units done -> the next iteration's first units
+          EF_UNIT_NEXT(12, has_next, 0, EF_UNIT_BYTES)
+          // this tile's x again for the tail combine (L2-hot): 16 loads the next boundary must not wait for
+          if (reload_x) { EF_LOAD_X(xf, xrs) }
+        } else if (m == 3) {
+          if (reload_x) { EF_UNIT_NEXT_K(13, has_next, 1, EF_PART_BYTES, EF_WAIT_VM(16)) }
+          else { EF_UNIT_NEXT_K(13, has_next, 1, EF_PART_BYTES, EF_WAIT_VM(0)) }
         }
         const uint4 r0 = *reinterpret_cast<const uint4*>(park + 1024 * (2 * m));
         const uint4 r1 = *reinterpret_cast<const uint4*>(park + 1024 * (2 * m + 1));
@@ -655,7 +708,6 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
       if (a.tail) {
         ef_row_stats(zp, a.eps, mu, rstd);
         nmr = -mu * rstd;
-        if (a.alpha != 0.f) { EF_LOAD_X() }       // x again for the combine (L2-hot): its registers were free in between
 #pragma unroll
         for (int f = 0; f < 8; ++f) {
           EF_FENCE();
