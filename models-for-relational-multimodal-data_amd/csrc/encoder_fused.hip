@@ -209,17 +209,20 @@ __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_d
 }
 // Stage pipeline of the backward kernels.  Double-buffered: stage g sits in buffer g & 1, the next stage's DMA is issued
 // on entry, one barrier on leaving.  Single-buffered: barrier (buffer free) -> DMA -> barrier (landed).
+// (the DMA is inline asm: the compiler does not wait for it at a __syncthreads(), EF_DMA_LANDED() does)
+#define EF_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #if EF_DBUF
 #define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
   char* wb = (gstage & 1) ? wbuf1 : wbuf0;                                                            \
   if (NEXT_VALID) ef_dma<EF_STAGE_BYTES>(a.wpack + (size_t)(NEXT) * EF_STAGE_BYTES, (gstage & 1) ? wbuf0 : wbuf1, wave, lane16);
-#define EF_STAGE_LEAVE() __syncthreads(); gstage += 1;
-#define EF_PIPE_PROLOGUE() if (blockIdx.x < n_it) ef_dma<EF_STAGE_BYTES>(a.wpack, wbuf0, wave, lane16); __syncthreads();
+#define EF_STAGE_LEAVE() EF_DMA_LANDED(); __syncthreads(); gstage += 1;
+#define EF_PIPE_PROLOGUE() if (blockIdx.x < n_it) ef_dma<EF_STAGE_BYTES>(a.wpack, wbuf0, wave, lane16); EF_DMA_LANDED(); __syncthreads();
 #else
 #define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
   if (!(EF_ABL & 32)) {                                                                               \
     __syncthreads();                                                                                  \
     ef_dma<EF_STAGE_BYTES>(a.wpack + (size_t)(CUR) * EF_STAGE_BYTES, wbuf0, wave, lane16);            \
+    EF_DMA_LANDED();                                                                                  \
     __syncthreads();                                                                                  \
   }                                                                                                   \
   char* wb = wbuf0;
@@ -328,6 +331,24 @@ __device__ __forceinline__ void ef_drop_tile(ef_f32x16& acc, unsigned key, unsig
   }
 }
 
+// Diagnostic build (EF_ABL & 1024, tools/enc_timeline.py): s_memtime stamps at section edges of the forward, summed per
+// section and wave in scalar registers, written once at kernel end to a buffer of their own (never an output).
+#if EF_ABL & 1024
+constexpr int EF_NSEC = 16;
+__device__ unsigned long long ef_dbg[EF_NSEC * 4096];
+#define EF_STAMP(K)                                                                                   \
+  {                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t_;                                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    sec[K] += t_ - t_prev;                                                                            \
+    t_prev = t_;                                                                                      \
+  }
+#else
+#define EF_STAMP(K)
+#endif
+
 struct EfArgs {
   const unsigned short* x;        // [T,128]
   unsigned short* out;            // [T,128]
@@ -352,6 +373,7 @@ struct EfArgs {
 // read, the DMA of unit u+1 is in flight into the other buffer.  EF_UNIT_NEXT at the end of unit u: barrier (every wave
 // done with u, every wave's pieces of u+1 landed), then the DMA of u+2 goes into u's buffer at once, so it has the
 // whole of unit u+1 to land.  One barrier per unit, no exposed DMA wait.
+#define EF_SEC 0
 #define EF_UBUF(U) (smem + ((U) & 1) * EF_UNIT_BYTES)
 // Boundary at the end of unit U: wait until this wave's pieces of unit U+1 have landed, barrier, then issue the DMA of
 // unit U+2 into U's buffer.  The wait is COUNTED: K = the vector-memory operations this wave issued AFTER the DMA of
@@ -362,8 +384,11 @@ struct EfArgs {
 #define EF_WAIT_VM(K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory")
 #define EF_UNIT_NEXT_K(U, VALID, U2, BYTES, WAIT)                                                     \
   {                                                                                                   \
-    if (!(EF_ABL & 128)) { WAIT; __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }       \
+    EF_STAMP(EF_SEC)                                                                                  \
+    if (!(EF_ABL & 128)) { WAIT; EF_STAMP(12) __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }       \
+    EF_STAMP(13)                                                                                      \
     if (!(EF_ABL & 32) && (VALID)) ef_dma<BYTES>(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, EF_UBUF(U), wave, lane16); \
+    EF_STAMP(14)                                                                                      \
   }
 #define EF_UNIT_NEXT(U, VALID, U2, BYTES) EF_UNIT_NEXT_K(U, VALID, U2, BYTES, EF_WAIT_VM(0))
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
@@ -385,6 +410,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
 
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
+  EF_DMA_LANDED();
   __syncthreads();
   if (blockIdx.x < n_it) ef_dma<EF_PART_BYTES>(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, wave, lane16);
 
@@ -432,6 +458,10 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
     EF_LOAD_X(xn, xrs0)
   }
 
+#if EF_ABL & 1024
+  unsigned long long sec[EF_NSEC] = {0}, t_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#endif
   for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
     // (row0 opaque, in scalar registers: nothing below is an affine function of the loop counter for the compiler, so it
     // cannot strength-reduce the per-lane 64-bit addresses into loop-carried VGPR pairs — 11 of them, spilled, before)
@@ -454,6 +484,9 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
       if (ks == 3) EF_MID_FENCE();                                                                    \
     }
 
+    EF_STAMP(10)
+#undef EF_SEC
+#define EF_SEC 0
     // ================================================================ attention, per 32-channel head block
     ef_v8bf of[8];               // attention output o^T, packed: the B operand of the output projection
     // attention-dropout geometry: element index of (table row, head, query q, key k) = ((row * NH + head) * S + q) * S + k
@@ -497,6 +530,7 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
       if (blk < 3) { EF_UNIT_NEXT(2 * blk + 1, true, 2 * blk + 3, EF_PART_BYTES) }     // next head block's Wv rows
       else { EF_UNIT_NEXT(2 * blk + 1, true, 2 * blk + 3, EF_UNIT_BYTES) }            // (units 8, 9: Wo)
 
+      EF_STAMP(0)
 #pragma unroll
       for (int hh = 0; hh < HB; ++hh) {
         // scores S^T[key (rows), query (columns)] + 256 * [same table row], exp2 domain
@@ -571,8 +605,11 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
           if (hh == 0) of[2 * blk] = ef_pack<0>(ot); else of[2 * blk + 1] = ef_pack<1>(ot);
         }
       }
+      EF_STAMP(1)
     }
 
+#undef EF_SEC
+#define EF_SEC 2
     // ================================================================ output projection + LayerNorm 1 (registers)
     // z1 = x + drop(o Wo^T + b_o), rounded to bf16 (what is stored and what the backward recomputes from);
     // x1 = LN(z1) * g1 + be1, rounded to bf16: the feed-forward input and residual
@@ -604,7 +641,9 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
         zp[2 * m + 1] = __builtin_bit_cast(ef_v8bf, o1);
         EF_FENCE();
       }
+      EF_STAMP(2)
       if (a.z1) ef_store_rows(zp, la, ef_tile_rsrc(a.z1, tok0, nvalid));
+      EF_STAMP(3)
       float mu, rstd;
       ef_row_stats(zp, a.eps, mu, rstd);
       const float nmr = -mu * rstd;
@@ -619,6 +658,9 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
       }
     }
 
+    EF_STAMP(4)
+#undef EF_SEC
+#define EF_SEC 5
     // ================================================================ feed-forward 1: h = drop(relu(W1 x1 + b1))
     ef_v8bf hf[8];
     {
@@ -658,6 +700,9 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
       }
     }
 
+    EF_STAMP(5)
+#undef EF_SEC
+#define EF_SEC 6
     // ================================================================ feed-forward 2 + LayerNorm 2 (+ tail LayerNorm)
     {
       ef_v8bf zp[8];
@@ -694,7 +739,9 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
         zp[2 * m + 1] = __builtin_bit_cast(ef_v8bf, o1);
         EF_FENCE();
       }
+      EF_STAMP(6)
       if (a.z2) ef_store_rows(zp, la, ef_tile_rsrc(a.z2, tok0, nvalid));
+      EF_STAMP(7)
       float mu, rstd;
       ef_row_stats(zp, a.eps, mu, rstd);
       float nmr = -mu * rstd;
@@ -715,9 +762,17 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
                                 reinterpret_cast<const float*>(pb) + EF_P_BT + 16 * f, a.alpha, a.beta_c);
         }
       }
+      EF_STAMP(8)
       ef_store_rows(zp, la, ef_tile_rsrc(a.out, tok0, nvalid));
+      EF_STAMP(9)
     }
   }
+#if EF_ABL & 1024
+  if (lane == 0) {
+    const int slot = (blockIdx.x * EF_WAVES + wave) & 4095;
+    for (int k = 0; k < EF_NSEC; ++k) ef_dbg[slot * EF_NSEC + k] = sec[k];
+  }
+#endif
 }
 
 
@@ -1454,6 +1509,11 @@ using namespace tg;
 
 extern "C" int64_t tg_encoder_pack_bytes(void) { return (int64_t)EF_NSTAGE * EF_STAGE_BYTES; }
 extern "C" int64_t tg_encoder_stage_bytes(void) { return EF_STAGE_BYTES; }
+#if EF_ABL & 1024
+extern "C" int tg_encoder_dbg_read(unsigned long long* host, int n_slots) {      // diagnostic build only
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(tg::ef_dbg), sizeof(unsigned long long) * tg::EF_NSEC * n_slots);
+}
+#endif
 extern "C" int64_t tg_encoder_prm_floats(void) { return EF_P_FLOATS; }
 
 // Builds the LDS weight images + the fp32 parameter block of one ColumnTransformerLayer call (bf16 weights [out,in]
