@@ -292,28 +292,28 @@ int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2, const void
 
 /* backward of the fused layer, feed-forward half: everything between d out and d x1, recomputed from (z1, z2).
  * tg_encoder_pack_tiles: stage i = LDS image of a [128,128] bf16 tile (here W1, W2^T, W1^T).  Writes d_x1 and the
- * operands of the two weight-gradient GEMMs (d_y2, h) and (d_hpre, x1) (tg_gemm_tn_bf16 sums the bias gradients). */
+ * operands of the two weight-gradient GEMMs (d_y2, h) and (d_hpre, x1) (tg_gemm_tn_bf16 sums the bias gradients).
+ * lnp: [tg_encoder_ln_partial_blocks(R, S)][4][128] fp32 partial sums of the LayerNorm parameter gradients
+ * (d gamma2, d beta2, d gamma_t, d beta_t), one row per workgroup; tg_encoder_ln_reduce adds them up. */
 int tg_encoder_pack_tiles(const void* const* tiles /*host [n]*/, const int32_t* ld /*host [n]*/, int32_t n, void* wpack,
                           void* stream);
 int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void* z2, void* dx1, void* dy2, void* hout, void* dhpre,
                             void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S, int32_t tail,
-                            float beta_c, float eps, float p_drop, uint64_t seed, const uint32_t* rs, void* stream);
-/* backward of the fused layer, attention half (4 heads): d_x1 -> LayerNorm-1 backward -> output projection backward
- * -> attention backward with q / k / v / probabilities recomputed from x.  Writes dx (partial: tg_gemm_nt_bf16 then adds
- * d_qkv W_in), and the operands of the weight-gradient GEMMs: dy, o [R,S,128] and dqkv [R,S,384]. */
+                            float beta_c, float eps, float p_drop, uint64_t seed, const uint32_t* rs, float* lnp,
+                            void* stream);
+/* backward of the fused layer, attention half (4 or 8 heads): d_x1 -> LayerNorm-1 backward -> output projection
+ * backward -> attention backward with q / k / v / probabilities recomputed from x.  Writes dx (partial:
+ * tg_gemm_nt_bf16 then adds d_qkv W_in), the operands of the weight-gradient GEMMs: dy, o [R,S,128] and dqkv [R,S,384],
+ * and (lnp, as above) the partial sums of d gamma1, d beta1 (rows 2, 3 zero). */
 int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const void* x, const void* g /*d out; NULL if alpha == 0*/,
                              void* dx, void* dy, void* o, void* dqkv, const void* w_in /*[384,128]*/,
-                             const void* w_o_t /*Wo^T [128, ld_ot]*/, int32_t ld_ot, void* wpack /*4 x 32 KiB*/,
-                             const float* prm, int64_t R, int32_t S, int32_t H, float alpha, float eps, float p_drop,
-                             uint64_t seed, const uint32_t* rs, void* stream);
-/* LayerNorm weight / bias gradients of the fused layer (sums over tokens; a streaming pass of its own):
- * mode 0: dy = d out, z = z2 -> out = (d gamma2, d beta2, d gamma_t, d beta_t);  mode 1: dy = d_x1, z = z1 -> (d gamma1,
- * d beta1).  out[i] fp32 [128] or NULL; accumulate = 1: += . */
-int64_t tg_encoder_ln_grads_partials_floats(void);
-int tg_encoder_ln_grads(int32_t mode, const void* dy, const void* z, const float* gamma, const float* beta,
-                        const float* gamma_t, float beta_c, float eps, int64_t T, float* const* out /*host [4]*/,
-                        int32_t accumulate, float* partials, void* stream);
-
+                             const void* w_o_t /*Wo^T [128, ld_ot]*/, int32_t ld_ot,
+                             void* wpack /*4 x tg_encoder_stage_bytes()*/, const float* prm, int64_t R, int32_t S, int32_t H,
+                             float alpha, float eps, float p_drop, uint64_t seed, const uint32_t* rs, float* lnp,
+                             void* stream);
+int64_t tg_encoder_ln_partial_blocks(int64_t R, int32_t S);
+int tg_encoder_ln_reduce(const float* lnp, int64_t nblk, float* const* out /*host [4]: fp32 [128] or NULL*/,
+                         int32_t accumulate, void* stream);
 /* ---- weight gradient of every Linear on the path (autograd of torch.nn.Linear in the reference):
  *      out[M,N] (fp32) = G[R,M]^T X[R,N], bf16 operands, split over row slabs, deterministic slab sum ------- */
 int64_t tg_gemm_tn_workspace_floats(int64_t R, int32_t M, int32_t N);

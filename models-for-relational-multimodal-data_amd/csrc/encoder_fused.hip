@@ -776,15 +776,20 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
 }
 
 
+#undef EF_STAMP
+#define EF_STAMP(K)
 // ---------------------------------------------------------------------------------------------- backward, feed-forward half
 // Everything between the layer output and x1, recomputed from (z1, z2) in the same register-chained form:
 //     g = d out -> (tail LayerNorm backward) -> LayerNorm-2 backward -> d_z2 ; d_y2 = mask3 . d_z2
 //     x1 = LN1(z1) ; h = drop(relu(W1 x1 + b1))                           (recomputed, one GEMM)
 //     d_h = d_y2 W2 ; d_hpre = d_h . [h > 0] / keep ; d_x1 = d_z2 + d_hpre W1
 // Written: d_x1 (the gradient the attention half continues from) and the four operands of the two weight-gradient
-// GEMMs (d_y2, h) and (d_hpre, x1) — tg_gemm_tn_bf16 also sums the bias gradients from d_y2 / d_hpre.  LayerNorm
-// parameter gradients are a separate streaming pass (tg_encoder_ln_grads).
-// Stages (LDS weight images, k-permuted like the forward's): W1 [f][n] | W2^T [f][n] | W1^T [n][f].
+// GEMMs (d_y2, h) and (d_hpre, x1) — tg_gemm_tn_bf16 also sums the bias gradients from d_y2 / d_hpre — and, per
+// workgroup, the partial LayerNorm parameter gradients of norm2 and the tail norm (see ef_ln_bwd below; round 2 read
+// g, z2 again in a separate streaming kernel for them).
+// Units (LDS weight images, k-permuted like the forward's, two 64-row units per [128,128] tile): W1 | W2^T | W1^T,
+// streamed through the forward's double-buffered unit pipeline (round 2: one 32 KiB buffer, DMA latency exposed).
+constexpr int EF_WAVE_LDS = 9728;          // per-wave scratch: staging regions A / B (32 rows x 144 B each) + a 512-byte table
 struct EbArgs {
   const unsigned short *g, *z1, *z2;
   unsigned short *dx1, *dy2, *hout, *dhpre, *x1out;
@@ -797,248 +802,314 @@ struct EbArgs {
   float inv_keep;
   unsigned long long seed;
   unsigned rs2, rs3;
+  int small_idx;
+  float* lnp;                    // [grid][4][128] partial sums: d gamma2, d beta2, d gamma_t, d beta_t
 };
 
-// sums over a token's 128 channels of (a) dy*gamma and (b) dy*gamma*xhat, with xhat = (z - mu) * rstd; dy, z packed
-__device__ __forceinline__ void ef_ln_bwd_sums(const ef_v8bf (&dy)[8], const ef_v8bf (&z)[8], float dy_scale, float mu,
-                                               float rstd, const float* gamma, int h, float& s1, float& s2) {
-  s1 = 0.f; s2 = 0.f;
+__device__ __forceinline__ void ef_dot2c(float& acc, unsigned a, unsigned b) {      // acc += a.lo*b.lo + a.hi*b.hi (bf16 pairs)
+  asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+typedef short ef_v4s __attribute__((ext_vector_type(4)));
+typedef ef_v4s __attribute__((address_space(3))) * ef_lds_v4s_ptr;
+
+// LayerNorm backward of a wave tile (token on the lane, 64 channels in its registers) + the parameter gradients.
+//   dy, z: packed fragments; dy_scale: factor on dy (the tail norm's beta_c); gamma: LDS floats (+ 4h applied);
+//   out[f] = bf16( rstd * (dg - mean(dg) - xhat * mean(dg * xhat)) ),  dg = dy * dy_scale * gamma,  xhat = (z - mu) * rstd
+//   OUT2: out2[f] = bf16(post(f, d, r)) — a second result formed from every fp32 result pair r before it is rounded (the
+//   caller's dropout-masked copy); out2 may be the registers of dy (a fragment of dy is dead once it has been staged).
+// Parameter gradients (sums over TOKENS = over lanes): dy and bf16(xhat) of 64 channels at a time are staged as
+// [token][channel] rows in the wave's LDS regions A / B and read back transposed (ds_read_b64_tr_b16: lane = channel, 4
+// tokens per read); v_dot2c_f32_bf16 then adds dy . xhat (d gamma) and dy . 1 (d beta) over token pairs into this lane's
+// accumulators acc[2 * half + 0 / 1] — 64 matrix-free VALU instructions per LayerNorm, no second pass over HBM.
+template <bool OUT2, typename Post>
+__device__ __forceinline__ void ef_ln_bwd(const ef_v8bf (&dy)[8], const ef_v8bf (&z)[8], float dy_scale, float mu, float rstd,
+                                          const float* gamma, ef_v8bf (&out)[8], ef_v8bf (&out2)[8], const EfLaneAddr& la,
+                                          const char* trb, float (&acc)[4], Post post) {
+  constexpr bool want_params = true;      // (always: the kernels are only launched by a training backward)
+  const float nmr = -mu * rstd;
+  ef_f2 s1 = ef_splat(0.f), s2 = ef_splat(0.f);
 #pragma unroll
   for (int f = 0; f < 8; ++f) {
-    ef_v8bf d = dy[f], zz = z[f];
-    asm volatile("" : "+v"(d), "+v"(zz));
-    const float4 g0 = *reinterpret_cast<const float4*>(gamma + 16 * f + 4 * h), g1 = *reinterpret_cast<const float4*>(gamma + 16 * f + 8 + 4 * h);
-    const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + 16 * f), g1 = *reinterpret_cast<const float4*>(gamma + 16 * f + 8);
+    const ef_f2 gg[4] = {{g0.x, g0.y}, {g0.z, g0.w}, {g1.x, g1.y}, {g1.z, g1.w}};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float dg = (float)d[j] * dy_scale * gg[j];
+    for (int d = 0; d < 4; ++d) {
+      const ef_f2 dg = ef_unpk(ef_dw(dy[f], d)) * gg[d];
+      const ef_f2 xh = ef_fma2(ef_unpk(ef_dw(z[f], d)), ef_splat(rstd), ef_splat(nmr));
       s1 += dg;
-      s2 += dg * (((float)zz[j] - mu) * rstd);
+      s2 = ef_fma2(dg, xh, s2);
     }
   }
-  s1 += ef_xor32(s1);
-  s2 += ef_xor32(s2);
-  s1 *= (1.f / 128.f);
-  s2 *= (1.f / 128.f);
-}
-// d_z = rstd * (dy*gamma - s1 - xhat * s2) for one fragment
-__device__ __forceinline__ ef_f32x8 ef_ln_bwd_apply(ef_v8bf d, ef_v8bf zz, float dy_scale, float mu, float rstd, float s1,
-                                                     float s2, const float* gamma_f) {
-  asm volatile("" : "+v"(d), "+v"(zz));
-  const float4 g0 = *reinterpret_cast<const float4*>(gamma_f), g1 = *reinterpret_cast<const float4*>(gamma_f + 8);
-  const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-  ef_f32x8 o;
+  float m1 = s1.x + s1.y, m2 = s2.x + s2.y;
+  m1 += ef_xor32(m1);
+  m2 += ef_xor32(m2);
+  const float c0 = rstd * dy_scale, c1 = -m1 * (dy_scale * (1.f / 128.f)) * rstd, c2 = -m2 * (dy_scale * (1.f / 128.f)) * rstd;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float dg = (float)d[j] * dy_scale * gg[j];
-    o[j] = rstd * (dg - s1 - (((float)zz[j] - mu) * rstd) * s2);
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int ff = 0; ff < 4; ++ff) {
+      const int f = 4 * half + ff;
+      EF_FENCE();
+      // second pass over dy, z, gamma: opaque copies, or the compiler keeps the first pass's 64 + 64 unpacked values and
+      // the 64 gamma values alive across the reductions (spills)
+      const float* gam2 = gamma;
+      ef_v8bf dyo = dy[f], zo = z[f];
+      asm volatile("" : "+v"(gam2), "+v"(dyo), "+v"(zo));
+      const float4 g0 = *reinterpret_cast<const float4*>(gam2 + 16 * f), g1 = *reinterpret_cast<const float4*>(gam2 + 16 * f + 8);
+      const ef_f2 gg[4] = {{g0.x, g0.y}, {g0.z, g0.w}, {g1.x, g1.y}, {g1.z, g1.w}};
+      const uint4 dyw = __builtin_bit_cast(uint4, dyo);
+      uint4 o, o2, xw;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const ef_f2 dg = ef_unpk(dyw[d]) * gg[d];
+        const ef_f2 xh = ef_fma2(ef_unpk(ef_dw(zo, d)), ef_splat(rstd), ef_splat(nmr));
+        const ef_f2 r = ef_fma2(xh, ef_splat(c2), ef_fma2(dg, ef_splat(c0), ef_splat(c1)));
+        if constexpr (OUT2) o2[d] = ef_pk(post(f, d, r));
+        o[d] = ef_pk(r);
+        xw[d] = ef_pk(xh);
+      }
+      if (want_params) {        // (dy is staged BEFORE out[f] is written: out may be the same registers)
+        *reinterpret_cast<uint2*>(la.sw + 32 * ff) = make_uint2(dyw.x, dyw.y);
+        *reinterpret_cast<uint2*>(la.sw + 32 * ff + 16) = make_uint2(dyw.z, dyw.w);
+        *reinterpret_cast<uint2*>(la.sw + 4608 + 32 * ff) = make_uint2(xw.x, xw.y);
+        *reinterpret_cast<uint2*>(la.sw + 4608 + 32 * ff + 16) = make_uint2(xw.z, xw.w);
+      }
+      out[f] = __builtin_bit_cast(ef_v8bf, o);
+      if constexpr (OUT2) out2[f] = __builtin_bit_cast(ef_v8bf, o2);
+    }
+    if (want_params) {
+      float ga = 0.f, gb = 0.f, ba = 0.f, bb = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint2 dv = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ef_lds_v4s_ptr)(trb + 576 * j)));
+        const uint2 xv = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ef_lds_v4s_ptr)(trb + 4608 + 576 * j)));
+        ef_dot2c(ga, dv.x, xv.x); ef_dot2c(gb, dv.y, xv.y);
+        ef_dot2c(ba, dv.x, 0x3f803f80u); ef_dot2c(bb, dv.y, 0x3f803f80u);
+      }
+      acc[2 * half] += (ga + gb) * dy_scale;
+      acc[2 * half + 1] += (ba + bb) * dy_scale;
+    }
   }
-  return o;
 }
 
-template <int DROP /* 0 = off, else hash bits per element: 16 | 8 (common.hpp) */>
+// workgroup partial of the per-lane LayerNorm parameter sums: lane = channel (64 half + lane) -> lnp[block][4][128]
+__device__ __forceinline__ void ef_ln_partials(const float (&q)[8], float* red /* LDS [EF_WAVES][4][128] */, float* lnp, int wave,
+                                               int lane, int tid) {
+  __syncthreads();               // every wave is done with its scratch (red aliases the staging regions)
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) red[(wave * 4 + v) * 128 + 64 * half + lane] = q[2 * v + half];
+  __syncthreads();
+  for (int i = tid; i < 512; i += EF_THREADS) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < EF_WAVES; ++w) t += red[w * 512 + i];
+    lnp[(size_t)blockIdx.x * 512 + i] = t;
+  }
+}
+
+template <int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* wbuf0 = smem;
-  char* wbuf1 = smem + (EF_NBUF - 1) * EF_STAGE_BYTES;
-  float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);
-  char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;
+  float* prm = reinterpret_cast<float*>(smem + 2 * EF_UNIT_BYTES);
+  char* stg_all = smem + 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tl0 = lane & 31, h0 = lane >> 5, lane16 = 16 * lane;
-  char* stg = stg_all + wave * 8192;
-  EfLaneAddr la;
-  la.sw = stg + EF_STG_ROWB * tl0 + 8 * h0;
-  la.sr = stg + EF_STG_ROWB * (lane >> 3) + 16 * (lane & 7);
-  la.go = (unsigned)(256 * (lane >> 3) + 16 * (lane & 7));
+  const int tl = lane & 31, h = lane >> 5, h4 = 4 * h, lane16 = 16 * lane;
+  char* stg = stg_all + wave * EF_WAVE_LDS;
   const int S = a.S;
   const int RW = 32 / S;
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
-  EF_PIPE_PROLOGUE()
+  if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
+  EF_DMA_LANDED();
+  __syncthreads();
+  if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, wave, lane16);
 
-  int gstage = 0;
+  const int fb = EF_ROWB * tl + 16 * h;
+  const char* pb = reinterpret_cast<const char*>(prm) + 16 * h;
+  const float* pf = reinterpret_cast<const float*>(pb);           // parameter floats of this lane half (+ 4h applied)
+  EfLaneAddr la;
+  la.sw = stg + EF_STG_ROWB * tl + 8 * h;
+  la.sr = stg + EF_STG_ROWB * (lane >> 3) + 16 * (lane & 7);
+  la.go = (unsigned)(256 * (lane >> 3) + 16 * (lane & 7));
+  const unsigned xoff = (unsigned)(256 * tl + 8 * h);
+  // transposed reads of the staged [token][channel] rows: 16-lane group g reads channels 16g..16g+15, lane 4q+p of the
+  // group addresses row q (+ 4j), columns 4p..4p+3
+  const char* trb = stg + EF_STG_ROWB * ((lane & 15) >> 2) + 32 * (lane >> 4) + 8 * (lane & 3);
+  const unsigned skey2 = rng_key(a.seed, a.rs2, 0u), skey3 = rng_key(a.seed, a.rs3, 0u);
+  const float keep_scale = DROP ? a.inv_keep : 1.f;
+  float q2[4] = {0.f, 0.f, 0.f, 0.f}, qt[4] = {0.f, 0.f, 0.f, 0.f};      // norm2 / tail: (d gamma, d beta) x channel halves
+
   for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
-    int tl = tl0, h = h0;
-    asm volatile("" : "+v"(tl), "+v"(h));
-    const long long wt = it * EF_WAVES + wave;
-    const long long row0 = wt * RW;
-    long long rows_here = a.R - row0;
-    rows_here = rows_here < 0 ? 0 : (rows_here > RW ? RW : rows_here);
-    const int nvalid = (int)rows_here * S;
-    const long long tok0 = row0 * S;
-    const bool tok_ok = tl0 < nvalid;
-    const long long tglob = tok0 + tl0;
-    const unsigned long long e_base = (unsigned long long)tglob * EF_C;
-    const unsigned xoff = (unsigned)((tok_ok ? tl0 : 0) * EF_C + 4 * h0);
-#define EB_LOAD(DST, SRC)                                                                             \
-    {                                                                                                 \
-      const unsigned short* base_ = (SRC) + tok0 * EF_C;                                              \
-      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
-        uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);                                       \
-        if (tok_ok) {                                                                                 \
-          lo = *reinterpret_cast<const uint2*>(base_ + (xoff + 16 * ks));                             \
-          hi = *reinterpret_cast<const uint2*>(base_ + (xoff + 16 * ks + 8));                         \
-        }                                                                                             \
-        DST[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                    \
-      }                                                                                               \
-    }
+    EF_TILE_GEOM(it, row0, nvalid, tok0)
+    const bool has_next = it + gridDim.x < n_it;
+    const unsigned long long e_base = (unsigned long long)tok0 * EF_C + (unsigned long long)(tl * EF_C);
+    const unsigned e_lo = (unsigned)((unsigned long long)tok0 * EF_C) + (unsigned)(tl * EF_C);
     ef_v8bf gf[8], zf[8];
-    EB_LOAD(gf, a.g)
-    EB_LOAD(zf, a.z2)
+    {
+      const __amdgpu_buffer_rsrc_t rg = ef_tile_rsrc(a.g, tok0, nvalid), rz = ef_tile_rsrc(a.z2, tok0, nvalid);
+      EF_LOAD_X(gf, rg)
+      EF_LOAD_X(zf, rz)
+    }
 
     // ---- tail LayerNorm backward and LayerNorm-2 backward (registers); gf becomes d_x2, then d_y2; dzf = d_z2
     float mu2, rstd2;
     ef_row_stats(zf, a.eps, mu2, rstd2);
     if (a.tail) {
       ef_v8bf x2f[8];
+      const float nmr2 = -mu2 * rstd2;
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         EF_FENCE();
-        x2f[f] = ef_ln_apply(zf[f], -mu2 * rstd2, rstd2, prm + EF_P_G2 + 16 * f + 4 * h, prm + EF_P_BE2 + 16 * f + 4 * h);
+        x2f[f] = ef_ln_apply(zf[f], nmr2, rstd2, pf + EF_P_G2 + 16 * f, pf + EF_P_BE2 + 16 * f);
       }
-      float mut, rstdt, s1, s2;
+      float mut, rstdt;
       ef_row_stats(x2f, a.eps, mut, rstdt);
-      ef_ln_bwd_sums(gf, x2f, a.beta_c, mut, rstdt, prm + EF_P_GT, h, s1, s2);
-#pragma unroll
-      for (int f = 0; f < 8; ++f) {
-        EF_FENCE();
-        gf[f] = __builtin_convertvector(ef_ln_bwd_apply(gf[f], x2f[f], a.beta_c, mut, rstdt, s1, s2, prm + EF_P_GT + 16 * f + 4 * h), ef_v8bf);
-      }
+      ef_ln_bwd<false>(gf, x2f, a.beta_c, mut, rstdt, pf + EF_P_GT, gf, gf, la, trb, qt,
+                       [](int, int, ef_f2 r) { return r; });
     }
     ef_v8bf dzf[8];
     {
-      float s1, s2;
-      ef_ln_bwd_sums(gf, zf, 1.f, mu2, rstd2, prm + EF_P_G2, h, s1, s2);
-      const unsigned dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
+      unsigned dkey = skey3;
+      if (DROP && !a.small_idx) dkey = rng_key(a.seed, a.rs3, (unsigned)(e_base >> 32));
+      int hs[4] = {0, 0, 0, 0};
+      if constexpr (DROP == 1) {
 #pragma unroll
-      for (int f = 0; f < 8; ++f) {
-        EF_FENCE();
-        ef_f32x8 dz = ef_ln_bwd_apply(gf[f], zf[f], 1.f, mu2, rstd2, s1, s2, prm + EF_P_G2 + 16 * f + 4 * h);
-        dzf[f] = __builtin_convertvector(dz, ef_v8bf);
-        if constexpr (DROP) {
-          float dm0[4], dm1[4];
-          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
-          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { dz[j] *= dm0[j]; dz[4 + j] *= dm1[j]; }
-          gf[f] = __builtin_convertvector(dz, ef_v8bf);
-        } else {
-          gf[f] = dzf[f];
-        }
+        for (int m = 0; m < 4; ++m) hs[m] = (int)(mix32(((e_lo >> 5) + (unsigned)m) ^ dkey) >> h4);
       }
+      // out = d_z2 (dzf); out2 = d_y2 = dropout mask of the norm2 site on d_z2 (fp32, before rounding), over gf
+      ef_ln_bwd<true>(gf, zf, 1.f, mu2, rstd2, pf + EF_P_G2, dzf, gf, la, trb, q2, [&](int f, int d, ef_f2 r) {
+        if constexpr (DROP == 1) {
+          const int bit = 16 * (f & 1) + 8 * (d >> 1) + 2 * (d & 1);
+          r.x = __uint_as_float(__float_as_uint(r.x) & ef_bitmask(hs[f >> 1], bit));
+          r.y = __uint_as_float(__float_as_uint(r.y) & ef_bitmask(hs[f >> 1], bit + 1));
+          r *= ef_splat(keep_scale);
+        } else if constexpr (DROP != 0) {
+          // (two elements of one group of four: the hash is recomputed per pair; not the reference's default p)
+          float dm[4];
+          drop_scale4_t<DROP>(dkey, e_lo + (unsigned)(16 * f + 8 * (d >> 1)) + (unsigned)h4, a.thresh, a.inv_keep, dm);
+          r.x *= dm[2 * (d & 1)];
+          r.y *= dm[2 * (d & 1) + 1];
+        }
+        return r;
+      });
     }
     ef_store_rows(gf, la, ef_tile_rsrc(a.dy2, tok0, nvalid));            // d_y2: operand of dW2 (and db2)
 
     // ---- x1 = LN1(z1) (recomputed), written as the X operand of dW1
     ef_v8bf x1f[8];
     {
-      EB_LOAD(zf, a.z1)
+      const __amdgpu_buffer_rsrc_t rz1 = ef_tile_rsrc(a.z1, tok0, nvalid);
+      EF_LOAD_X(zf, rz1)
       float mu1, rstd1;
       ef_row_stats(zf, a.eps, mu1, rstd1);
+      const float nmr1 = -mu1 * rstd1;
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         EF_FENCE();
-        x1f[f] = ef_ln_apply(zf[f], -mu1 * rstd1, rstd1, prm + EF_P_G1 + 16 * f + 4 * h, prm + EF_P_BE1 + 16 * f + 4 * h);
+        x1f[f] = ef_ln_apply(zf[f], nmr1, rstd1, pf + EF_P_G1 + 16 * f, pf + EF_P_BE1 + 16 * f);
       }
       ef_store_rows(x1f, la, ef_tile_rsrc(a.x1out, tok0, nvalid));
     }
 
-    // ---- stage W1: h = drop(relu(W1 x1 + b1)) (recomputed), written as the X operand of dW2
+    // ---- units 0, 1 (W1): h = drop(relu(W1 x1 + b1)) (recomputed), written as the X operand of dW2
     ef_v8bf hf[8];
     {
-      asm volatile("" : "+v"(tl), "+v"(h));
-      EF_STAGE_ENTER(0, true, 1)                    // W1 (next: W2^T)
-      const unsigned dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
+      unsigned dkey = skey2;
+      if (DROP && !a.small_idx) dkey = rng_key(a.seed, a.rs2, (unsigned)(e_base >> 32));
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        ef_f32x16 acc = ef_zero16();
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), x1f[ks], acc);
-          if (ks == 3) EF_MID_FENCE();
+        const char* wu = EF_UBUF(m >> 1);
+        ef_f32x16 acc;
+        EF_ACC_BIAS(acc, EF_P_B1 + 32 * m)
+        EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), x1f)
+        if (m == 1) {
+          // issued since the DMA of unit 1 (end of the previous tile): its 8 d_x1 stores, this tile's 48 loads (all
+          // consumed by now) and the 16 stores of d_y2 and x1
+          EF_UNIT_NEXT_K(0, true, 2, EF_UNIT_BYTES, EF_WAIT_VM(16))
+        } else if (m == 3) {
+          EF_UNIT_NEXT(1, true, 3, EF_UNIT_BYTES)
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 b = *reinterpret_cast<const float4*>(prm + EF_P_B1 + 32 * m + 8 * g + 4 * h);
-          const float bb[4] = {b.x, b.y, b.z, b.w};
-          float dm[4];
-          if constexpr (DROP) drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(32 * m + 8 * g + 4 * h), a.thresh, a.inv_keep, dm);
+        for (int i = 0; i < 16; ++i) acc[i] = fmaxf(acc[i], 0.f);
+        ef_drop_tile<DROP>(acc, dkey, e_lo + 32u * m, h4, a.thresh);
+        if constexpr (DROP != 0) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            float u = fmaxf(acc[4 * g + j] + bb[j], 0.f);
-            if constexpr (DROP) u *= dm[j];
-            acc[4 * g + j] = u;
-          }
+          for (int i = 0; i < 16; ++i) acc[i] *= keep_scale;
         }
         hf[2 * m] = ef_pack<0>(acc);
         hf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
       ef_store_rows(hf, la, ef_tile_rsrc(a.hout, tok0, nvalid));
-      EF_STAGE_LEAVE()
     }
 
-    // ---- stage W2^T: d_h = d_y2 W2, gated by the recomputed h: d_hpre (G operand of dW1, and db1)
+    // ---- units 2, 3 (W2^T): d_h = d_y2 W2, gated by the recomputed h: d_hpre (G operand of dW1, and db1)
     {
-      asm volatile("" : "+v"(tl), "+v"(h));
-      EF_STAGE_ENTER(1, true, 2)                    // W2^T (next: W1^T)
-      const float keep = DROP ? a.inv_keep : 1.f;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
+        const char* wu = EF_UBUF(2 + (m >> 1));
         ef_f32x16 acc = ef_zero16();
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), gf[ks], acc);
-          if (ks == 3) EF_MID_FENCE();
+        EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), gf)
+        if (m == 1) {
+          EF_UNIT_NEXT_K(2, true, 4, EF_UNIT_BYTES, EF_WAIT_VM(8))       // since the DMA of unit 3: the 8 stores of h
+        } else if (m == 3) {
+          EF_UNIT_NEXT(3, true, 5, EF_UNIT_BYTES)
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = ef_bf(hf[2 * m + (i >> 3)], i & 7) > 0.f ? acc[i] * keep : 0.f;
+        for (int i = 0; i < 16; ++i) acc[i] = ef_bf(hf[2 * m + (i >> 3)], i & 7) > 0.f ? acc[i] * keep_scale : 0.f;
         hf[2 * m] = ef_pack<0>(acc);            // hf now holds d_hpre for the blocks done
         hf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
       ef_store_rows(hf, la, ef_tile_rsrc(a.dhpre, tok0, nvalid));
-      EF_STAGE_LEAVE()
     }
 
-    // ---- stage W1^T: d_x1 = d_z2 + d_hpre W1
+    // ---- units 4, 5 (W1^T): d_x1 = d_z2 + d_hpre W1
     {
-      asm volatile("" : "+v"(tl), "+v"(h));
-      EF_STAGE_ENTER(2, it + gridDim.x < n_it, 0)   // W1^T (next: the next iteration's W1)
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        ef_f32x16 acc = ef_zero16();
+        const char* wu = EF_UBUF(4 + (m >> 1));
+        ef_f32x16 acc;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          acc = EF_MFMA(ef_frag(wb, ef_off(32 * m + tl, 2 * ks + h)), hf[ks], acc);
-          if (ks == 3) EF_MID_FENCE();
+        for (int i = 0; i < 16; ++i) acc[i] = ef_bf(dzf[2 * m + (i >> 3)], i & 7);
+        EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), hf)
+        if (m == 1) {
+          EF_UNIT_NEXT_K(4, has_next, 0, EF_UNIT_BYTES, EF_WAIT_VM(8))   // since the DMA of unit 5: the 8 stores of d_hpre
+        } else if (m == 3) {
+          EF_UNIT_NEXT(5, has_next, 1, EF_UNIT_BYTES)
         }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += ef_bf(dzf[2 * m + (i >> 3)], i & 7);
         dzf[2 * m] = ef_pack<0>(acc);
         dzf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
       ef_store_rows(dzf, la, ef_tile_rsrc(a.dx1, tok0, nvalid));
-      EF_STAGE_LEAVE()
     }
+  }
+  {
+    const float q[8] = {q2[0], q2[2], q2[1], q2[3], qt[0], qt[2], qt[1], qt[3]};      // [d gamma2 | d beta2 | d gamma_t | d beta_t] x halves
+    ef_ln_partials(q, reinterpret_cast<float*>(stg_all), a.lnp, wave, lane, tid);
   }
 }
 
 // ---------------------------------------------------------------------------------------------- backward, attention half
 // From d_x1 (gradient wrt x1, written by the feed-forward half) back to the layer input, everything recomputed from
 // (x, z1) in registers, per wave tile of 32 tokens:
-//     LayerNorm-1 backward -> d_z1 ;  d_y = mask1 . d_z1 ;  d_x(partial) = d_z1 (+ alpha * g)
-//     per head: recompute K, Q, V (BOTH MFMA orientations: a product that contracts over tokens needs its operand with
-//     tokens on the accumulator rows), S^T -> P^T (softmax, same statistics as the forward), O^T (written: dWo operand);
-//     d_o = d_y Wo (both orientations);  dP^T = V dO^T ; dS^T = P^T (dP^T - delta) ; dV^T = dO^T-contracted with P ;
-//     dQ^T = K-contracted with dS^T ; dK^T = Q-contracted with dS  — every one of them one or two 32x32x16 MFMAs on
-//     packed accumulator tiles, no LDS round trip (a 32-entry per-query table in LDS carries max / 1/sum / delta to the
-//     orientation that has queries on rows).
+//     LayerNorm-1 backward -> d_z1 ;  d_y = mask1 . d_z1 ;  d_x(partial) = d_z1 (+ alpha * g) ; LayerNorm-1 parameter sums
+//     per 32-channel block (one head of 32 dims or two of 16): K, Q, V, dO recomputed in BOTH MFMA orientations (a
+//     product that contracts over tokens needs its operand with tokens on the accumulator rows);  per head:
+//         S^T (+ the block-diagonal mask as one more k-step) -> P^T (exp2 softmax) -> Pd^T = dropout(P^T)
+//         O^T = V^T Pd^T                       (written: operand of dWo)
+//         dPd^T = V dO^T ; dS^T = P^T (mask . dPd^T - delta), delta = sum_key P^T mask . dPd^T
+//         dQ^T = K-contracted with dS^T ;  Pd and dS with queries on the accumulator rows are the TRANSPOSES of the
+//         packed Pd^T / dS^T tiles (through a 2.5 KiB wave-private LDS tile: 4 ds_write_b64 + 4 ds_read_b64_tr_b16 each;
+//         round 2 recomputed the scores, the softmax and the dropout hash in the second orientation instead):
+//         dV^T = dO-contracted with Pd ;  dK^T = Q-contracted with dS.
 // Written: d_x (partial: the QKV projection's input gradient is accumulated into it by the next GEMM), d_y, o, d_qkv
-// (operands of the weight-gradient GEMMs for Wo and W_in).  Head dim 32 (4 heads).
-// Stages: per 32-channel head block  Wq rows | Wk rows | Wv rows | Wo^T rows  (8 KiB each).
+// (operands of the weight-gradient GEMMs for Wo and W_in) and the workgroup's partial norm1 parameter sums.
+// Units: per 32-channel block  (Wq rows | Wk rows)  and  (Wv rows | Wo^T rows), 17 KiB each, double-buffered.
 struct EaArgs {
   const unsigned short *dx1, *z1, *x, *g;
   unsigned short *dx, *dy, *o, *dqkv;
@@ -1051,315 +1122,366 @@ struct EaArgs {
   float inv_keep;
   unsigned long long seed;
   unsigned rs0, rs1;
+  int small_idx;
+  float* lnp;                    // [grid][4][128] partial sums: d gamma1, d beta1, 0, 0
 };
 
-// a [32 token][32 channel] block held as two packed fragments -> memory (row stride ld elements), via the restage
-__device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* stg, unsigned short* dst, int ld, int lane,
-                                                 int tl, int h, int nvalid) {
-  asm volatile("" : "+v"(lane), "+v"(tl), "+v"(h));
-  const uint4 v0 = __builtin_bit_cast(uint4, f0), v1 = __builtin_bit_cast(uint4, f1);
-  // fragment s: channels 16s + 4h + 0..3 (.xy), 16s + 8 + 4h + 0..3 (.zw) -> 16-byte chunks 2s, 2s+1 of the 64-byte row
-  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (0 ^ (tl & 3)) + 8 * h) = make_uint2(v0.x, v0.y);
-  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (1 ^ (tl & 3)) + 8 * h) = make_uint2(v0.z, v0.w);
-  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (2 ^ (tl & 3)) + 8 * h) = make_uint2(v1.x, v1.y);
-  *reinterpret_cast<uint2*>(stg + 64 * tl + 16 * (3 ^ (tl & 3)) + 8 * h) = make_uint2(v1.z, v1.w);
+constexpr int EF_T_ROWB = 80;    // transpose tile: 32 rows x 32 bf16 (64 B) padded to 80 B
+// Transpose of a 32 x 32 bf16 tile held as two packed fragments (lane (c, h), fragment s, element j <-> X[16s + 8(j>>2)
+// + 4h + (j&3)][c]) through LDS: returns the fragments of X^T in the same form.  tw = tile + 80 * tl + 8 * h (write
+// base), tr = tile + 80 * (4 * h + ((lane & 15) >> 2)) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3) (transposed-read base).
+__device__ __forceinline__ void ef_transpose32(ef_v8bf f0, ef_v8bf f1, char* tw, const char* tr, ef_v8bf& t0, ef_v8bf& t1) {
+  const uint4 a = __builtin_bit_cast(uint4, f0), b = __builtin_bit_cast(uint4, f1);
+  // row tl of Z = X^T rows: elements r = 16s + 8g + 4h .. +3 at byte 2r
+  *reinterpret_cast<uint2*>(tw) = make_uint2(a.x, a.y);
+  *reinterpret_cast<uint2*>(tw + 16) = make_uint2(a.z, a.w);
+  *reinterpret_cast<uint2*>(tw + 32) = make_uint2(b.x, b.y);
+  *reinterpret_cast<uint2*>(tw + 48) = make_uint2(b.z, b.w);
+  uint2 r[4];
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int t = (lane >> 2) + 16 * p, c = lane & 3;
-    const uint4 v = *reinterpret_cast<const uint4*>(stg + 64 * t + 16 * (c ^ (t & 3)));
-    if (t < nvalid) *reinterpret_cast<uint4*>(dst + (unsigned)(t * ld + 8 * c)) = v;
+  for (int k = 0; k < 4; ++k)        // k = 2 s' + g': rows 16 s' + 8 g' + 4 h' .. +3 of Z, this group's 16 columns
+    r[k] = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ef_lds_v4s_ptr)(tr + EF_T_ROWB * (16 * (k >> 1) + 8 * (k & 1)))));
+  t0 = __builtin_bit_cast(ef_v8bf, make_uint4(r[0].x, r[0].y, r[1].x, r[1].y));
+  t1 = __builtin_bit_cast(ef_v8bf, make_uint4(r[2].x, r[2].y, r[3].x, r[3].y));
+}
+
+// a [32 token][32 channel] block held as two packed fragments -> columns col .. col+31 of a [T, ld] bf16 tensor, via a
+// wave-private restage (64-byte rows padded to 80 B); rs = descriptor of the tile's valid rows (ef_tile_rsrc_ld)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ef_tile_rsrc_ld(const unsigned short* base, long long tok0, int nvalid, int ld) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base + tok0 * ld), 0, nvalid * (ld * 2), 0x00020000);
+}
+__device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* bw, const char* br, __amdgpu_buffer_rsrc_t rs,
+                                                 unsigned go, int ld2 /* row bytes */, int col2 /* column byte offset */) {
+  const uint4 v0 = __builtin_bit_cast(uint4, f0), v1 = __builtin_bit_cast(uint4, f1);
+  // fragment s: channels 16s + 4h + 0..3 (.xy), 16s + 8 + 4h + 0..3 (.zw); bw = tile + 80 * tl + 8 * h
+  *reinterpret_cast<uint2*>(bw) = make_uint2(v0.x, v0.y);
+  *reinterpret_cast<uint2*>(bw + 16) = make_uint2(v0.z, v0.w);
+  *reinterpret_cast<uint2*>(bw + 32) = make_uint2(v1.x, v1.y);
+  *reinterpret_cast<uint2*>(bw + 48) = make_uint2(v1.z, v1.w);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {      // br = tile + 80 * (lane >> 2) + 16 * (lane & 3): rows (lane >> 2) + 16 p
+    const uint4 v = *reinterpret_cast<const uint4*>(br + 16 * p * EF_T_ROWB);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, v), rs, go + (unsigned)(16 * p * ld2), col2, 0);
   }
 }
 
-template <int DROP /* 0 = off, else hash bits per element: 16 | 8 (common.hpp) */>
+template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* wbuf0 = smem;
-  char* wbuf1 = smem + (EF_NBUF - 1) * EF_STAGE_BYTES;
-  float* prm = reinterpret_cast<float*>(smem + EF_NBUF * EF_STAGE_BYTES);
-  char* stg_all = smem + EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4;
+  float* prm = reinterpret_cast<float*>(smem + 2 * EF_UNIT_BYTES);
+  char* stg_all = smem + 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tl0 = lane & 31, h0 = lane >> 5, lane16 = 16 * lane;
-  char* stg = stg_all + wave * 8192;
-  EfLaneAddr la;
-  la.sw = stg + EF_STG_ROWB * tl0 + 8 * h0;
-  la.sr = stg + EF_STG_ROWB * (lane >> 3) + 16 * (lane & 7);
-  la.go = (unsigned)(256 * (lane >> 3) + 16 * (lane & 7));
-  float* tab = reinterpret_cast<float*>(stg + 6144);            // [3][32]: max, 1/sum, delta per query slot
-  constexpr int NH = 4;
-  const float scale = 0.17677669529663687f;
+  const int tl = lane & 31, h = lane >> 5, h4 = 4 * h, lane16 = 16 * lane;
+  char* stg = stg_all + wave * EF_WAVE_LDS;
+  constexpr int NH = EF_C / HD, HB = 32 / HD;
+  const float scale = HD == 32 ? 0.17677669529663687f : 0.25f;
+  const float qscale = scale * 1.4426950408889634f;
   const int S = a.S;
   const int RW = 32 / S;
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
-  EF_PIPE_PROLOGUE()
-  const int q_row = tl0 / S;
-  const int row_lo = q_row * S;
+  if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
+  EF_DMA_LANDED();
+  __syncthreads();
+  if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, wave, lane16);
 
-  int gstage = 0;
+  const int fb = EF_ROWB * tl + 16 * h;
+  const char* pb = reinterpret_cast<const char*>(prm) + 16 * h;
+  const float* pf = reinterpret_cast<const float*>(pb);
+  EfLaneAddr la;
+  la.sw = stg + EF_STG_ROWB * tl + 8 * h;
+  la.sr = stg + EF_STG_ROWB * (lane >> 3) + 16 * (lane & 7);
+  la.go = (unsigned)(256 * (lane >> 3) + 16 * (lane & 7));
+  const unsigned xoff = (unsigned)(256 * tl + 8 * h);
+  const char* trb = stg + EF_STG_ROWB * ((lane & 15) >> 2) + 32 * (lane >> 4) + 8 * (lane & 3);
+  // 32 x 32 tiles (transposes, block stores) live in staging region B
+  char* tile = stg + 4608;
+  char* tw = tile + EF_T_ROWB * tl + 8 * h;
+  const char* ttr = tile + EF_T_ROWB * (4 * h + ((lane & 15) >> 2)) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  const char* tbr = tile + EF_T_ROWB * (lane >> 2) + 16 * (lane & 3);
+  const int q_row = tl / S;
+  const int row_lo = q_row * S;
+  ef_v8bf uf;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) uf[j] = (__bf16)((8 * h + j) == q_row ? 16.f : 0.f);
+  const unsigned skey0 = rng_key(a.seed, a.rs0, 0u), skey1 = rng_key(a.seed, a.rs1, 0u);
+  const float keep_scale = DROP ? a.inv_keep : 1.f;
+  float q1[4] = {0.f, 0.f, 0.f, 0.f};
+
   for (long long it = blockIdx.x; it < n_it; it += gridDim.x) {
-    int tl = tl0, h = h0;
-    asm volatile("" : "+v"(tl), "+v"(h));
-    const long long wt = it * EF_WAVES + wave;
-    const long long row0 = wt * RW;
-    long long rows_here = a.R - row0;
-    rows_here = rows_here < 0 ? 0 : (rows_here > RW ? RW : rows_here);
-    const int nvalid = (int)rows_here * S;
-    const long long tok0 = row0 * S;
-    const bool tok_ok = tl0 < nvalid;
-    const long long tglob = tok0 + tl0;
-    const unsigned long long e_base = (unsigned long long)tglob * EF_C;
-    const unsigned xoff = (unsigned)((tok_ok ? tl0 : 0) * EF_C + 4 * h0);
+    EF_TILE_GEOM(it, row0, nvalid, tok0)
+    const bool has_next = it + gridDim.x < n_it;
+    const unsigned long long e_base = (unsigned long long)tok0 * EF_C + (unsigned long long)(tl * EF_C);
+    const unsigned e_lo = (unsigned)((unsigned long long)tok0 * EF_C) + (unsigned)(tl * EF_C);
 
     // ---- LayerNorm-1 backward: d_z1 -> d_x (partial) and d_y
     ef_v8bf dyf[8], xf[8];
     {
-      ef_v8bf zf[8];
-      EB_LOAD(dyf, a.dx1)
-      EB_LOAD(zf, a.z1)
-      float mu, rstd, s1, s2;
-      ef_row_stats(zf, a.eps, mu, rstd);
-      ef_ln_bwd_sums(dyf, zf, 1.f, mu, rstd, prm + EF_P_G1, h, s1, s2);
+      ef_v8bf zf[8], df[8];
+      const __amdgpu_buffer_rsrc_t rd = ef_tile_rsrc(a.dx1, tok0, nvalid), rz = ef_tile_rsrc(a.z1, tok0, nvalid);
+      EF_LOAD_X(df, rd)
+      EF_LOAD_X(zf, rz)
       const bool with_g = a.alpha != 0.f;
-      if (with_g) { EB_LOAD(xf, a.g) }
-      const unsigned dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
+      if (with_g) {
+        const __amdgpu_buffer_rsrc_t rg = ef_tile_rsrc(a.g, tok0, nvalid);
+        EF_LOAD_X(xf, rg)
+      } else {
 #pragma unroll
-      for (int f = 0; f < 8; ++f) {
-        EF_FENCE();
-        ef_f32x8 dz = ef_ln_bwd_apply(dyf[f], zf[f], 1.f, mu, rstd, s1, s2, prm + EF_P_G1 + 16 * f + 4 * h);
-        ef_f32x8 dxp = dz;
-        if (with_g) {
+        for (int f = 0; f < 8; ++f) xf[f] = __builtin_bit_cast(ef_v8bf, make_uint4(0u, 0u, 0u, 0u));
+      }
+      float mu, rstd;
+      ef_row_stats(zf, a.eps, mu, rstd);
+      unsigned dkey = skey1;
+      if (DROP && !a.small_idx) dkey = rng_key(a.seed, a.rs1, (unsigned)(e_base >> 32));
+      int hs[4] = {0, 0, 0, 0};
+      if constexpr (DROP == 1) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) dxp[j] += a.alpha * (float)xf[f][j];
+        for (int m = 0; m < 4; ++m) hs[m] = (int)(mix32(((e_lo >> 5) + (unsigned)m) ^ dkey) >> h4);
+      }
+      // out2 = d_y = mask1 . d_z1 (over the registers of d_x1); the plain d_z1 (out) is only needed as d_x (partial) =
+      // d_z1 + alpha * g, formed from the rounded out afterwards
+      ef_ln_bwd<true>(df, zf, 1.f, mu, rstd, pf + EF_P_G1, zf, dyf, la, trb, q1, [&](int f, int d, ef_f2 r) {
+        if constexpr (DROP == 1) {
+          const int bit = 16 * (f & 1) + 8 * (d >> 1) + 2 * (d & 1);
+          r.x = __uint_as_float(__float_as_uint(r.x) & ef_bitmask(hs[f >> 1], bit));
+          r.y = __uint_as_float(__float_as_uint(r.y) & ef_bitmask(hs[f >> 1], bit + 1));
+          r *= ef_splat(keep_scale);
+        } else if constexpr (DROP != 0) {
+          float dm[4];
+          drop_scale4_t<DROP>(dkey, e_lo + (unsigned)(16 * f + 8 * (d >> 1)) + (unsigned)h4, a.thresh, a.inv_keep, dm);
+          r.x *= dm[2 * (d & 1)];
+          r.y *= dm[2 * (d & 1) + 1];
         }
-        zf[f] = __builtin_convertvector(dxp, ef_v8bf);
-        if constexpr (DROP) {
-          float dm0[4], dm1[4];
-          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 4 * h), a.thresh, a.inv_keep, dm0);
-          drop_scale4_t<DROP ? DROP : 16>(dkey, (unsigned)e_base + (unsigned)(16 * f + 8 + 4 * h), a.thresh, a.inv_keep, dm1);
+        return r;
+      });
+      if (with_g) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { dz[j] *= dm0[j]; dz[4 + j] *= dm1[j]; }
+        for (int f = 0; f < 8; ++f) {
+          uint4 w;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) w[d] = ef_pk(ef_fma2(ef_unpk(ef_dw(xf[f], d)), ef_splat(a.alpha), ef_unpk(ef_dw(zf[f], d))));
+          zf[f] = __builtin_bit_cast(ef_v8bf, w);
         }
-        dyf[f] = __builtin_convertvector(dz, ef_v8bf);
       }
       ef_store_rows(zf, la, ef_tile_rsrc(a.dx, tok0, nvalid));
       ef_store_rows(dyf, la, ef_tile_rsrc(a.dy, tok0, nvalid));
     }
-    EB_LOAD(xf, a.x)
+    {
+      const __amdgpu_buffer_rsrc_t rx = ef_tile_rsrc(a.x, tok0, nvalid);
+      EF_LOAD_X(xf, rx)
+    }
+    const __amdgpu_buffer_rsrc_t ro = ef_tile_rsrc_ld(a.o, tok0, nvalid, EF_C), rq = ef_tile_rsrc_ld(a.dqkv, tok0, nvalid, 3 * EF_C);
+    const unsigned go_o = (unsigned)((lane >> 2) * (EF_C * 2) + 16 * (lane & 3)), go_q = (unsigned)((lane >> 2) * (3 * EF_C * 2) + 16 * (lane & 3));
+    const unsigned long long att_u = (unsigned long long)row0 * (unsigned long long)(NH * S * S);
+    const unsigned att_l = (unsigned)(q_row * NH * S * S + (tl - row_lo) * S + h4 - row_lo);
 
 #pragma unroll 1
     for (int blk = 0; blk < 4; ++blk) {
-      asm volatile("" : "+v"(tl), "+v"(h));
-      EF_STAGE_ENTER(blk, blk < 3 || it + gridDim.x < n_it, (blk + 1) & 3)
-      const int fo = ef_off(tl, h);                 // chunk (2ks + h) = ef_off(tl, 2ks + h): computed per use below
-      (void)fo;
-#define EA_CHAIN_STD(ACC, WOFF, BOP)                                                                  \
-      ACC = ef_zero16();                                                                              \
+      // transposed-orientation chain: D[token rows, 32 columns] += A . W^T, weight fragments at WT + fb + IMM + 32 ks
+#define EA_CHAIN_TR(ACC, WT, IMM, AOP)                                                                \
       _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
-        ACC = EF_MFMA(ef_frag(wb + (WOFF), ef_off(tl, 2 * ks + h)), BOP[ks], ACC);                    \
-        if (ks == 3) EF_MID_FENCE();                                               \
+        ACC = EF_MFMA(AOP[ks], ef_frag((WT) + (IMM) + 32 * ks, fb), ACC);                             \
+        if (ks == 3) EF_MID_FENCE();                                                                  \
       }
-#define EA_CHAIN_TR(ACC, WOFF, AOP)                                                                   \
-      ACC = ef_zero16();                                                                              \
-      _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                              \
-        ACC = EF_MFMA(AOP[ks], ef_frag(wb + (WOFF), ef_off(tl, 2 * ks + h)), ACC);                    \
-        if (ks == 3) EF_MID_FENCE();                                               \
-      }
-#define EA_ROWBIAS(ACC, POFF)                                                                         \
-      _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
-        const float4 b = *reinterpret_cast<const float4*>(prm + (POFF) + 8 * g + 4 * h);              \
-        ACC[4 * g] += b.x; ACC[4 * g + 1] += b.y; ACC[4 * g + 2] += b.z; ACC[4 * g + 3] += b.w;       \
-      }
+#define EA_SPLAT(ACC, V)                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) ACC[i] = (V);
+      const float* pbias = pf + 32 * blk;                 // (+ 4h applied) row biases of this block: + EF_P_BIN + 128 part
+      const float* plane = prm + 32 * blk + tl;           // per-lane (column) biases
       ef_f32x16 acc;
-      // 1. K^T, Q^T [32 d (rows), 32 tokens]
-      EA_CHAIN_STD(acc, EF_PART_BYTES, xf)
-      EA_ROWBIAS(acc, EF_P_BIN + 128 + 32 * blk)
-      const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
-      EF_FENCE();
-      EA_CHAIN_STD(acc, 0, xf)
-      EA_ROWBIAS(acc, EF_P_BIN + 32 * blk)
-      const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
-      EF_FENCE();
-
-      // dropout geometry of this (table row, head)
-      const unsigned long long blk0 = ((unsigned long long)(row0 + q_row) * NH + blk) * (unsigned long long)(S * S);
-      const unsigned key0 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32));
-      const unsigned key1 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32) + 1u);
-
-      // 2. S^T[key, q] and the softmax down the keys of the query's table row: P^T (fp32)
-      ef_f32x16 pt = ef_zero16();
-      pt = EF_MFMA(kf0, qf0, pt);
-      pt = EF_MFMA(kf1, qf1, pt);
-      float mx = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
-        pt[i] *= scale;
-        mx = (key >= row_lo && key < row_lo + S) ? fmaxf(mx, pt[i]) : mx;
-      }
-      mx = fmaxf(mx, ef_xor32(mx));
-      float l = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
-        pt[i] = (key >= row_lo && key < row_lo + S) ? __expf(pt[i] - mx) : 0.f;
-        l += pt[i];
-      }
-      l += ef_xor32(l);
-      const float inv = 1.f / l;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pt[i] *= inv;
-      tab[tl] = mx;
-      tab[32 + tl] = inv;
-
-      // 3. V [tokens (rows), d]; O^T = V^T Pd^T, written (operand of dWo)
-      EA_CHAIN_TR(acc, 2 * EF_PART_BYTES, xf)
-      {
-        const float bv = prm[EF_P_BIN + 256 + 32 * blk + tl];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += bv;
-      }
-      {
-        const ef_v8bf vt0 = ef_pack<0>(acc), vt1 = ef_pack<1>(acc);
-        ef_f32x16 pd = pt;
-        if constexpr (DROP) {
-          const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const unsigned lo = lo0 + (unsigned)(key - row_lo);
-            pd[i] *= drop_scale_key_t<DROP ? DROP : 16>(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
-          }
-        }
-        const ef_v8bf pd0 = ef_pack<0>(pd), pd1 = ef_pack<1>(pd);
-        ef_f32x16 ot = ef_zero16();
-        ot = EF_MFMA(vt0, pd0, ot);
-        ot = EF_MFMA(vt1, pd1, ot);
-        ef_store_block32(ef_pack<0>(ot), ef_pack<1>(ot), stg, a.o + tok0 * EF_C + 32 * blk, EF_C, lane, tl, h, nvalid);
-      }
-      EF_FENCE();
-
-      // 4. dO^T [d, q] = Wo^T rows . d_y ; V^T [d, key] ; dPd^T = V dO^T ; dS^T
-      EA_CHAIN_STD(acc, 3 * EF_PART_BYTES, dyf)
-      const ef_v8bf dof0 = ef_pack<0>(acc), dof1 = ef_pack<1>(acc);
-      EF_FENCE();
-      EA_CHAIN_STD(acc, 2 * EF_PART_BYTES, xf)
-      EA_ROWBIAS(acc, EF_P_BIN + 256 + 32 * blk)
-      const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
-      EF_FENCE();
-      ef_v8bf dstf0, dstf1;
-      {
-        ef_f32x16 dp = ef_zero16();
-        dp = EF_MFMA(vf0, dof0, dp);
-        dp = EF_MFMA(vf1, dof1, dp);
-        if constexpr (DROP) {
-          const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int key = (i & 3) + 8 * (i >> 2) + 4 * h;
-            const unsigned lo = lo0 + (unsigned)(key - row_lo);
-            dp[i] *= drop_scale_key_t<DROP ? DROP : 16>(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
-          }
-        }
-        float delta = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) delta += pt[i] * dp[i];
-        delta += ef_xor32(delta);
-        tab[64 + tl] = delta;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dp[i] = pt[i] * (dp[i] - delta);
-        dstf0 = ef_pack<0>(dp); dstf1 = ef_pack<1>(dp);
-      }
-      EF_FENCE();
-
-      // 5. dO [q (rows), d] ; P, Pd with queries on rows ; dV^T [d, key]
-      EA_CHAIN_TR(acc, 3 * EF_PART_BYTES, dyf)
-      const ef_v8bf dotf0 = ef_pack<0>(acc), dotf1 = ef_pack<1>(acc);
-      EF_FENCE();
-      ef_f32x16 p2 = ef_zero16();
-      p2 = EF_MFMA(qf0, kf0, p2);
-      p2 = EF_MFMA(qf1, kf1, p2);
-      ef_f32x16 m2;                                   // dropout factor of (query row i, key tl)
-      float dl2[16];
+      // ---- unit 2 blk: Wq rows | Wk rows
+      const char* wa = EF_UBUF(0);
+      // K^T, Q^T [32 d (rows), 32 tokens]
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 mx4 = *reinterpret_cast<const float4*>(tab + 8 * g + 4 * h);
-        const float4 iv4 = *reinterpret_cast<const float4*>(tab + 32 + 8 * g + 4 * h);
-        const float4 dl4 = *reinterpret_cast<const float4*>(tab + 64 + 8 * g + 4 * h);
-        const float mxs[4] = {mx4.x, mx4.y, mx4.z, mx4.w}, ivs[4] = {iv4.x, iv4.y, iv4.z, iv4.w};
-        const float dls[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+        const float4 b = *reinterpret_cast<const float4*>(pbias + EF_P_BIN + 128 + 8 * g);
+        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+      }
+      EF_CHAIN(acc, wa, EF_PART_BYTES, xf)
+      const ef_v8bf kf0 = ef_pack<0>(acc), kf1 = ef_pack<1>(acc);
+      EF_FENCE();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = 4 * g + j;
-          const int q = 8 * g + 4 * h + j;
-          const bool okq = q >= row_lo && q < row_lo + S;
-          p2[i] = okq ? __expf(p2[i] * scale - mxs[j]) * ivs[j] : 0.f;
-          dl2[i] = dls[j];
-          if constexpr (DROP) {
-            const unsigned lo = (unsigned)blk0 + (unsigned)((q - row_lo) * S + (tl - row_lo));
-            m2[i] = drop_scale_key_t<DROP ? DROP : 16>(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, a.inv_keep);
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(pbias + EF_P_BIN + 8 * g);
+        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+      }
+      EF_CHAIN(acc, wa, 0, xf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] *= qscale;
+      const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
+      EF_FENCE();
+      // K [key (rows), d], Q [q (rows), d]: operands of the products that contract over tokens
+      EA_SPLAT(acc, plane[EF_P_BIN + 128])
+      EA_CHAIN_TR(acc, wa, EF_PART_BYTES, xf)
+      const ef_v8bf kt0 = ef_pack<0>(acc), kt1 = ef_pack<1>(acc);
+      EF_FENCE();
+      EA_SPLAT(acc, plane[EF_P_BIN])
+      EA_CHAIN_TR(acc, wa, 0, xf)
+      const ef_v8bf qt0 = ef_pack<0>(acc), qt1 = ef_pack<1>(acc);
+      // boundary: wait for unit 2 blk + 1; since its DMA was issued: the 8 block stores of the previous head block
+      if (blk == 0) { EF_UNIT_NEXT_K(0, true, 2 * blk + 2, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
+      else if (blk < 3) { EF_UNIT_NEXT_K(0, true, 2 * blk + 2, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
+      else { EF_UNIT_NEXT_K(0, has_next, 0, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
+
+      // ---- unit 2 blk + 1: Wv rows | Wo^T rows
+      const char* wb = EF_UBUF(1);
+      EA_SPLAT(acc, plane[EF_P_BIN + 256])
+      EA_CHAIN_TR(acc, wb, 0, xf)                                        // V [key (rows), d]
+      const ef_v8bf vt0 = ef_pack<0>(acc), vt1 = ef_pack<1>(acc);
+      EF_FENCE();
+      acc = ef_zero16();
+      EF_CHAIN(acc, wb, EF_PART_BYTES, dyf)                              // dO^T [d, q] = Wo^T rows . d_y
+      const ef_v8bf dof0 = ef_pack<0>(acc), dof1 = ef_pack<1>(acc);
+      EF_FENCE();
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(pbias + EF_P_BIN + 256 + 8 * g);
+        acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
+      }
+      EF_CHAIN(acc, wb, 0, xf)                                           // V^T [d, key]
+      const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
+      EF_FENCE();
+      acc = ef_zero16();
+      EA_CHAIN_TR(acc, wb, EF_PART_BYTES, dyf)                           // dO [q (rows), d]
+      const ef_v8bf dotf0 = ef_pack<0>(acc), dotf1 = ef_pack<1>(acc);
+      if (blk < 3) { EF_UNIT_NEXT(1, true, 2 * blk + 3, EF_UNIT_BYTES) }
+      else { EF_UNIT_NEXT(1, has_next, 1, EF_UNIT_BYTES) }
+
+      // ---- per head
+      ef_f32x16 o_all, dq_all, dk_all, dv_all;
+#pragma unroll
+      for (int hh = 0; hh < HB; ++hh) {
+        ef_f32x16 pt = EF_MFMA(uf, uf, ef_zero16());
+        if constexpr (HB == 1) {
+          pt = EF_MFMA(kf0, qf0, pt);
+          pt = EF_MFMA(kf1, qf1, pt);
+        } else {
+          pt = hh == 0 ? EF_MFMA(kf0, qf0, pt) : EF_MFMA(kf1, qf1, pt);
+        }
+        // P^T: exp2 softmax down the keys of the query's table row (other rows sit 256 lower: they underflow)
+        float mx = fmaxf(fmaxf(pt[0], pt[1]), pt[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, pt[i]), pt[i + 1]);
+        mx = fmaxf(mx, pt[15]);
+        mx = fmaxf(mx, ef_xor32(mx));
+        float l = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          pt[i] = __builtin_amdgcn_exp2f(pt[i] - mx);
+          l += pt[i];
+        }
+        l += ef_xor32(l);
+        const float inv = __builtin_amdgcn_rcpf(l);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pt[i] *= inv;
+        // dropout mask of this (row, head): AND masks for the 16 (key, query) pairs of this lane
+        unsigned dmask[16];      // (DROP 8 / 16: kept; DROP 1: a bit of hsw per register, re-extracted at each use)
+        int hsw = 0;
+#define EA_DMASK(I) (DROP == 1 ? ef_bitmask(hsw, ((I) & 3) + 8 * ((I) >> 2)) : dmask[I])
+        if constexpr (DROP == 1) {
+          unsigned al = att_l;
+          asm volatile("" : "+v"(al));
+          const unsigned hoff = (unsigned)((blk * HB + hh) * S * S);
+          const unsigned ab32 = (unsigned)att_u + al + hoff;
+          unsigned k0 = skey0, k1 = skey0;
+          if (!a.small_idx) {
+            const unsigned long long ab = att_u + (unsigned long long)(al + hoff);
+            k0 = rng_key(a.seed, a.rs0, (unsigned)(ab >> 32));
+            k1 = rng_key(a.seed, a.rs0, (unsigned)((ab + 32) >> 32));
+          }
+          const unsigned g0 = ab32 >> 5;
+          const unsigned w0 = mix32(g0 ^ k0), w1 = mix32(((g0 + 1u) & 0x07ffffffu) ^ k1);
+          hsw = (int)__builtin_amdgcn_alignbit(w1, w0, ab32 & 31u);
+        } else if constexpr (DROP != 0) {
+          const int head = blk * HB + hh;
+          const unsigned long long blk0 = att_u + (unsigned long long)((q_row * NH + head) * S * S);
+          const unsigned lo0 = (unsigned)blk0 + (unsigned)((tl - row_lo) * S);
+          const unsigned key0 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32));
+          const unsigned key1 = rng_key(a.seed, a.rs0, (unsigned)(blk0 >> 32) + 1u);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = (i & 3) + 8 * (i >> 2) + h4;
+            const unsigned lo = lo0 + (unsigned)(key - row_lo);
+            dmask[i] = drop_scale_key_t<DROP>(lo < (unsigned)blk0 ? key1 : key0, lo, a.thresh, 1.f) != 0.f ? 0xffffffffu : 0u;
+          }
+        }
+        // Pd^T (packed: k = key) and O^T = V^T Pd^T
+        ef_v8bf pd0, pd1;
+        {
+          ef_f32x16 pd;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            if constexpr (DROP != 0) pd[i] = __uint_as_float(__float_as_uint(pt[i]) & EA_DMASK(i)) * keep_scale;
+            else pd[i] = pt[i];
+          }
+          pd0 = ef_pack<0>(pd); pd1 = ef_pack<1>(pd);
+        }
+        {
+          ef_f32x16 ot = EF_MFMA(vt0, pd0, ef_zero16());
+          ot = EF_MFMA(vt1, pd1, ot);
+          if constexpr (HB == 1) o_all = ot;
+          else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o_all[8 * hh + i] = ot[8 * hh + i];
+          }
+        }
+        // dPd^T = V dO^T (contract over this head's dims) ; dS^T
+        ef_v8bf ds0, ds1;
+        {
+          ef_f32x16 dp = ef_zero16();
+          if constexpr (HB == 1) {
+            dp = EF_MFMA(vf0, dof0, dp);
+            dp = EF_MFMA(vf1, dof1, dp);
           } else {
-            m2[i] = 1.f;
+            dp = hh == 0 ? EF_MFMA(vf0, dof0, dp) : EF_MFMA(vf1, dof1, dp);
+          }
+          if constexpr (DROP != 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = __uint_as_float(__float_as_uint(dp[i]) & EA_DMASK(i)) * keep_scale;
+          }
+          float delta = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) delta += pt[i] * dp[i];
+          delta += ef_xor32(delta);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dp[i] = (pt[i] * scale) * (dp[i] - delta);     // (1/sqrt(d) of dQ, dK folded in)
+          ds0 = ef_pack<0>(dp); ds1 = ef_pack<1>(dp);
+        }
+        // dQ^T [d, q] = K-contracted (over keys) with dS^T
+        {
+          ef_f32x16 dq = EF_MFMA(kt0, ds0, ef_zero16());
+          dq = EF_MFMA(kt1, ds1, dq);
+          if constexpr (HB == 1) dq_all = dq;
+          else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dq_all[8 * hh + i] = dq[8 * hh + i];
+          }
+        }
+        // Pd, dS with queries on the accumulator rows: transposes of the packed tiles
+        ef_v8bf pq0, pq1, sq0, sq1;
+        ef_transpose32(pd0, pd1, tw, ttr, pq0, pq1);
+        ef_transpose32(ds0, ds1, tw, ttr, sq0, sq1);
+        {
+          ef_f32x16 dv = EF_MFMA(dotf0, pq0, ef_zero16());                 // dV^T [d, key] = sum_q dO[q, d] Pd[q, key]
+          dv = EF_MFMA(dotf1, pq1, dv);
+          ef_f32x16 dk = EF_MFMA(qt0, sq0, ef_zero16());                   // dK^T [d, key] = sum_q Q[q, d] dS[q, key]
+          dk = EF_MFMA(qt1, sq1, dk);
+          if constexpr (HB == 1) { dv_all = dv; dk_all = dk; }
+          else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { dv_all[8 * hh + i] = dv[8 * hh + i]; dk_all[8 * hh + i] = dk[8 * hh + i]; }
           }
         }
       }
-      ef_v8bf dvf0, dvf1;
-      {
-        ef_f32x16 pd2;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pd2[i] = p2[i] * m2[i];
-        const ef_v8bf pd20 = ef_pack<0>(pd2), pd21 = ef_pack<1>(pd2);
-        ef_f32x16 dv = ef_zero16();
-        dv = EF_MFMA(dotf0, pd20, dv);
-        dv = EF_MFMA(dotf1, pd21, dv);
-        dvf0 = ef_pack<0>(dv); dvf1 = ef_pack<1>(dv);
-      }
-      ef_store_block32(dvf0, dvf1, stg, a.dqkv + tok0 * (3 * EF_C) + 256 + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
-      EF_FENCE();
-
-      // 6. K [key (rows), d] ; dQ^T [d, q] = K-contracted with dS^T
-      EA_CHAIN_TR(acc, EF_PART_BYTES, xf)
-      {
-        const float bk = prm[EF_P_BIN + 128 + 32 * blk + tl];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += bk;
-      }
-      {
-        const ef_v8bf kt0 = ef_pack<0>(acc), kt1 = ef_pack<1>(acc);
-        ef_f32x16 dq = ef_zero16();
-        dq = EF_MFMA(kt0, dstf0, dq);
-        dq = EF_MFMA(kt1, dstf1, dq);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dq[i] *= scale;
-        ef_store_block32(ef_pack<0>(dq), ef_pack<1>(dq), stg, a.dqkv + tok0 * (3 * EF_C) + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
-      }
-      EF_FENCE();
-
-      // 7. Q [q (rows), d] ; dPd, dS with queries on rows ; dK^T [d, key] = Q-contracted with dS
-      EA_CHAIN_TR(acc, 0, xf)
-      {
-        const float bq = prm[EF_P_BIN + 32 * blk + tl];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += bq;
-      }
-      {
-        const ef_v8bf qt0 = ef_pack<0>(acc), qt1 = ef_pack<1>(acc);
-        ef_f32x16 ds = ef_zero16();
-        ds = EF_MFMA(dof0, vf0, ds);                  // dPd[q, key] = sum_d dO^T[d, q] V^T[d, key]
-        ds = EF_MFMA(dof1, vf1, ds);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) ds[i] = p2[i] * (ds[i] * m2[i] - dl2[i]);
-        const ef_v8bf ds0 = ef_pack<0>(ds), ds1 = ef_pack<1>(ds);
-        ef_f32x16 dk = ef_zero16();
-        dk = EF_MFMA(qt0, ds0, dk);
-        dk = EF_MFMA(qt1, ds1, dk);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) dk[i] *= scale;
-        ef_store_block32(ef_pack<0>(dk), ef_pack<1>(dk), stg, a.dqkv + tok0 * (3 * EF_C) + 128 + 32 * blk, 3 * EF_C, lane, tl, h, nvalid);
-      }
-      EF_STAGE_LEAVE()
+      ef_store_block32(ef_pack<0>(o_all), ef_pack<1>(o_all), tw, tbr, ro, go_o, EF_C * 2, 64 * blk);
+      ef_store_block32(ef_pack<0>(dq_all), ef_pack<1>(dq_all), tw, tbr, rq, go_q, 3 * EF_C * 2, 64 * blk);
+      ef_store_block32(ef_pack<0>(dk_all), ef_pack<1>(dk_all), tw, tbr, rq, go_q, 3 * EF_C * 2, 256 + 64 * blk);
+      ef_store_block32(ef_pack<0>(dv_all), ef_pack<1>(dv_all), tw, tbr, rq, go_q, 3 * EF_C * 2, 512 + 64 * blk);
     }
+  }
+  {
+    const float q[8] = {q1[0], q1[2], q1[1], q1[3], 0.f, 0.f, 0.f, 0.f};
+    ef_ln_partials(q, reinterpret_cast<float*>(stg_all), a.lnp, wave, lane, tid);
   }
 }
 
@@ -1378,95 +1500,9 @@ __global__ void __launch_bounds__(256) k_encoder_pack_attn_bwd(const unsigned sh
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm parameter gradients
-// The chained kernels keep a token on a lane, so sums over TOKENS (the LayerNorm weight / bias gradients) are taken by
-// this streaming pass instead: 16 lanes per token row (8 channels each), per-thread column accumulators, per-block
-// partial vectors summed in block order by k_ef_reduce (deterministic, no float atomics).
-//   MODE 0 (tail + norm2): reads g = d out and z2:  d_gt, d_bt (tail) and d_g2, d_be2
-//   MODE 1 (norm1):        reads d_x1 and z1:       d_g1, d_be1
-constexpr int EG_BLOCK = 256, EG_MAXBLK = 1024;
-struct EgArgs {
-  const unsigned short *dy, *z;
-  const float *g_inner, *b_inner, *g_tail;      // MODE 0: gamma2, beta2, gamma_t;  MODE 1: unused
-  float* partials;                              // [grid][4][128]
-  long long T;
-  int tail;
-  float beta_c, eps;
-};
-template <int MODE>
-__global__ void __launch_bounds__(EG_BLOCK) k_encoder_ln_grads(const EgArgs a) {
-  __shared__ float red[16][4][128];
-  const int gl = threadIdx.x & 15, gi = threadIdx.x >> 4;
-  float acc[4][8];
-#pragma unroll
-  for (int v = 0; v < 4; ++v)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[v][j] = 0.f;
-  float g2[8], b2[8], gt[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    g2[j] = MODE == 0 ? a.g_inner[8 * gl + j] : 1.f;
-    b2[j] = MODE == 0 ? a.b_inner[8 * gl + j] : 0.f;
-    gt[j] = (MODE == 0 && a.tail) ? a.g_tail[8 * gl + j] : 1.f;
-  }
-  for (long long row = (long long)blockIdx.x * 16 + gi; row < a.T; row += (long long)gridDim.x * 16) {
-    float dy[8], z[8];
-    loadv<bf16_t, 8>(reinterpret_cast<const bf16_t*>(a.dy) + row * EF_C + 8 * gl, dy);
-    loadv<bf16_t, 8>(reinterpret_cast<const bf16_t*>(a.z) + row * EF_C + 8 * gl, z);
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += z[j];
-    const float mu = group_sum<16>(s) * (1.f / 128.f);
-    float v = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = z[j] - mu; v += d * d; }
-    const float rstd = rsqrtf(group_sum<16>(v) * (1.f / 128.f) + a.eps);
-    float zh[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) zh[j] = (z[j] - mu) * rstd;
-    if (MODE == 0 && a.tail) {
-      // x2 = bf16(LN2(z2)); tail statistics; d_x2 = tail LayerNorm backward of beta_c * g
-      float x2[8], s2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { x2[j] = bf2f(f2bf(zh[j] * g2[j] + b2[j])); s2 += x2[j]; }
-      const float mut = group_sum<16>(s2) * (1.f / 128.f);
-      float vt = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = x2[j] - mut; vt += d * d; }
-      const float rstdt = rsqrtf(group_sum<16>(vt) * (1.f / 128.f) + a.eps);
-      float t1 = 0.f, t2 = 0.f, xh[8], dg[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float go = dy[j] * a.beta_c;
-        xh[j] = (x2[j] - mut) * rstdt;
-        acc[2][j] += go * xh[j];            // d gamma_t
-        acc[3][j] += go;                    // d beta_t
-        dg[j] = go * gt[j];
-        t1 += dg[j];
-        t2 += dg[j] * xh[j];
-      }
-      t1 = group_sum<16>(t1) * (1.f / 128.f);
-      t2 = group_sum<16>(t2) * (1.f / 128.f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dy[j] = bf2f(f2bf(rstdt * (dg[j] - t1 - xh[j] * t2)));     // d_x2, rounded as the chain rounds it
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      acc[0][j] += dy[j] * zh[j];           // d gamma (norm2 / norm1)
-      acc[1][j] += dy[j];                   // d beta
-    }
-  }
-#pragma unroll
-  for (int v = 0; v < 4; ++v)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) red[gi][v][8 * gl + j] = acc[v][j];
-  __syncthreads();
-  for (int i = threadIdx.x; i < 4 * 128; i += EG_BLOCK) {
-    float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t += red[r][i >> 7][i & 127];
-    a.partials[(size_t)blockIdx.x * 512 + i] = t;
-  }
-}
+// The chained backward kernels leave one partial row [4][128] per workgroup (ef_ln_partials); k_ef_reduce sums the rows
+// in block order (deterministic, no float atomics).  (Round 2 had a separate streaming pass over g, z2 / d_x1, z1 for
+// these sums: 0.83 ms per step.)
 struct EgOut { float* dst[4]; };
 __global__ void __launch_bounds__(1024) k_ef_reduce(const float* __restrict__ partials, int nblk, const EgOut o, int accumulate) {
   __shared__ float red[8][128];
@@ -1606,7 +1642,7 @@ extern "C" int tg_encoder_pack_tiles(const void* const* tiles, const int32_t* ld
   return 0;
 }
 
-static size_t ef_lds_bytes() { return EF_NBUF * EF_STAGE_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192; }
+static size_t ef_lds_bytes() { return 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4 + EF_WAVES * EF_WAVE_LDS; }
 static unsigned ef_grid(long long R, int S) {
   const int RW = 32 / S;
   const long long n_wt = (R + RW - 1) / RW, n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
@@ -1627,9 +1663,9 @@ static unsigned ef_grid(long long R, int S) {
 extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void* z2, void* dx1, void* dy2, void* hout,
                                        void* dhpre, void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S,
                                        int32_t tail, float beta_c, float eps, float p_drop, uint64_t seed,
-                                       const uint32_t* rs, void* stream) {
+                                       const uint32_t* rs, float* lnp, void* stream) {
   TG_CHECK(S >= 2 && S <= 32, "tg_encoder_bwd_ffn_bf16: unsupported S=%d", S);
-  TG_CHECK(g && z1 && z2 && dx1 && dy2 && hout && dhpre && x1out && wpack && prm && rs, "tg_encoder_bwd_ffn_bf16: null operand");
+  TG_CHECK(g && z1 && z2 && dx1 && dy2 && hout && dhpre && x1out && wpack && prm && rs && lnp, "tg_encoder_bwd_ffn_bf16: null operand");
   if (R <= 0) return 0;
   EbArgs a;
   a.g = (const unsigned short*)g; a.z1 = (const unsigned short*)z1; a.z2 = (const unsigned short*)z2;
@@ -1639,6 +1675,8 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
   a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   a.seed = seed; a.rs2 = rs[2]; a.rs3 = rs[3];
+  a.small_idx = (double)(R + 32) * S * 128.0 < 4294967296.0 ? 1 : 0;
+  a.lnp = lnp;
   const size_t lds = ef_lds_bytes();
   const unsigned grid = ef_grid(R, S);
   const int drop = drop_mode(a.thresh);      // DROP template value (common.hpp)
@@ -1658,28 +1696,17 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
   return 0;
 }
 
-extern "C" int64_t tg_encoder_ln_grads_partials_floats(void) { return (int64_t)EG_MAXBLK * 512; }
-// LayerNorm parameter gradients of the fused layer backward (k_encoder_ln_grads).
-//   mode 0: dy = d out, z = z2, gamma/beta = norm2's, gamma_t = tail norm's (NULL without tail):
-//           out[0] = d gamma2, out[1] = d beta2, out[2] = d gamma_t, out[3] = d beta_t
-//   mode 1: dy = d_x1, z = z1: out[0] = d gamma1, out[1] = d beta1
-// out[i] fp32 [128] or NULL; accumulate = 1 adds into them (.grad semantics).  partials: tg_encoder_ln_grads_partials_floats().
-extern "C" int tg_encoder_ln_grads(int32_t mode, const void* dy, const void* z, const float* gamma, const float* beta,
-                                   const float* gamma_t, float beta_c, float eps, int64_t T, float* const* out,
-                                   int32_t accumulate, float* partials, void* stream) {
-  TG_CHECK((mode == 0 || mode == 1) && dy && z && out && partials, "tg_encoder_ln_grads: bad arguments");
-  TG_CHECK(mode == 1 || (gamma && beta), "tg_encoder_ln_grads: mode 0 needs norm2's gamma / beta");
+// The chained backward kernels leave per-workgroup partial LayerNorm parameter sums (lnp [nblk][4][128], nblk =
+// tg_encoder_ln_partial_blocks(R, S)); this sums them in block order (deterministic) into out[i] (fp32 [128] or NULL;
+// accumulate = 1 adds: .grad semantics).  Feed-forward half: d gamma2, d beta2, d gamma_t, d beta_t; attention half:
+// d gamma1, d beta1.
+extern "C" int64_t tg_encoder_ln_partial_blocks(int64_t R, int32_t S) { return S >= 1 && S <= 32 && R > 0 ? (int64_t)ef_grid(R, S) : 0; }
+extern "C" int tg_encoder_ln_reduce(const float* lnp, int64_t nblk, float* const* out, int32_t accumulate, void* stream) {
+  TG_CHECK(lnp && out && nblk >= 0, "tg_encoder_ln_reduce: bad arguments");
+  if (nblk == 0) return 0;
   EgOut o;
-  for (int i = 0; i < 4; ++i) o.dst[i] = (mode == 0 || i < 2) ? out[i] : nullptr;
-  hipStream_t st = (hipStream_t)stream;
-  if (T <= 0) return 0;
-  EgArgs a;
-  a.dy = (const unsigned short*)dy; a.z = (const unsigned short*)z; a.g_inner = gamma; a.b_inner = beta; a.g_tail = gamma_t;
-  a.partials = partials; a.T = T; a.tail = gamma_t != nullptr; a.beta_c = beta_c; a.eps = eps;
-  const int grid = grid_cap(ceil_div(T, 16 * 8), EG_MAXBLK);
-  if (mode == 0) hipLaunchKernelGGL(k_encoder_ln_grads<0>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
-  else hipLaunchKernelGGL(k_encoder_ln_grads<1>, dim3(grid), dim3(EG_BLOCK), 0, st, a);
-  hipLaunchKernelGGL(k_ef_reduce, dim3(4), dim3(1024), 0, st, partials, grid, o, accumulate);
+  for (int i = 0; i < 4; ++i) o.dst[i] = out[i];
+  hipLaunchKernelGGL(k_ef_reduce, dim3(4), dim3(1024), 0, (hipStream_t)stream, lnp, (int)nblk, o, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }
@@ -1690,9 +1717,10 @@ extern "C" int tg_encoder_ln_grads(int32_t mode, const void* dy, const void* z, 
 extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const void* x, const void* g, void* dx, void* dy,
                                         void* o, void* dqkv, const void* w_in, const void* w_o_t, int32_t ld_ot,
                                         void* wpack, const float* prm, int64_t R, int32_t S, int32_t H, float alpha,
-                                        float eps, float p_drop, uint64_t seed, const uint32_t* rs, void* stream) {
-  TG_CHECK(S >= 2 && S <= 32 && H == 4, "tg_encoder_bwd_attn_bf16: unsupported geometry S=%d H=%d (4 heads only)", S, H);
-  TG_CHECK(dx1 && z1 && x && dx && dy && o && dqkv && w_in && w_o_t && wpack && prm && rs && (g || alpha == 0.f),
+                                        float eps, float p_drop, uint64_t seed, const uint32_t* rs, float* lnp,
+                                        void* stream) {
+  TG_CHECK(S >= 2 && S <= 32 && (H == 4 || H == 8), "tg_encoder_bwd_attn_bf16: unsupported geometry S=%d H=%d", S, H);
+  TG_CHECK(dx1 && z1 && x && dx && dy && o && dqkv && w_in && w_o_t && wpack && prm && rs && lnp && (g || alpha == 0.f),
            "tg_encoder_bwd_attn_bf16: null operand");
   if (R <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -1705,20 +1733,26 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
   a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1];
+  a.small_idx = ((double)(R + 32) * S * 128.0 < 4294967296.0 && (double)(R + 32) * H * S * S < 4294967296.0) ? 1 : 0;
+  a.lnp = lnp;
   const size_t lds = ef_lds_bytes();
   const unsigned grid = ef_grid(R, S);
   const int drop = drop_mode(a.thresh);      // DROP template value (common.hpp)
-#define EF_LAUNCH_B(DR_)                                                                                       \
+#define EF_LAUNCH_B(HD_, DR_)                                                                                  \
   {                                                                                                            \
     static bool attr_done = false;                                                                             \
     if (!attr_done) {                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_attn<DR_>),                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_attn<HD_, DR_>),                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
       attr_done = true;                                                                                        \
     }                                                                                                          \
-    hipLaunchKernelGGL((k_encoder_bwd_attn<DR_>), dim3(grid), dim3(EF_THREADS), lds, st, a);                    \
+    hipLaunchKernelGGL((k_encoder_bwd_attn<HD_, DR_>), dim3(grid), dim3(EF_THREADS), lds, st, a);              \
   }
-  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 1) EF_LAUNCH_B(1) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
+  if (H == 4) {
+    if (drop == 0) EF_LAUNCH_B(32, 0) else if (drop == 1) EF_LAUNCH_B(32, 1) else if (drop == 8) EF_LAUNCH_B(32, 8) else EF_LAUNCH_B(32, 16)
+  } else {
+    if (drop == 0) EF_LAUNCH_B(16, 0) else if (drop == 1) EF_LAUNCH_B(16, 1) else if (drop == 8) EF_LAUNCH_B(16, 8) else EF_LAUNCH_B(16, 16)
+  }
 #undef EF_LAUNCH_B
   TG_LAUNCH_CHECK();
   return 0;

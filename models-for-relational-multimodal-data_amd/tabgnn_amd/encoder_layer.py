@@ -24,7 +24,6 @@ from . import ops
 _FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B switch
 _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B switch: the one-kernel layer (encoder_fused.hip)
 _FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
-_FUSED_ATTN_BWD = os.environ.get("TABGNN_NO_FUSED_ATTN_BWD") != "1"     # ... its attention-half backward kernel
 
 
 STATS = {"fused_fwd": 0, "fused_bwd": 0, "fused_bwd_attn": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
@@ -272,51 +271,56 @@ def _grad_ptrs(params):
     return tg if all(t is not None for t in tg) else None
 
 
-def _ln_grads(mode, dy, z, gamma, beta, gamma_t, beta_c, params):
-    """LayerNorm weight / bias gradients by the streaming pass (tg_encoder_ln_grads); ``params`` = the parameters whose
-    gradients come out, in the kernel's order.  Adds into their gradient buffers when every one has one (returns Nones),
-    else returns fp32 tensors."""
-    lib = L.load()
-    T = dy.numel() // 128
-    dev = dy.device
-    partials = torch.empty(lib.tg_encoder_ln_grads_partials_floats(), dtype=torch.float32, device=dev)
+def _ln_reduce(lnp, nblk, params):
+    """Sum the per-workgroup partial LayerNorm parameter gradients the chained backward kernels left in ``lnp``
+    (tg_encoder_ln_reduce).  ``params`` = up to four parameters in the kernel's row order (None = row not wanted).
+    Adds into their gradient buffers when every wanted one has one (returns Nones), else returns fp32 tensors."""
+    dev = lnp.device
     live = [p for p in params if p is not None]
     tg = _grad_ptrs(live)
-    outs = tg if tg is not None else [torch.empty(128, dtype=torch.float32, device=dev) for _ in live]
-    arr = (ctypes.c_void_p * 4)(*([t.data_ptr() for t in outs] + [None] * (4 - len(outs))))
-    f = lambda t: None if t is None else L.ptr(t.detach())
-    L.call("tg_encoder_ln_grads", mode, L.ptr(dy), L.ptr(z), f(gamma), f(beta), f(gamma_t), float(beta_c), 1e-5, T,
-           ctypes.addressof(arr), int(tg is not None), L.ptr(partials), L.stream())
-    return [None] * len(live) if tg is not None else outs
+    outs = iter(tg if tg is not None else [torch.empty(128, dtype=torch.float32, device=dev) for _ in live])
+    res, ptrs = [], []
+    for p in params:
+        if p is None:
+            ptrs.append(None); res.append(None)
+        else:
+            o = next(outs)
+            ptrs.append(o.data_ptr())
+            res.append(None if tg is not None else o)
+    arr = (ctypes.c_void_p * 4)(*(ptrs + [None] * (4 - len(ptrs))))
+    L.call("tg_encoder_ln_reduce", L.ptr(lnp), nblk, ctypes.addressof(arr), int(tg is not None), L.stream())
+    return res
 
 
 def _fused_backward(ctx, g):
-    """Backward of the one-kernel layer: everything is recomputed from (x, z1, z2).  Feed-forward half: one chained
-    kernel (tg_encoder_bwd_ffn_bf16) + the two weight-gradient GEMMs + the LayerNorm-parameter pass."""
+    """Backward of the one-kernel layer: everything is recomputed from (x, z1, z2) by two chained kernels — the
+    feed-forward half (tg_encoder_bwd_ffn_bf16) and the attention half (tg_encoder_bwd_attn_bf16, 4 or 8 heads) — which
+    also leave the LayerNorm parameter gradients as per-workgroup partial sums; the weight-gradient GEMMs take the
+    operand pairs the kernels wrote."""
     (x2d, z1, z2, prm, lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, g2, be2, gt) = ctx.saved_tensors
     R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
     p_in, pb_in, p_o, p_1, pb_1, p_2, pb_2 = ctx.params[:7]
     T = R * S
     dev = g.device
+    lib = L.load()
     g = g.contiguous().view(T, C)
     rs_arr = (ctypes.c_uint32 * 4)(*rs)
+    stage = lib.tg_encoder_stage_bytes()
+    nblk = lib.tg_encoder_ln_partial_blocks(R, S)
     # ---- feed-forward half
     tiles = [lw1.contiguous(), ops.wt(lw2, p_2).contiguous(), ops.wt(lw1, p_1).contiguous()]      # W1, W2^T, W1^T
-    wpack_b = torch.empty(3 * L.load().tg_encoder_stage_bytes(), dtype=torch.uint8, device=dev)
+    wpack_b = torch.empty(3 * stage, dtype=torch.uint8, device=dev)
     tp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tiles])
     ld = (ctypes.c_int32 * 3)(*[t.stride(0) for t in tiles])
     L.call("tg_encoder_pack_tiles", ctypes.addressof(tp), ctypes.addressof(ld), 3, L.ptr(wpack_b), L.stream())
     d_x1, d_y2, h, d_hpre, x1 = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(5))
+    lnp = torch.empty(nblk * 512, dtype=torch.float32, device=dev)
     ops._launch("tg_encoder_bwd_ffn_bf16", L.ptr(g), L.ptr(z1), L.ptr(z2), L.ptr(d_x1), L.ptr(d_y2), L.ptr(h), L.ptr(d_hpre),
                 L.ptr(x1), L.ptr(wpack_b), L.ptr(prm), R, S, int(tail), float(beta_c), 1e-5, float(p), int(seed),
-                ctypes.addressof(rs_arr), L.stream(), nbytes=2 * T * C * 8)
+                ctypes.addressof(rs_arr), L.ptr(lnp), L.stream(), nbytes=2 * T * C * 8)
     STATS["fused_bwd"] += 1
     gg2, gb2, ggt, gbt = ctx.ln_params[1][0], ctx.ln_params[1][1], ctx.ln_params[2][0], ctx.ln_params[2][1]
-    if tail:
-        dg2, dbe2, dgt, dbt = _ln_grads(0, g, z2, g2, be2, gt, beta_c, (gg2, gb2, ggt, gbt))
-    else:
-        dg2, dbe2 = _ln_grads(0, g, z2, g2, be2, None, beta_c, (gg2, gb2))
-        dgt = dbt = None
+    dg2, dbe2, dgt, dbt = _ln_reduce(lnp, nblk, (gg2, gb2, ggt if tail else None, gbt if tail else None))
     dw2, db2 = ops.weight_grad(d_y2, h, True, p_2, pb_2)
     if db2 is None and dw2 is not None:
         db2 = d_y2.sum(0, dtype=torch.float32)
@@ -325,48 +329,27 @@ def _fused_backward(ctx, g):
     if db1 is None and dw1 is not None:
         db1 = d_hpre.sum(0, dtype=torch.float32)
     del d_hpre, x1
-    # ---- attention half
+    # ---- attention half: LayerNorm-1 backward, output-projection backward, attention backward on recomputed q/k/v/P
     p_bo = ctx.params[7]
-    if H == 4 and _FUSED_ATTN_BWD:
-        # one chained kernel: LayerNorm-1 backward, output-projection backward, attention backward on recomputed q/k/v/P
-        wo_t = ops.wt(lw_o, p_o)
-        if not wo_t.is_contiguous():
-            wo_t = wo_t.contiguous()
-        wpack_a = torch.empty(4 * L.load().tg_encoder_stage_bytes(), dtype=torch.uint8, device=dev)
-        d_x, d_y, o = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(3))
-        d_qkv = torch.empty(T, 3 * C, dtype=g.dtype, device=dev)
-        with_g = tail and alpha != 0.0
-        ops._launch("tg_encoder_bwd_attn_bf16", L.ptr(d_x1), L.ptr(z1), L.ptr(x2d), L.ptr(g) if with_g else None, L.ptr(d_x),
-                    L.ptr(d_y), L.ptr(o), L.ptr(d_qkv), L.ptr(lw_in.contiguous()), L.ptr(wo_t), wo_t.stride(0),
-                    L.ptr(wpack_a), L.ptr(prm), R, S, H, float(alpha) if with_g else 0.0, 1e-5, float(p), int(seed),
-                    ctypes.addressof(rs_arr), L.stream(), nbytes=2 * T * C * (9 + int(with_g)))
-        STATS["fused_bwd_attn"] += 1
-        dg1, dbe1 = _ln_grads(1, d_x1, z1, None, None, None, 1.0, (ctx.ln_params[0][0], ctx.ln_params[0][1]))
-        del d_x1
-        dwo, dbo = ops.weight_grad(d_y, o, True, p_o, p_bo)
-        if dbo is None and dwo is not None:
-            dbo = d_y.sum(0, dtype=torch.float32)
-        del d_y, o
-    else:
-        # the op-by-op kernels on recomputed qkv / o (8 heads)
-        qkv = ops.gemm_nt(x2d, lw_in, b_in.detach())
-        o = torch.empty(T, C, dtype=g.dtype, device=dev)
-        lse = torch.empty(R, H, S, dtype=torch.float32, device=dev)
-        L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, H, p, seed, rs[0], L.dt(qkv), L.stream())
-        _, st1 = _ln_fwd(z1, None, None, g1, be1, None, 0.0, 1.0, 0.0, 0, 0)
-        tg1 = ops.ln_grad_targets(*ctx.ln_params[0])
-        acc_dx = tail and alpha != 0.0
-        d_x = g * alpha if acc_dx else torch.empty_like(g)
-        d_y, dp1 = _ln_bwd(z1, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
-        dg1, dbe1, dbo = dp1[0], dp1[1], dp1[2]
-        del d_x1
-        dwo, _ = ops.weight_grad(d_y, o, False, p_o)
-        d_o = ops.gemm_nt(d_y, ops.wt(lw_o, p_o))
-        del d_y
-        d_qkv = torch.empty_like(qkv)
-        L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
-               L.dt(qkv), L.stream())
-        del d_o, qkv, o
+    wo_t = ops.wt(lw_o, p_o)
+    if not wo_t.is_contiguous():
+        wo_t = wo_t.contiguous()
+    wpack_a = torch.empty(4 * stage, dtype=torch.uint8, device=dev)
+    d_x, d_y, o = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(3))
+    d_qkv = torch.empty(T, 3 * C, dtype=g.dtype, device=dev)
+    with_g = tail and alpha != 0.0
+    lnp1 = torch.empty(nblk * 512, dtype=torch.float32, device=dev)
+    ops._launch("tg_encoder_bwd_attn_bf16", L.ptr(d_x1), L.ptr(z1), L.ptr(x2d), L.ptr(g) if with_g else None, L.ptr(d_x),
+                L.ptr(d_y), L.ptr(o), L.ptr(d_qkv), L.ptr(lw_in.contiguous()), L.ptr(wo_t), wo_t.stride(0),
+                L.ptr(wpack_a), L.ptr(prm), R, S, H, float(alpha) if with_g else 0.0, 1e-5, float(p), int(seed),
+                ctypes.addressof(rs_arr), L.ptr(lnp1), L.stream(), nbytes=2 * T * C * (9 + int(with_g)))
+    STATS["fused_bwd_attn"] += 1
+    dg1, dbe1 = _ln_reduce(lnp1, nblk, (ctx.ln_params[0][0], ctx.ln_params[0][1]))[:2]
+    del d_x1
+    dwo, dbo = ops.weight_grad(d_y, o, True, p_o, p_bo)
+    if dbo is None and dwo is not None:
+        dbo = d_y.sum(0, dtype=torch.float32)
+    del d_y, o
     dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
     if dbin is None and dwin is not None:
         dbin = d_qkv.sum(0, dtype=torch.float32)

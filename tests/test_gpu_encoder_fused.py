@@ -135,7 +135,7 @@ def test_fused_training_gradients_match_op_by_op_kernels(S, H, R, use_tail, alph
     EL._FUSED_TRAIN = True
     out_f, g_f = _grads(layer, tail, x, p, use_tail, alpha, beta_c, co)
     assert EL.STATS["fused_fwd"] == n0["fused_fwd"] + 1 and EL.STATS["fused_bwd"] == n0["fused_bwd"] + 1
-    assert EL.STATS["fused_bwd_attn"] == n0["fused_bwd_attn"] + (1 if H == 4 else 0)      # 8 heads: op-by-op attention half
+    assert EL.STATS["fused_bwd_attn"] == n0["fused_bwd_attn"] + 1                          # 4 and 8 heads: the chained attention half
     EL._FUSED_TRAIN = False
     try:
         out_u, g_u = _grads(layer, tail, x, p, use_tail, alpha, beta_c, co)
