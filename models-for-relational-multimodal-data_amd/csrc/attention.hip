@@ -324,6 +324,15 @@ static int attn_common(AttnArgs& a, int64_t R, int32_t S, int32_t C, int32_t H, 
   return 0;
 }
 
+namespace tg {      // attention_mfma.hip: long rows in bf16 on MFMA
+bool attn_mfma_ok(int32_t S, int32_t C, int32_t H, int32_t dt);
+void attn_mfma_fwd(const void* qkv, void* out, float* lse, int64_t R, int32_t S, int32_t C, int32_t H, float scale,
+                   unsigned thresh, float inv_keep, uint64_t seed, uint32_t rstream, hipStream_t st);
+void attn_mfma_bwd(const void* qkv, const void* o, const void* dout, const float* lse, void* dqkv, int64_t R, int32_t S,
+                   int32_t C, int32_t H, float scale, unsigned thresh, float inv_keep, uint64_t seed, uint32_t rstream,
+                   hipStream_t st);
+}
+
 extern "C" int tg_attn_fwd(const void* qkv, void* out, float* lse, int64_t R, int32_t S, int32_t C, int32_t H,
                            float p_drop, uint64_t seed, uint32_t rstream, int32_t dt, void* stream) {
   TG_CHECK(H > 0 && C % H == 0 && S > 0, "tg_attn_fwd: bad geometry C=%d H=%d S=%d", C, H, S);
@@ -331,6 +340,11 @@ extern "C" int tg_attn_fwd(const void* qkv, void* out, float* lse, int64_t R, in
   AttnArgs a{};
   a.qkv = qkv; a.out = out; a.lse = lse;
   attn_common(a, R, S, C, H, p_drop, seed, rstream, stream);
+  if (attn_mfma_ok(S, C, H, dt)) {
+    attn_mfma_fwd(qkv, out, lse, R, S, C, H, a.scale, a.thresh, a.inv_keep, seed, rstream, a.st);
+    TG_LAUNCH_CHECK();
+    return 0;
+  }
   int rc = dt == F32 ? dispatch<float>(a, C / H, true) : dispatch<bf16_t>(a, C / H, true);
   if (rc) return rc;
   TG_LAUNCH_CHECK();
@@ -345,6 +359,12 @@ extern "C" int tg_attn_bwd(const void* qkv, const void* o, const void* dout, con
   AttnArgs a{};
   a.qkv = qkv; a.o = o; a.dout = dout; a.lse = const_cast<float*>(lse); a.dqkv = dqkv;
   attn_common(a, R, S, C, H, p_drop, seed, rstream, stream);
+  if (attn_mfma_ok(S, C, H, dt)) {
+    TG_CHECK(lse != nullptr, "tg_attn_bwd: the MFMA path needs the forward's log-sum-exp");
+    attn_mfma_bwd(qkv, o, dout, lse, dqkv, R, S, C, H, a.scale, a.thresh, a.inv_keep, seed, rstream, a.st);
+    TG_LAUNCH_CHECK();
+    return 0;
+  }
   int rc = dt == F32 ? dispatch<float>(a, C / H, false) : dispatch<bf16_t>(a, C / H, false);
   if (rc) return rc;
   TG_LAUNCH_CHECK();
