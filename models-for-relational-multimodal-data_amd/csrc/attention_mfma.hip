@@ -74,18 +74,29 @@ __device__ __forceinline__ am_v8bf am_load_frag(const unsigned short* base, long
 }
 
 // A [32 rows][HD columns] bf16 tile of token rows (row r = token tok0 + r, clamped to tok_last) -> wave-private LDS tile
-// (80-byte rows).  HD = 16: lane = (row = lane >> 1, 16-byte piece lane & 1); HD = 32: two rounds of (lane >> 2, lane & 3).
+// (80-byte rows), in two halves so that the NEXT tile's global loads are in flight while the current one is computed:
+// am_stage_load (registers) ... am_stage_write (LDS).  HD = 16: lane = (row = lane >> 1, 16-byte piece lane & 1);
+// HD = 32: two rounds of (lane >> 2, lane & 3).
+template <int HD> struct AmStage { uint4 v[HD / 16]; };
 template <int HD>
-__device__ __forceinline__ void am_stage_tile(const unsigned short* base, long long tok0, long long tok_last, int ld, int col,
-                                              char* tile, int lane) {
+__device__ __forceinline__ void am_stage_load(AmStage<HD>& st, const unsigned short* base, long long tok0, long long tok_last,
+                                              int ld, int col, int lane) {
   constexpr int PPR = HD / 8;                  // 16-byte pieces per row
 #pragma unroll
-  for (int rnd = 0; rnd < (32 * PPR) / 64; ++rnd) {
+  for (int rnd = 0; rnd < HD / 16; ++rnd) {
     const int idx = rnd * 64 + lane, row = idx / PPR, pc = idx % PPR;
     long long tok = tok0 + row;
     tok = tok > tok_last ? tok_last : tok;
-    const uint4 v = *reinterpret_cast<const uint4*>(base + tok * ld + col + 8 * pc);
-    *reinterpret_cast<uint4*>(tile + AM_ROWB * row + 16 * pc) = v;
+    st.v[rnd] = *reinterpret_cast<const uint4*>(base + tok * ld + col + 8 * pc);
+  }
+}
+template <int HD>
+__device__ __forceinline__ void am_stage_write(const AmStage<HD>& st, char* tile, int lane) {
+  constexpr int PPR = HD / 8;
+#pragma unroll
+  for (int rnd = 0; rnd < HD / 16; ++rnd) {
+    const int idx = rnd * 64 + lane, row = idx / PPR, pc = idx % PPR;
+    *reinterpret_cast<uint4*>(tile + AM_ROWB * row + 16 * pc) = st.v[rnd];
   }
 }
 // transposed fragments of a staged tile Z[row][col] as the A operand that goes with a PACKED ACCUMULATOR as B: the k order
@@ -114,11 +125,21 @@ __device__ __forceinline__ void am_transpose32(am_v8bf f0, am_v8bf f1, char* tw,
 
 // Dropout of one probability tile: register i <-> key kbase + (i & 3) + 8 (i >> 2) + 4h of query q (this lane).  Element
 // index e(i) = e0 + (i & 3) + 8 (i >> 2), e0 = ((row * H + head) * S + q) * S + kbase + 4h (64-bit).  Returns AND masks.
+// The RNG key depends on the high word of the index only: ka / kb = keys of hi0 and hi0 + 1, formed once per work item.
+struct AmKeys { unsigned hi0, ka, kb; };
+__device__ __forceinline__ AmKeys am_keys(unsigned long long e_first, const AmArgs& a) {
+  AmKeys k;
+  k.hi0 = (unsigned)(e_first >> 32);
+  k.ka = rng_key(a.seed, a.rstream, k.hi0);
+  k.kb = rng_key(a.seed, a.rstream, k.hi0 + 1u);
+  return k;
+}
 template <int DROP>
-__device__ __forceinline__ void am_drop_masks(unsigned long long e0, const AmArgs& a, unsigned (&m)[16]) {
+__device__ __forceinline__ void am_drop_masks(unsigned long long e0, const AmKeys& kk, const AmArgs& a, unsigned (&m)[16]) {
   if constexpr (DROP == 1) {
     const unsigned lo = (unsigned)e0;
-    const unsigned k0 = rng_key(a.seed, a.rstream, (unsigned)(e0 >> 32)), k1 = rng_key(a.seed, a.rstream, (unsigned)((e0 + 32) >> 32));
+    // (an item spans S * S <= 2^17 consecutive indices: at most one carry into the high word)
+    const unsigned k0 = (unsigned)(e0 >> 32) == kk.hi0 ? kk.ka : kk.kb, k1 = (unsigned)((e0 + 32) >> 32) == kk.hi0 ? kk.ka : kk.kb;
     const unsigned g0 = lo >> 5;
     const unsigned w0 = mix32(g0 ^ k0), w1 = mix32(((g0 + 1u) & 0x07ffffffu) ^ k1);
     const int hs = (int)__builtin_amdgcn_alignbit(w1, w0, lo & 31u);
@@ -160,13 +181,26 @@ __global__ void __launch_bounds__(256) k_attn_mfma_fwd(const AmArgs a) {
     for (int s = 0; s < NS; ++s) qf[s] = am_load_frag(a.qkv, tq, ld, hd * HD + 16 * s + 8 * h);
     float m = -INFINITY, l = 0.f;
     am_f32x16 ot = am_zero();
+    const unsigned long long e_item = ((unsigned long long)rh * S + (unsigned long long)(q_ok ? q : 0)) * (unsigned long long)S;
+    AmKeys kk{};
+    if constexpr (DROP == 1) kk = am_keys(e_item, a);
+    // software pipeline: the K fragments and the V tile of key tile kt + 1 are loaded while tile kt is computed
+    am_v8bf kf_n[NS];
+    AmStage<HD> vs_n;
+#define AM_FWD_LOAD(KT)                                                                               \
+    {                                                                                                 \
+      const int key_ = 32 * (KT) + tl;                                                                \
+      const long long tk_ = t0 + (key_ < S ? key_ : S - 1);                                           \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) kf_n[s] = am_load_frag(a.qkv, tk_, ld, C + hd * HD + 16 * s + 8 * h); \
+      am_stage_load<HD>(vs_n, a.qkv, t0 + 32 * (KT), t_last, ld, 2 * C + hd * HD, lane);             \
+    }
+    AM_FWD_LOAD(0)
     for (int kt = 0; kt < nt; ++kt) {
-      const int key = 32 * kt + tl;
-      const long long tk = t0 + (key < S ? key : S - 1);
       am_v8bf kf[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) kf[s] = am_load_frag(a.qkv, tk, ld, C + hd * HD + 16 * s + 8 * h);
-      am_stage_tile<HD>(a.qkv, t0 + 32 * kt, t_last, ld, 2 * C + hd * HD, tile, lane);
+      for (int s = 0; s < NS; ++s) kf[s] = kf_n[s];
+      am_stage_write<HD>(vs_n, tile, lane);
+      if (kt + 1 < nt) AM_FWD_LOAD(kt + 1)
       am_f32x16 st = am_zero();
 #pragma unroll
       for (int s = 0; s < NS; ++s) st = AM_MFMA(kf[s], qf[s], st);
@@ -192,9 +226,7 @@ __global__ void __launch_bounds__(256) k_attn_mfma_fwd(const AmArgs a) {
       m = mn;
       if constexpr (DROP != 0) {
         unsigned dm[16];
-        const unsigned long long e0 = ((unsigned long long)rh * S + (unsigned long long)(q_ok ? q : 0)) * (unsigned long long)S
-                                      + (unsigned long long)(32 * kt + 4 * h);
-        am_drop_masks<DROP>(e0, a, dm);
+        am_drop_masks<DROP>(e_item + (unsigned long long)(32 * kt + 4 * h), kk, a, dm);
 #pragma unroll
         for (int i = 0; i < 16; ++i) st[i] = __uint_as_float(__float_as_uint(st[i]) & dm[i]);
       }
@@ -229,7 +261,7 @@ template <int HD, int DROP>
 __device__ __forceinline__ void am_bwd_front(const am_v8bf (&kf)[HD / 16], const am_v8bf (&qf)[HD / 16],
                                              const am_v8bf (&vf)[HD / 16], const am_v8bf (&dof)[HD / 16], float lse2, float delta,
                                              float c2, float scale, float keep, int kbase, int h, int S, unsigned long long e0,
-                                             const AmArgs& a, am_f32x16& pd, am_f32x16& ds) {
+                                             const AmKeys& kk, const AmArgs& a, am_f32x16& pd, am_f32x16& ds) {
   constexpr int NS = HD / 16;
   am_f32x16 st = am_zero(), dp = am_zero();
 #pragma unroll
@@ -244,7 +276,7 @@ __device__ __forceinline__ void am_bwd_front(const am_v8bf (&kf)[HD / 16], const
   }
   if constexpr (DROP != 0) {
     unsigned dm[16];
-    am_drop_masks<DROP>(e0, a, dm);
+    am_drop_masks<DROP>(e0, kk, a, dm);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       pd[i] = __uint_as_float(__float_as_uint(st[i]) & dm[i]) * keep;
@@ -301,20 +333,31 @@ __global__ void __launch_bounds__(256) k_attn_mfma_bwd_dq(const AmArgs a) {
     const float delta = am_delta<HD>(dof, a.o, tq, C, hd * HD + 8 * h);
     const float lse2 = q_ok ? a.lse[rh * S + q] * 1.4426950408889634f : INFINITY;
     am_f32x16 dq = am_zero();
+    const unsigned long long e_item = ((unsigned long long)rh * S + (unsigned long long)(q_ok ? q : 0)) * (unsigned long long)S;
+    AmKeys kk{};
+    if constexpr (DROP == 1) kk = am_keys(e_item, a);
+    am_v8bf kf_n[NS], vf_n[NS];
+    AmStage<HD> ks_n;
+#define AM_DQ_LOAD(KT)                                                                                \
+    {                                                                                                 \
+      const int key_ = 32 * (KT) + tl;                                                                \
+      const long long tk_ = t0 + (key_ < S ? key_ : S - 1);                                           \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                \
+        kf_n[s] = am_load_frag(a.qkv, tk_, ld, C + hd * HD + 16 * s + 8 * h);                         \
+        vf_n[s] = am_load_frag(a.qkv, tk_, ld, 2 * C + hd * HD + 16 * s + 8 * h);                     \
+      }                                                                                               \
+      am_stage_load<HD>(ks_n, a.qkv, t0 + 32 * (KT), t_last, ld, C + hd * HD, lane);      /* K tile: K^T fragments */ \
+    }
+    AM_DQ_LOAD(0)
     for (int kt = 0; kt < nt; ++kt) {
-      const int key = 32 * kt + tl;
-      const long long tk = t0 + (key < S ? key : S - 1);
       am_v8bf kf[NS], vf[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        kf[s] = am_load_frag(a.qkv, tk, ld, C + hd * HD + 16 * s + 8 * h);
-        vf[s] = am_load_frag(a.qkv, tk, ld, 2 * C + hd * HD + 16 * s + 8 * h);
-      }
-      am_stage_tile<HD>(a.qkv, t0 + 32 * kt, t_last, ld, C + hd * HD, tile, lane);        // K tile: K^T fragments below
+      for (int s = 0; s < NS; ++s) { kf[s] = kf_n[s]; vf[s] = vf_n[s]; }
+      am_stage_write<HD>(ks_n, tile, lane);
+      if (kt + 1 < nt) AM_DQ_LOAD(kt + 1)
       am_f32x16 pd, ds;
-      const unsigned long long e0 = ((unsigned long long)rh * S + (unsigned long long)(q_ok ? q : 0)) * (unsigned long long)S
-                                    + (unsigned long long)(32 * kt + 4 * h);
-      am_bwd_front<HD, DROP>(kf, qf, vf, dof, lse2, delta, c2, a.scale, keep, 32 * kt, h, S, e0, a, pd, ds);
+      am_bwd_front<HD, DROP>(kf, qf, vf, dof, lse2, delta, c2, a.scale, keep, 32 * kt, h, S,
+                             e_item + (unsigned long long)(32 * kt + 4 * h), kk, a, pd, ds);
       dq = AM_MFMA(am_tr_frag(trb, 0), am_pack<0>(ds), dq);         // dQ^T[d, q] += K^T[d, key] dS^T[key, q]
       dq = AM_MFMA(am_tr_frag(trb, 1), am_pack<1>(ds), dq);
     }
@@ -365,24 +408,46 @@ __global__ void __launch_bounds__(256) k_attn_mfma_bwd_dkv(const AmArgs a) {
       vf[s] = am_load_frag(a.qkv, tk, ld, 2 * C + hd * HD + 16 * s + 8 * h);
     }
     am_f32x16 dk = am_zero(), dv = am_zero();
+    AmKeys kk{};
+    if constexpr (DROP == 1) kk = am_keys((unsigned long long)rh * S * (unsigned long long)S, a);
+    // software pipeline over the query tiles: fragments, tiles, O (for delta) and the log-sum-exp of tile qt + 1 in flight
+    am_v8bf qf_n[NS], dof_n[NS], of_n[NS];
+    AmStage<HD> qs_n, dos_n;
+    float lse_n;
+#define AM_DKV_LOAD(QT)                                                                               \
+    {                                                                                                 \
+      const int q_ = 32 * (QT) + tl;                                                                  \
+      const long long tq_ = t0 + (q_ < S ? q_ : S - 1);                                               \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                \
+        qf_n[s] = am_load_frag(a.qkv, tq_, ld, hd * HD + 16 * s + 8 * h);                             \
+        dof_n[s] = am_load_frag(a.dout, tq_, C, hd * HD + 16 * s + 8 * h);                            \
+        of_n[s] = am_load_frag(a.o, tq_, C, hd * HD + 16 * s + 8 * h);                                \
+      }                                                                                               \
+      am_stage_load<HD>(qs_n, a.qkv, t0 + 32 * (QT), t_last, ld, hd * HD, lane);          /* Q tile -> Q^T fragments */ \
+      am_stage_load<HD>(dos_n, a.dout, t0 + 32 * (QT), t_last, C, hd * HD, lane);         /* dO tile -> dO^T fragments */ \
+      lse_n = q_ < S ? a.lse[rh * S + q_] * 1.4426950408889634f : INFINITY;                           \
+    }
+    AM_DKV_LOAD(0)
     for (int qt = 0; qt < nt; ++qt) {
       const int q = 32 * qt + tl;
       const bool q_ok = q < S;
-      const long long tq = t0 + (q_ok ? q : S - 1);
       am_v8bf qf[NS], dof[NS];
+      float delta = 0.f;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        qf[s] = am_load_frag(a.qkv, tq, ld, hd * HD + 16 * s + 8 * h);
-        dof[s] = am_load_frag(a.dout, tq, C, hd * HD + 16 * s + 8 * h);
+        qf[s] = qf_n[s]; dof[s] = dof_n[s];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += (float)dof_n[s][j] * (float)of_n[s][j];
       }
-      am_stage_tile<HD>(a.qkv, t0 + 32 * qt, t_last, ld, hd * HD, tq_tile, lane);           // Q tile -> Q^T fragments
-      am_stage_tile<HD>(a.dout, t0 + 32 * qt, t_last, C, hd * HD, tdo_tile, lane);          // dO tile -> dO^T fragments
-      const float delta = am_delta<HD>(dof, a.o, tq, C, hd * HD + 8 * h);
-      const float lse2 = q_ok ? a.lse[rh * S + q] * 1.4426950408889634f : INFINITY;
+      delta += am_xor32(delta);
+      const float lse2 = lse_n;
+      am_stage_write<HD>(qs_n, tq_tile, lane);
+      am_stage_write<HD>(dos_n, tdo_tile, lane);
+      if (qt + 1 < nt) AM_DKV_LOAD(qt + 1)
       am_f32x16 pd, ds;
       const unsigned long long e0 = ((unsigned long long)rh * S + (unsigned long long)(q_ok ? q : 0)) * (unsigned long long)S
                                     + (unsigned long long)(32 * kt + 4 * h);
-      am_bwd_front<HD, DROP>(kf, qf, vf, dof, lse2, delta, c2, a.scale, keep, 32 * kt, h, S, e0, a, pd, ds);
+      am_bwd_front<HD, DROP>(kf, qf, vf, dof, lse2, delta, c2, a.scale, keep, 32 * kt, h, S, e0, kk, a, pd, ds);
       am_v8bf p0, p1, s0, s1;
       am_transpose32(am_pack<0>(pd), am_pack<1>(pd), tw, ttr, p0, p1);          // Pd [k = q][col = key]
       am_transpose32(am_pack<0>(ds), am_pack<1>(ds), tw, ttr, s0, s1);          // dS [k = q][col = key]
