@@ -1602,7 +1602,7 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  const long long slots = (long long)n_cu * (EF_DBUF ? 1 : 2);
+  const long long slots = (long long)n_cu * (EF_WAVES >= 8 ? 1 : 2);
   const unsigned grid = (unsigned)(n_it < slots ? n_it : slots);
   const size_t lds = 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
   // DROP template value: 0 = no dropout, else the hash bits per element the threshold allows (common.hpp)
@@ -1653,7 +1653,7 @@ static unsigned ef_grid(long long R, int S) {
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  const long long slots = (long long)n_cu * (EF_DBUF ? 1 : 2);
+  const long long slots = (long long)n_cu * (EF_WAVES >= 8 ? 1 : 2);
   return (unsigned)(n_it < slots ? n_it : slots);
 }
 
