@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed oracle steps per thread count (median reported)")
     ap.add_argument("--no-extras", action="store_true", help="skip every extra object (reference_batch, eval, "
                     "other_workloads, roofline_gemm, cpu_baseline, end_to_end): the bare contract line, for profiling")
-    ap.add_argument("--workload", default="aml-fused", choices=["aml-fused", "tabgnn-arxiv", "wide64-c256"],
+    ap.add_argument("--workload", default="aml-fused", choices=["aml-fused", "tabgnn-arxiv", "wide64-c256", "reference-batch-graph"],
                     help="aml-fused = the headline (BASELINE configs[1]); the other two run ONE extra leg alone "
                          "(configs[3] / configs[4] shapes) and print its object — for profiling, never the headline")
     ap.add_argument("--reverse-mp", action="store_true", help="PNAConvHetero (forward + reverse message passing); "
@@ -262,27 +262,77 @@ def reference_batch(args, cdt, dev):
     if args.index == "sampler":      # as in the timed region: the batch carries the sampler-built CSRs
         from tabgnn_amd.sampler import batch_index
         batches = [(b[0], batch_index(b[1].cpu(), b[0].num_rows, B, dev), b[2], b[3]) for b in batches]
-    step = T.GraphedTrainStep(model, flat, opt, lw) if getattr(T, "GraphedTrainStep", None) and os.environ.get("TABGNN_GRAPH") == "1" else None
 
-    def one(i):
-        if step is not None:
-            step(batches[i % 4])
-        else:
-            T.train_step(model, flat, opt, batches[i % 4], lw)
+    def timed(one, n=50):
+        for i in range(10):
+            one(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            one(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    dt_eager = timed(lambda i: T.train_step(model, flat, opt, batches[i % 4], lw))
+    E = sum(b[1].shape[1] for b in batches) / 4
+    launches = count_launches(lambda: T.train_step(model, flat, opt, batches[0], lw))
+    out = dict(batch_size=B, edges_per_step=int(E), ms_per_step=1e3 * dt_eager, value=E / dt_eager, unit="edges/s",
+               launches_per_step=launches, steps=50, mode="eager",
+               note="reference default --batch_size 200 (utils.py:40-44); launch-bound regime")
+    if os.environ.get("TABGNN_NO_GRAPH") == "1":
+        return out
+    # The same step as one HIP graph per shape bucket, measured in a CHILD process (a fault inside a replay would
+    # take this process, and with it the bench line, down): `python bench.py --workload reference-batch-graph`.
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "reference-batch-graph", "--dtype", args.dtype,
+           "--hidden", str(args.hidden), "--layers", str(args.layers), "--nhead", str(args.nhead)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        g = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
+    except Exception as e:      # noqa: BLE001 - reported, never fatal for the bench line
+        r, g = None, None
+        out["graph_error"] = repr(e)[:200]
+    if g is None:
+        out.setdefault("graph_error", (r.stderr[-300:] if r is not None else "") or "child failed")
+        return out
+    out.update(eager_ms_per_step=out["ms_per_step"], eager_value=out["value"])
+    out.update(g)
+    return out
+
+
+def reference_batch_graph(args, cdt, dev):
+    """Child leg of ``reference_batch``: batches padded to their bucket on the host next to the sampler
+    (``graph_step.prepare``), uploaded ahead of the step, copied into the bucket's static buffers, replayed.
+    Edges/s counts the REAL edges of the batches, not the padding."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    from tabgnn_amd import graph_step as G
+    B = 200
+    torch.manual_seed(1234)
+    cfg = S.make_config(args.hidden, args.layers, args.nhead, B, compute_dtype=cdt)
+    model = T.TABGNNFusedS(cfg).to(dev).train()
+    flat = T.FlatParams(model, shadow_dtype=cdt)
+    opt = T.FusedAdam(flat, lr=cfg["lr"])
+    lw = torch.tensor(cfg["loss_weights"], device=dev)
+    plain = [S.make_batch(B, seed=77 + i, device=dev) for i in range(4)]
+    preps = [G.prepare(b, B).to(dev) for b in plain]
+    step = G.GraphedTrainStep(model, flat, opt, lw, B)
+    frames = (plain[0][0], plain[0][2])
     for i in range(10):
-        one(i)
+        step(preps[i % 4], frames)
     torch.cuda.synchronize()
-    n = 50
+    n = 100
     t0 = time.perf_counter()
     for i in range(n):
-        one(i)
+        loss, _ = step(preps[i % 4], frames)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    E = sum(b[1].shape[1] for b in batches) / 4
-    launches = count_launches(lambda: one(0))
-    return dict(batch_size=B, edges_per_step=int(E), ms_per_step=1e3 * dt, value=E / dt, unit="edges/s",
-                launches_per_step=launches, steps=n, mode="hip-graph replay" if step is not None else "eager",
-                note="reference default --batch_size 200 (utils.py:40-44); launch-bound regime")
+    E = sum(p.e_real for p in preps) / 4
+    return dict(mode="hip-graph replay over shape buckets", ms_per_step=1e3 * dt, value=E / dt, steps=n,
+                buckets=len(step.buckets), padded_edges_per_step=int(sum(p.key[0] for p in preps) / 4),
+                final_loss=float(loss),
+                graph_note="one captured graph per (E_pad, N_pad) bucket; dropout seed, Adam step count and the "
+                           "BatchNorm row count are read from device memory by the kernels")
 
 
 def eval_throughput(model, batches, dev, steps=10):
@@ -529,6 +579,9 @@ def main():
     _lib.call("tg_device_check")
 
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.workload == "reference-batch-graph":
+        print(json.dumps(reference_batch_graph(args, cdt, dev)))
+        return
     if args.workload != "aml-fused":          # one extra leg alone (profiling aid): prints that leg's object
         leg = leg_tabgnn_arxiv if args.workload == "tabgnn-arxiv" else leg_wide64
         print(json.dumps(leg(cdt, dev, steps=args.steps, warmup=args.warmup)))

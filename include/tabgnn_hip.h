@@ -18,7 +18,7 @@
 #define TABGNN_HIP_H_
 #include <stdint.h>
 
-#define TABGNN_HIP_ABI_VERSION 4
+#define TABGNN_HIP_ABI_VERSION 5
 
 #ifdef __cplusplus
 extern "C" {
@@ -330,6 +330,26 @@ int tg_weighted_ce_bwd(const void* logits, const int64_t* y, const float* w, con
 int tg_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float lr, float beta1, float beta2,
                  float eps, int32_t t, float grad_scale, int32_t zero_grad, void* stream);
 int tg_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---- device-resident step state: what lets one captured HIP graph serve every step of a shape bucket --------------
+ * (the reference's loop, main.py:41-75, re-launches ~1 300 framework kernels per step; at its default --batch_size 200
+ * the step is bound by that launch work, not by the GPU)
+ * `state` = 4 x uint64 in device memory: [0] dropout seed word, [1] optimiser step count t, [2] two floats
+ * (lr/(1-beta1^t), 1/sqrt(1-beta2^t)), [3] reserved.  tg_advance_step: one single-thread kernel moves the record to
+ * the next step (seed <- LCG(seed), t += 1, Adam's bias corrections for the new t), then every translation unit that
+ * draws dropout masks takes the seed word (it is XOR-ed into the `seed` argument of every kernel).
+ * tg_seed_source_sync(NULL) returns to host seeds alone. */
+int tg_advance_step(uint64_t* state, float lr, float beta1, float beta2, void* stream);
+int tg_seed_source_sync(const uint64_t* state, void* stream);
+/* tg_adam_step with the step-dependent scalars read from `state` (written by tg_advance_step in the same stream) */
+int tg_adam_step_dev(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float beta1, float beta2,
+                     float eps, const uint64_t* state, float grad_scale, int32_t zero_grad, void* stream);
+/* stream-ordered zero fill by a kernel (bytes % 4 == 0): the package never records a library memset node */
+int tg_zero(void* p, int64_t bytes, void* stream);
+/* padded batches: BatchNorm (tg_bn_act_res_fwd/bwd, training, unsynchronised) takes its statistics over the first
+ * *limit_dev rows only and gives the padding rows a zero input gradient; NULL (default) = every row counts.
+ * The pointer is read by the kernels at run time: one captured graph serves batches of different true size. */
+int tg_set_bn_row_limit(const int32_t* limit_dev);
 /* one launch: transposed bf16 copies of all 2-D parameters (table int64 [n][3] = element offset, rows, cols inside
  * src/dst) — the input-gradient GEMMs read W^T as their row-major weight */
 int tg_transpose_batched_bf16(const void* src, void* dst, const int64_t* table, int32_t n, void* stream);

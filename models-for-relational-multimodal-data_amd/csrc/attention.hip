@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(256) k_attn_fwd(const T* __restrict__ qkv, T* 
                                                    float* __restrict__ lse, long long R, int S, int H, float scale,
                                                    unsigned thresh, float inv_keep, unsigned long long seed,
                                                    unsigned rstream) {
+  seed = live_seed(seed);
   const int C = H * D;
   long long total = R * H * S;
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd(const T* __restrict__ qkv, con
                                                    T* __restrict__ dqkv, long long R, int S, int H, float scale,
                                                    unsigned thresh, float inv_keep, unsigned long long seed,
                                                    unsigned rstream) {
+  seed = live_seed(seed);
   const int C = H * D;
   long long total = R * H * S;
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -188,6 +190,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_split(const T* __restrict__ qk
                                                          T* __restrict__ dqkv, long long R, int S, int H, float scale,
                                                          unsigned thresh, float inv_keep, unsigned long long seed,
                                                          unsigned rstream) {
+  seed = live_seed(seed);
   constexpr int LPD = D / DL;
   static_assert(D % DL == 0 && (LPD & (LPD - 1)) == 0 && LPD <= 16, "head dim must be DL * power of two");
   const int C = H * D;
@@ -370,3 +373,5 @@ extern "C" int tg_attn_bwd(const void* qkv, const void* o, const void* dout, con
   TG_LAUNCH_CHECK();
   return 0;
 }
+
+TG_DROPOUT_TU(attention)

@@ -156,7 +156,9 @@ __device__ __forceinline__ void am_drop_masks(unsigned long long e0, const AmKey
 
 // ---------------------------------------------------------------------------------------------- forward
 template <int HD, int DROP>
-__global__ void __launch_bounds__(256) k_attn_mfma_fwd(const AmArgs a) {
+__global__ void __launch_bounds__(256) k_attn_mfma_fwd(const AmArgs a_) {
+  AmArgs a = a_;
+  a.seed = live_seed(a_.seed);
   __shared__ __attribute__((aligned(16))) char smem[4 * AM_TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 31, h = lane >> 5;
   char* tile = smem + wave * AM_TILE;
@@ -304,7 +306,9 @@ __device__ __forceinline__ float am_delta(const am_v8bf (&dof)[HD / 16], const u
 
 // ---------------------------------------------------------------------------------------------- backward: dQ
 template <int HD, int DROP>
-__global__ void __launch_bounds__(256) k_attn_mfma_bwd_dq(const AmArgs a) {
+__global__ void __launch_bounds__(256) k_attn_mfma_bwd_dq(const AmArgs a_) {
+  AmArgs a = a_;
+  a.seed = live_seed(a_.seed);
   __shared__ __attribute__((aligned(16))) char smem[4 * AM_TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 31, h = lane >> 5;
   char* tile = smem + wave * AM_TILE;
@@ -378,7 +382,9 @@ __global__ void __launch_bounds__(256) k_attn_mfma_bwd_dq(const AmArgs a) {
 
 // ---------------------------------------------------------------------------------------------- backward: dK, dV
 template <int HD, int DROP>
-__global__ void __launch_bounds__(256) k_attn_mfma_bwd_dkv(const AmArgs a) {
+__global__ void __launch_bounds__(256) k_attn_mfma_bwd_dkv(const AmArgs a_) {
+  AmArgs a = a_;
+  a.seed = live_seed(a_.seed);
   __shared__ __attribute__((aligned(16))) char smem[4 * 3 * AM_TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 31, h = lane >> 5;
   char* tq_tile = smem + wave * 3 * AM_TILE;           // Q tile (row-major), dO tile, transpose tile
@@ -515,3 +521,5 @@ void attn_mfma_bwd(const void* qkv, const void* o, const void* dout, const float
 }
 
 }  // namespace tg
+
+TG_DROPOUT_TU(attention_mfma)

@@ -123,6 +123,13 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 __device__ __forceinline__ unsigned rng_key(unsigned long long seed, unsigned stream, unsigned hi) {
   return mix32((unsigned)seed ^ (stream * 0x9E3779B9U) ^ mix32(hi + (unsigned)(seed >> 32) + 0x85ebca6bU));
 }
+// Device-resident seed word (tg_seed_source_sync / tg_advance_step): every kernel that draws a dropout mask XORs its
+// seed argument with it ONCE at its top (live_seed).  A captured HIP graph bakes the host-side seed argument into its
+// kernel nodes; this word is read at run time, so a replay draws the masks of its own step.  Zero (the start value)
+// leaves the host seed as it is.  One copy per translation unit (no relocatable device code): TG_DROPOUT_TU(name)
+// registers the unit's setter kernel, and tg_seed_source_sync launches every registered setter.
+static __device__ unsigned long long g_seed_xor = 0ull;
+__device__ __forceinline__ unsigned long long live_seed(unsigned long long seed) { return seed ^ g_seed_xor; }
 __device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned stream, unsigned long long idx) {
   return mix32((unsigned)idx ^ rng_key(seed, stream, (unsigned)(idx >> 32)));
 }
@@ -247,5 +254,20 @@ inline int grid_full(long long blocks, int old_cap = 256 * 8) {
   if (off_) return grid_cap(blocks, old_cap);
   return (int)(blocks < 1 ? 1 : (blocks > 2147483647LL ? 2147483647LL : blocks));
 }
+
+// ---------------------------------------------------------------- per-unit seed-word setters (see g_seed_xor)
+typedef void (*seed_setter_fn)(const unsigned long long* src, hipStream_t st);
+void seed_tu_register(seed_setter_fn fn);          // train_ops.hip
+#define TG_DROPOUT_TU(NAME)                                                                                   \
+  namespace tg { namespace {                                                                                  \
+  __global__ void k_seed_xor_set_##NAME(const unsigned long long* __restrict__ src) {                         \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_seed_xor = src ? src[0] : 0ull;                                \
+  }                                                                                                           \
+  void seed_xor_launch_##NAME(const unsigned long long* src, hipStream_t st) {                                \
+    hipLaunchKernelGGL(k_seed_xor_set_##NAME, dim3(1), dim3(64), 0, st, src);                                 \
+  }                                                                                                           \
+  struct SeedTu_##NAME { SeedTu_##NAME() { seed_tu_register(&seed_xor_launch_##NAME); } };                    \
+  SeedTu_##NAME seed_tu_instance_##NAME;                                                                      \
+  } }
 
 }  // namespace tg

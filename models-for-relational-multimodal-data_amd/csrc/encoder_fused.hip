@@ -392,7 +392,9 @@ struct EfArgs {
   }
 #define EF_UNIT_NEXT(U, VALID, U2, BYTES) EF_UNIT_NEXT_K(U, VALID, U2, BYTES, EF_WAIT_VM(0))
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
-__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a) {
+__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a_) {
+  EfArgs a = a_;
+  a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* prm = reinterpret_cast<float*>(smem + 2 * EF_UNIT_BYTES);                         // 6 KiB
   char* stg_all = smem + 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4;                              // EF_WAVES x 8 KiB
@@ -910,7 +912,9 @@ __device__ __forceinline__ void ef_ln_partials(const float (&q)[8], float* red /
 }
 
 template <int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
-__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs a) {
+__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs a_) {
+  EbArgs a = a_;
+  a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* prm = reinterpret_cast<float*>(smem + 2 * EF_UNIT_BYTES);
   char* stg_all = smem + 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4;
@@ -1166,7 +1170,9 @@ __device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* b
 }
 
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
-__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs a) {
+__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs a_) {
+  EaArgs a = a_;
+  a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* prm = reinterpret_cast<float*>(smem + 2 * EF_UNIT_BYTES);
   char* stg_all = smem + 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4;
@@ -1757,3 +1763,5 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
   TG_LAUNCH_CHECK();
   return 0;
 }
+
+TG_DROPOUT_TU(encoder_fused)

@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
                                                            int flags, unsigned thresh, float inv_keep,
                                                            unsigned long long seed, unsigned rstream,
                                                            const float* __restrict__ scales, int kreal, NtGather gth) {
+  seed = live_seed(seed);
   __shared__ __attribute__((aligned(16))) char lds[2 * NT_TILE_BYTES];   // [X image | W image] = 64 KiB
   __shared__ int gidx[GATHER ? 3 * NT_BM : 1];
   char* xs = lds;
@@ -339,6 +340,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_ln_bf16(const unsigned short
                                                               float* __restrict__ stats, long long R, int K,
                                                               long long ldx, float eps, unsigned thresh, float inv_keep,
                                                               unsigned long long seed, unsigned rstream) {
+  seed = live_seed(seed);
   __shared__ __attribute__((aligned(16))) char lds[2 * NT_TILE_BYTES];
   char* xs = lds;
   char* ws = lds + NT_TILE_BYTES;
@@ -583,3 +585,5 @@ extern "C" int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bia
   TG_LAUNCH_CHECK();
   return 0;
 }
+
+TG_DROPOUT_TU(gemm_nt)

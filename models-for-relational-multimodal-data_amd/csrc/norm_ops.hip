@@ -20,6 +20,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_fwd(const T* __restrict__ a, co
                                                       T* __restrict__ out, float* __restrict__ stats, long long M, int C,
                                                       int lpr, float eps, float alpha, float beta_c, unsigned thresh,
                                                       float inv_keep, unsigned long long seed, unsigned rstream) {
+  seed = live_seed(seed);
   const int groups = LN_BLOCK / lpr;
   const int gl = threadIdx.x % lpr;
   long long row = (long long)blockIdx.x * groups + threadIdx.x / lpr;
@@ -109,6 +110,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_bwd(const T* __restrict__ a, co
                                                       float* __restrict__ partials, long long M, int C, int lpr,
                                                       float alpha, float beta_c, unsigned thresh, float inv_keep,
                                                       unsigned long long seed, unsigned rstream, int accum_da) {
+  seed = live_seed(seed);
   extern __shared__ float red[];  // [groups][3][C]
   const int groups = LN_BLOCK / lpr;
   const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
@@ -297,12 +299,14 @@ __global__ void __launch_bounds__(1024) k_reduce_partials_acc3(const float* __re
 }
 
 // ------------------------------------------------------------------ BatchNorm (+ReLU, + residual average)
+extern const int* g_bn_row_limit;       // train_ops.hip:tg_set_bn_row_limit (device-side row count of a padded batch)
 // column statistics: each lane owns VEC channels, rows strided over lane groups and blocks
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_col_stats(const T* __restrict__ x, const T* __restrict__ y2,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                     const T* __restrict__ gate, float* __restrict__ partials,
-                                                    long long N, int F, int mode) {
+                                                    long long N, int F, int mode, const int* __restrict__ nlim) {
+  if (nlim) N = min(N, (long long)nlim[0]);       // padded batch: rows past the device-side limit are not part of the batch
   // mode 0: partial (sum x, sum x^2).   mode 1 (backward): with dz = x (upstream, already scaled) gated by
   // gate>0 (if gate), xhat = (y2-mean)*rstd: partial (sum dz, sum dz*xhat)
   extern __shared__ float red[];  // [groups][2][F]
@@ -345,9 +349,11 @@ __global__ void __launch_bounds__(256) k_col_stats(const T* __restrict__ x, cons
 
 __global__ void k_bn_finalize(const float* __restrict__ partials, int nblk, long long N, int F, float eps,
                               float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                              float* __restrict__ running_mean, float* __restrict__ running_var) {
+                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                              const int* __restrict__ nlim) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= F) return;
+  if (nlim) N = min(N, (long long)nlim[0]);
   float s1 = partials[c], s2 = partials[F + c];   // already reduced over blocks (k_reduce_partials)
   float mu = s1 / (float)N;
   float var = fmaxf(s2 / (float)N - mu * mu, 0.f);
@@ -415,7 +421,9 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ do
                                const float* __restrict__ rstd, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ sums /*[2][F]*/,
                                T* __restrict__ dx, T* __restrict__ dres, long long N, long long n_stat, int F, int relu,
-                               int training, float alpha, float beta_c) {
+                               int training, float alpha, float beta_c, const int* __restrict__ nlim) {
+  long long n_real = N;                           // rows past it (padding) get dx = 0: they never were in the statistics
+  if (nlim) { n_real = min(N, (long long)nlim[0]); n_stat = min(n_stat, n_real); }
   const int vpr = F / VEC;
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long stride = (long long)gridDim.x * blockDim.x;
@@ -441,7 +449,7 @@ __global__ void k_bn_bwd_apply(const T* __restrict__ x, const T* __restrict__ do
       float y = xh * gm[j] + bt[j];
       float dz = (relu && !(y > 0.f)) ? 0.f : beta_c * g[j];
       float t = dz - m1[j] - xh * m2[j];
-      o[j] = gm[j] * rs[j] * t;
+      o[j] = r < n_real ? gm[j] * rs[j] * t : 0.f;
     }
     storev<T, VEC>(dx + r * F + c, o);
     if (dres) {
@@ -458,7 +466,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_stats(const T* __restrict__ x, c
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ partials, long long N, int F, int relu,
-                                                       float beta_c) {
+                                                       float beta_c, const int* __restrict__ nlim) {
+  if (nlim) N = min(N, (long long)nlim[0]);
   extern __shared__ float red[];
   const int lpr = F / VEC, groups = 256 / lpr;
   const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
@@ -496,6 +505,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_stats(const T* __restrict__ x, c
 template <typename T, int VEC>
 __global__ void k_act_dropout_fwd(const T* __restrict__ x, T* __restrict__ y, long long n, int act, unsigned thresh,
                                   float inv_keep, unsigned long long seed, unsigned rstream) {
+  seed = live_seed(seed);
   long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * VEC;
   long long stride = (long long)gridDim.x * blockDim.x * VEC;
   for (; i < n; i += stride) {
@@ -525,6 +535,7 @@ __global__ void k_act_dropout_fwd(const T* __restrict__ x, T* __restrict__ y, lo
 template <typename T, int VEC>
 __global__ void k_act_dropout_bwd(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, long long n,
                                   int act, unsigned thresh, float inv_keep, unsigned long long seed, unsigned rstream) {
+  seed = live_seed(seed);
   long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * VEC;
   long long stride = (long long)gridDim.x * blockDim.x * VEC;
   for (; i < n; i += stride) {
@@ -607,6 +618,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_ln_tail_ln_bwd(const T* __restrict
                                                               float* __restrict__ partials, long long M, int C, int lpr,
                                                               float alpha, float beta_c, unsigned thresh, float inv_keep,
                                                               unsigned long long seed, unsigned rstream) {
+  seed = live_seed(seed);
   extern __shared__ float red[];  // [groups][5][C]
   const int groups = LN_BLOCK / lpr;
   const int gl = threadIdx.x % lpr, gi = threadIdx.x / lpr;
@@ -905,6 +917,7 @@ extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* ga
   TG_CHECK(phase >= 0 && phase <= 2 && (phase == 0 || training), "tg_bn_act_res_fwd: bad phase %d", phase);
   hipStream_t st = (hipStream_t)stream;
   if (n_stat <= 0 || phase == 0) n_stat = N;
+  const int* nlim = phase == 0 && training ? g_bn_row_limit : nullptr;   // (not combined with the synchronised phases)
   DISPATCH_T(dt, {
     TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_fwd: F/VEC must divide 256 (F=%d)", F);
     float* sums = partials + (size_t)512 * 2 * F;      // (sum x, sum x^2): the vector a synchronised BN all-reduces
@@ -914,7 +927,7 @@ extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* ga
         int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
         size_t shm = (size_t)groups * 2 * F * sizeof(float);
         hipLaunchKernelGGL((k_col_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, partials, (long long)N, F, 0);
+                           (const float*)nullptr, (const float*)nullptr, (const T*)nullptr, partials, (long long)N, F, 0, nlim);
         hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, sums);
       }
       if (phase == 1) {
@@ -922,7 +935,7 @@ extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* ga
         return 0;
       }
       hipLaunchKernelGGL(k_bn_finalize, dim3(ceil_div(F, 256)), dim3(256), 0, st, sums, 1, (long long)n_stat, F, eps,
-                         momentum, mean, rstd, running_mean, running_var);
+                         momentum, mean, rstd, running_mean, running_var, nlim);
     } else {
       hipLaunchKernelGGL(k_bn_eval_stats, dim3(ceil_div(F, 256)), dim3(256), 0, st, running_mean, running_var, F, eps,
                          mean, rstd);
@@ -944,6 +957,7 @@ extern "C" int tg_bn_act_res_bwd(const void* x, const void* dout, const float* g
   TG_CHECK(phase >= 0 && phase <= 2, "tg_bn_act_res_bwd: bad phase %d", phase);
   hipStream_t st = (hipStream_t)stream;
   if (n_stat <= 0 || phase == 0) n_stat = N;
+  const int* nlim = phase == 0 && training ? g_bn_row_limit : nullptr;
   DISPATCH_T(dt, {
     TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_bwd: F/VEC must divide 256 (F=%d)", F);
     if (phase != 2) {
@@ -951,14 +965,14 @@ extern "C" int tg_bn_act_res_bwd(const void* x, const void* dout, const float* g
       int grid = grid_cap(ceil_div(N, (long long)groups * 4), 512);
       size_t shm = (size_t)groups * 2 * F * sizeof(float);
       hipLaunchKernelGGL((k_bn_bwd_stats<T, VEC>), dim3(grid), dim3(256), shm, st, (const T*)x, (const T*)dout, mean,
-                         rstd, gamma, beta, partials, (long long)N, F, relu, beta_c);
+                         rstd, gamma, beta, partials, (long long)N, F, relu, beta_c, nlim);
       hipLaunchKernelGGL(k_reduce_partials, dim3(ceil_div(2 * F, 64)), dim3(1024), 0, st, partials, grid, 2 * F, dparams);
     }
     if (phase != 1) {    // the statistics terms divide by the number of rows behind dparams (all ranks when synchronised)
       long long total = (long long)N * (F / VEC);
       hipLaunchKernelGGL((k_bn_bwd_apply<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, st, (const T*)x,
                          (const T*)dout, mean, rstd, gamma, beta, dparams, (T*)dx, (T*)dres, (long long)N,
-                         (long long)n_stat, F, relu, training, alpha, beta_c);
+                         (long long)n_stat, F, relu, training, alpha, beta_c, nlim);
     }
   })
   TG_LAUNCH_CHECK();
@@ -1017,3 +1031,5 @@ extern "C" int tg_cls_merge_fwd(const void* xtab, const void* xf, void* out, int
   TG_LAUNCH_CHECK();
   return 0;
 }
+
+TG_DROPOUT_TU(norm_ops)

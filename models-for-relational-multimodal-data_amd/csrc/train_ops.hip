@@ -67,7 +67,9 @@ __global__ void k_ce_bwd(const T* __restrict__ logits, const long long* __restri
 
 __global__ void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                        unsigned short* __restrict__ p_bf16, long long n, float step_size, float beta1, float beta2,
-                       float inv_sqrt_bc2, float eps, float grad_scale, int zero_grad) {
+                       float inv_sqrt_bc2, float eps, float grad_scale, int zero_grad,
+                       const float* __restrict__ coef) {
+  if (coef) { step_size = coef[0]; inv_sqrt_bc2 = coef[1]; }      // device-resident step state (tg_advance_step)
   long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;
   long long stride = (long long)gridDim.x * blockDim.x * 4;
   for (; i < n; i += stride) {
@@ -155,8 +157,77 @@ extern "C" int tg_adam_step(float* p, float* g, float* m, float* v, void* p_bf16
   double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
   hipLaunchKernelGGL(k_adam, dim3(grid_cap(ceil_div(n, 1024))), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                      (unsigned short*)p_bf16, (long long)n, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)),
-                     eps, grad_scale, zero_grad);
+                     eps, grad_scale, zero_grad, (const float*)nullptr);
   TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------- device-resident step state (HIP-graph replay)
+// A captured graph bakes every host-side scalar into its kernel nodes.  The three scalars of the train step that
+// change from step to step therefore live in a 32-byte device record `state`:
+//   word 0 (u64)  dropout seed word (XOR-ed into every kernel's seed argument: common.hpp:g_seed_xor)
+//   word 1 (i64)  optimiser step count t
+//   word 2        two floats: lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)   (Adam's bias corrections for this t)
+//   word 3        reserved
+// tg_advance_step (one single-thread kernel, first node of the graph) moves the record to the next step and copies the
+// seed word into every translation unit that draws masks; tg_adam_step_dev reads the corrections from it.
+namespace tg {
+__global__ void k_step_advance(unsigned long long* __restrict__ state, float lr, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  state[0] = state[0] * 6364136223846793005ULL + 1442695040888963407ULL;
+  const long long t = (long long)state[1] + 1;
+  state[1] = (unsigned long long)t;
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  float* c = reinterpret_cast<float*>(state + 2);
+  c[0] = (float)((double)lr / bc1);
+  c[1] = (float)(1.0 / sqrt(bc2));
+}
+static seed_setter_fn g_seed_setters[32];
+static int g_n_seed_setters = 0;
+void seed_tu_register(seed_setter_fn fn) {
+  if (g_n_seed_setters < 32) g_seed_setters[g_n_seed_setters++] = fn;
+}
+}  // namespace tg
+
+// every mask-drawing translation unit takes its seed word from state[0] (NULL: back to zero = host seeds alone)
+extern "C" int tg_seed_source_sync(const uint64_t* state, void* stream) {
+  for (int i = 0; i < tg::g_n_seed_setters; ++i) tg::g_seed_setters[i]((const unsigned long long*)state, (hipStream_t)stream);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_advance_step(uint64_t* state, float lr, float beta1, float beta2, void* stream) {
+  TG_CHECK(state != nullptr, "tg_advance_step: %s", "state is NULL");
+  hipLaunchKernelGGL(tg::k_step_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)state, lr, beta1,
+                     beta2);
+  return tg_seed_source_sync(state, stream);
+}
+
+extern "C" int tg_adam_step_dev(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float beta1,
+                                float beta2, float eps, const uint64_t* state, float grad_scale, int32_t zero_grad,
+                                void* stream) {
+  TG_CHECK(n >= 0 && state != nullptr, "tg_adam_step_dev: bad n=%lld or NULL state", (long long)n);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_adam, dim3(grid_cap(ceil_div(n, 1024))), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (unsigned short*)p_bf16, (long long)n, 0.f, beta1, beta2, 1.f, eps, grad_scale, zero_grad,
+                     reinterpret_cast<const float*>(state + 2));
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Stream-ordered zero fill by a kernel (never a memset node: see common.hpp:zero_async)
+extern "C" int tg_zero(void* p, int64_t bytes, void* stream) {
+  TG_CHECK(bytes >= 0 && bytes % 4 == 0, "tg_zero: bytes=%lld must be a multiple of 4", (long long)bytes);
+  if (bytes) tg::zero_async(p, (size_t)bytes, (hipStream_t)stream);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Device-side row limit of the BatchNorm statistics (norm_ops.hip): rows >= *limit of a padded batch are left out of
+// the batch statistics and get a zero input gradient.  NULL (the default) = every row counts.
+namespace tg { const int* g_bn_row_limit = nullptr; }
+extern "C" int tg_set_bn_row_limit(const int32_t* limit_dev) {
+  tg::g_bn_row_limit = (const int*)limit_dev;
   return 0;
 }
 

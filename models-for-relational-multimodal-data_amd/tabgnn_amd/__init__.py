@@ -17,4 +17,5 @@ from .layers import BatchNorm, ColumnTransformerLayer, GINEConv, GINEConvHetero,
 from .models import (CPNA, PNAS, TABGNN, GINe, FTTransformerLayer, FTTransformerPNAFusedLayer,  # noqa: E402
                      FTTransformerPNAInterleavedLayer, PNALayer, TABGNNFused, TABGNNInterleaved)
 from .train import DataParallel, FlatParams, FusedAdam, IndexGuard, train_step  # noqa: E402
+from .graph_step import GraphedTrainStep, StepState, bucket_size, prepare as prepare_batch  # noqa: E402
 from .wrappers import GNN, TABGNNFusedS, TABGNNS, degree_histogram  # noqa: E402

@@ -1,0 +1,248 @@
+"""HIP-graph replay of the supervised train step over shape buckets (the launch-bound regime).
+
+At the reference's default ``--batch_size 200`` (``utils.py:40-44``) one step of ``main.py:41-75`` is ~330 kernel launches
+here for well under 2 ms of GPU work: the step is bound by the host issuing launches.  A HIP graph removes that cost,
+but a graph bakes in every pointer, size and host scalar of its nodes, and a sampled batch never repeats its (E, N).
+What this module does about each:
+
+* **shapes** — a batch is padded to a *bucket* ``(E_pad, N_pad)`` (``bucket_size``: eighth-of-an-octave steps, at most
+  12.5 % extra rows).  Padding edges are self loops on padding nodes, so no real node ever aggregates a padding
+  message; padding rows carry the raw values of table row 0 (any valid row does).  Every operator of the path is local
+  to a row, an edge or a seed — their padding rows get a zero upstream gradient and add nothing to any weight
+  gradient — except BatchNorm, whose statistics couple the rows: the BatchNorm kernels take the number of real rows
+  from device memory (``tg_set_bn_row_limit``) and give the padding rows a zero input gradient.
+* **pointers** — every input of the step lives in static buffers owned by the bucket (``_Bucket.static``): raw rows
+  or row ids of the two frames, labels, ``edge_index``, the host-built index structures (one int32 array whose part
+  offsets depend on the bucket alone) and the real node count.  A step copies the batch into them and replays.
+  Intermediates come from the graph's private pool (one pool for all buckets: replays are sequential).
+* **host scalars** — the dropout seed, Adam's step count and bias corrections live in a device record
+  (``StepState`` -> ``tg_advance_step``), advanced by the first node of the graph.
+* **library nodes** — the body records kernels only: gradient zeroing happens in the Adam kernel, ``tg_zero`` replaces
+  memsets, and the input copies stay outside the graph.
+
+``GraphedTrainStep.run_eager`` executes the very same body without capture (the parity twin of the replay test).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .frame import TensorFrame
+from .sampler import host_batch_index, index_over
+
+
+class StepState:
+    """The device-resident scalars of a step: ``buf`` = int64[4] (seed word, step count t, two packed floats
+    lr/(1-b1^t) and 1/sqrt(1-b2^t), reserved) — layout of ``include/tabgnn_hip.h:tg_advance_step``."""
+
+    def __init__(self, device, seed=0x1234ABCD, t=0):
+        self.buf = torch.tensor([int(seed) & ((1 << 63) - 1), int(t), 0, 0], dtype=torch.int64, device=device)
+
+    def advance(self, lr, betas):
+        L.call("tg_advance_step", L.ptr(self.buf), float(lr), float(betas[0]), float(betas[1]), L.stream())
+
+    @staticmethod
+    def release():
+        """Back to host seeds alone (kernels stop reading the seed word)."""
+        L.call("tg_seed_source_sync", None, L.stream())
+
+
+def bucket_size(n, floor=64):
+    """Smallest multiple of 2^(floor(log2 n) - 3) that is >= n: eight steps per octave, <= 12.5 % padding."""
+    n = max(int(n), floor)
+    q = 1 << max(n.bit_length() - 4, 0)
+    return -(-n // q) * q
+
+
+def pad_edges(edge_index, n_real, e_pad, n_pad):
+    """``edge_index`` (int64 [2,E], host) with ``e_pad - E`` self loops appended, spread over the padding nodes
+    ``n_real .. n_pad-1``."""
+    ei = np.ascontiguousarray(edge_index.numpy() if isinstance(edge_index, torch.Tensor) else np.asarray(edge_index),
+                              dtype=np.int64)
+    extra = e_pad - ei.shape[1]
+    if extra < 0 or n_pad < n_real:
+        raise ValueError("bucket smaller than the batch")
+    if extra == 0:
+        return ei
+    if n_pad == n_real:
+        raise ValueError("padding edges need at least one padding node")
+    loops = n_real + np.arange(extra, dtype=np.int64) % (n_pad - n_real)
+    return np.concatenate([ei, np.stack([loops, loops])], axis=1)
+
+
+def _pad_rows(t, n):
+    """[R, ...] -> [n, ...]: the padding rows repeat row 0."""
+    if t.shape[0] == n:
+        return t
+    return torch.cat([t, t[:1].expand(n - t.shape[0], *t.shape[1:])], dim=0)
+
+
+class Prepared:
+    """One batch in bucket form: ``key`` = (E_pad, N_pad), ``tensors`` name -> tensor (host or device) for the
+    same-named static buffers, ``off`` = part offsets of the index array."""
+    __slots__ = ("key", "tensors", "off", "e_real", "n_real", "lazy")
+
+    def __init__(self, key, tensors, off, e_real, n_real, lazy):
+        self.key, self.tensors, self.off, self.e_real, self.n_real, self.lazy = key, tensors, off, e_real, n_real, lazy
+
+    def to(self, device):
+        """The same batch with its parts on ``device`` (uploaded ahead of the step, as a prefetching loader does)."""
+        return Prepared(self.key, {k: v.to(device, non_blocking=True) for k, v in self.tensors.items()}, self.off,
+                        self.e_real, self.n_real, self.lazy)
+
+
+def prepare(batch, n_seed, key=None):
+    """Pad ``batch`` = (node_tf, edge_index, edge_tf, y) to its bucket (or to ``key``) and build the index structures of
+    the padded graph on the host.  ``edge_index`` may be a host or device int64 tensor; lazy frames (row ids over an
+    HBM-resident table) stay lazy.  Pure host/torch work outside any capture: a sampler thread can run it."""
+    node_tf, edge_index, edge_tf, y = batch
+    if isinstance(edge_index, ops.BatchIndex):
+        edge_index = edge_index.edge_index
+    E, N = int(edge_index.shape[1]), int(node_tf.num_rows)
+    e_pad, n_pad = key if key is not None else (bucket_size(E), bucket_size(N + 1))
+    ei = pad_edges(edge_index.cpu() if isinstance(edge_index, torch.Tensor) else edge_index, N, e_pad, n_pad)
+    flat, off, ei = host_batch_index(ei, n_pad, n_seed)
+    lazy = node_tf.row_ids is not None
+    if lazy != (edge_tf.row_ids is not None):
+        raise ValueError("node and edge frame must both be lazy or both be materialised")
+    t = {"flat": torch.from_numpy(flat), "ei": torch.from_numpy(ei),
+         "n_real": torch.tensor([N], dtype=torch.int32), "y": y.reshape(-1)}
+    if lazy:
+        t["node.ids"], t["edge.ids"] = _pad_rows(node_tf.row_ids, n_pad), _pad_rows(edge_tf.row_ids, e_pad)
+    else:
+        for name, tf, n in (("node", node_tf, n_pad), ("edge", edge_tf, e_pad)):
+            for st, v in tf.feat_dict.items():
+                t[f"{name}.{st.value}"] = _pad_rows(v, n)
+    return Prepared((e_pad, n_pad), t, off, E, N, lazy)
+
+
+class _Bucket:
+    def __init__(self, prep, frames, device):
+        self.key, self.off = prep.key, prep.off
+        self.static = {k: torch.empty(v.shape, dtype=v.dtype, device=device) for k, v in prep.tensors.items()}
+        node_tf, edge_tf = frames
+        e_pad, n_pad = prep.key
+
+        def frame(name, tf):
+            if prep.lazy:
+                return TensorFrame(tf.feat_dict, tf.col_names_dict, None, self.static[f"{name}.ids"])
+            return TensorFrame({st: self.static[f"{name}.{st.value}"] for st in tf.feat_dict}, tf.col_names_dict)
+        self.node_tf, self.edge_tf = frame("node", node_tf), frame("edge", edge_tf)
+        self.graph = None
+        self.loss = self.logits = None
+
+    def load(self, prep):
+        for k, v in prep.tensors.items():
+            dst = self.static[k]
+            if dst.shape != v.shape:
+                raise RuntimeError(f"batch part {k} {tuple(v.shape)} does not fit its bucket {tuple(dst.shape)}")
+            dst.copy_(v, non_blocking=True)
+
+    def index(self, n_seed):
+        """Fresh index objects over the static buffers (no cached per-graph tensors from an earlier batch)."""
+        return index_over(self.static["flat"], self.off, self.key[1], n_seed, self.static["ei"])
+
+
+class GraphedTrainStep:
+    """``train.train_step`` (reference ``main.py:41-75``) as one HIP graph per shape bucket.
+
+    ``step(prepare(batch, n_seed))`` -> (loss, logits of the padded batch; rows [:n_seed] are the seed edges).  With a
+    ``DataParallel`` the graph ends after the backward and the all-reduce + Adam run eagerly behind it."""
+
+    def __init__(self, model, flat, opt, loss_weight, n_seed, ddp=None, state=None, warmup=2):
+        self.model, self.flat, self.opt, self.loss_weight = model, flat, opt, loss_weight
+        self.n_seed, self.ddp, self.warmup = int(n_seed), ddp, int(warmup)
+        self.device = flat.flat.device
+        self.state = state if state is not None else StepState(self.device, t=opt.t)
+        self.buckets = {}
+        self.pool = None
+        self.host_seed = ops.DropoutRNG.seed         # (per rank under DataParallel)
+        flat.zero_grad()                     # afterwards every Adam launch leaves the gradients zeroed
+
+    # ---- the step itself: every launch below is a kernel on the current stream
+    def _body(self, b):
+        ops.DropoutRNG.new_step(self.host_seed)                 # host seed and stream ids: the same in every step ...
+        self.state.advance(self.opt.lr, self.opt.betas)         # ... the device seed word makes the masks differ
+        L.call("tg_set_bn_row_limit", L.ptr(b.static["n_real"]))       # read by BatchNorm's forward AND backward kernels
+        try:
+            logits = self.model(b.node_tf, b.index(self.n_seed), b.edge_tf)
+            loss = ops.weighted_cross_entropy(logits[:self.n_seed], b.static["y"], self.loss_weight)
+            loss.backward()
+        finally:
+            L.call("tg_set_bn_row_limit", None)
+        if self.ddp is None:
+            self.opt.step(zero_grad=True, state=self.state)
+        return loss.detach(), logits.detach()
+
+    def _tail(self):
+        if self.ddp is not None:
+            self.opt.step(grad_scale=self.ddp.all_reduce_grads(), zero_grad=True, state=self.state)
+
+    def _snapshot(self):
+        bufs = [b for b in self.model.buffers()]
+        return (self.flat.flat.clone(), self.opt.m.clone(), self.opt.v.clone(), self.state.buf.clone(),
+                [b.clone() for b in bufs], bufs, self.opt.t)
+
+    def _restore(self, snap):
+        w, m, v, st, saved, bufs, t = snap
+        self.flat.flat.copy_(w); self.opt.m.copy_(m); self.opt.v.copy_(v); self.state.buf.copy_(st)
+        for b, s in zip(bufs, saved):
+            b.copy_(s)
+        self.opt.t = t
+        self.flat.zero_grad()
+        self.flat.refresh_shadow()
+
+    def _bucket(self, prep, frames):
+        b = self.buckets.get(prep.key)
+        if b is not None:
+            return b
+        b = _Bucket(prep, frames, self.device)
+        b.load(prep)
+        snap = self._snapshot()              # warm-up steps and the capture must not train the model
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._body(b)
+                if self.ddp is not None:
+                    self.opt.step(zero_grad=True, state=self.state)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self.pool):
+            b.loss, b.logits = self._body(b)
+        b.graph = g
+        torch.cuda.synchronize()
+        self._restore(snap)
+        self.buckets[prep.key] = b
+        return b
+
+    def __call__(self, prep, frames=None):
+        """``frames`` = (node_tf, edge_tf) templates, needed the first time a bucket is seen (column names, and for lazy
+        frames the HBM-resident tables)."""
+        b = self.buckets.get(prep.key)
+        if b is None:
+            if frames is None:
+                raise RuntimeError("first batch of a bucket: pass frames=(node_tf, edge_tf)")
+            b = self._bucket(prep, frames)
+        b.load(prep)
+        b.graph.replay()
+        if self.ddp is None:
+            self.opt.t += 1                  # the Adam node ran inside the graph: mirror its device-side step count
+        self._tail()
+        return b.loss, b.logits
+
+    def run_eager(self, prep, frames):
+        """The same body without a graph (same static buffers, same device state): the replay test's twin."""
+        b = self.buckets.get(prep.key)
+        if b is None:
+            b = _Bucket(prep, frames, self.device)
+            self.buckets[prep.key] = b
+        b.load(prep)
+        loss, logits = self._body(b)
+        self._tail()
+        return loss, logits

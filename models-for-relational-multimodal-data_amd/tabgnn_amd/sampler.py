@@ -145,12 +145,19 @@ def batch_index(edge_index, num_nodes, n_seed, device, prebuilt=None):
     from . import ops
     flat_h, off, ei = prebuilt if prebuilt is not None else host_batch_index(edge_index, num_nodes, n_seed)
     flat = torch.from_numpy(flat_h).to(device, non_blocking=True)                                     # ONE upload
+    return index_over(flat, off, num_nodes, n_seed, torch.from_numpy(ei).to(device, non_blocking=True))
+
+
+def index_over(flat, off, num_nodes, n_seed, edge_index):
+    """``ops.BatchIndex`` whose parts are views of ``flat`` (device int32, laid out by ``host_batch_index``); the part
+    offsets depend on (E, N, n_seed) alone, so a static buffer serves every batch of one shape bucket."""
+    from . import ops
     v = [flat[int(off[i]):int(off[i + 1])] for i in range(13)]
     src, dst, rp_d, pm_d, rp_s, pm_s, tei_d, rp_t, pm_t, dst_sorted, src_sorted, inv_d, s2s = v
     graph = ops.SubgraphIndex(src, dst, (rp_d, pm_d), (rp_s, pm_s), int(num_nodes))
     graph._sorted = dict(perm=pm_d, dst=dst_sorted, src=src_sorted, inv=inv_d, src_to_sorted=s2s)
     seeds = ops.SeedIndex.from_parts(tei_d, rp_t, pm_t, int(n_seed), int(num_nodes))
-    return ops.BatchIndex(graph, seeds, torch.from_numpy(ei).to(device, non_blocking=True))
+    return ops.BatchIndex(graph, seeds, edge_index)
 
 
 class ColumnStore:

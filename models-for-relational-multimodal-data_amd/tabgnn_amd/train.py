@@ -91,7 +91,10 @@ class FlatParams:
                    self.t_table.shape[0], L.stream())
 
     def zero_grad(self):
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            L.call("tg_zero", L.ptr(self.grad), 4 * self.grad.numel(), L.stream())     # a kernel, never a memset node
+        else:
+            self.grad.zero_()
         for p, off in zip(self.params, self.offsets):     # autograd may have replaced .grad; re-point the views
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view_as(p)
@@ -104,9 +107,17 @@ class FusedAdam:
         self.v = torch.zeros_like(flat.flat)
         self.t = 0
 
-    def step(self, grad_scale=1.0, zero_grad=False):
+    def step(self, grad_scale=1.0, zero_grad=False, state=None):
+        """``state`` (``graph_step.StepState``): bias corrections of the step count kept on the device — the form a
+        captured HIP graph replays; ``self.t`` then only mirrors it."""
         self.t += 1
         f = self.flat
+        if state is not None:
+            L.call("tg_adam_step_dev", L.ptr(f.flat), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(f.shadow),
+                   f.flat.numel(), self.betas[0], self.betas[1], self.eps, L.ptr(state.buf), grad_scale, int(zero_grad),
+                   L.stream())
+            f.refresh_transposed()
+            return
         L.call("tg_adam_step", L.ptr(f.flat), L.ptr(f.grad), L.ptr(self.m), L.ptr(self.v), L.ptr(f.shadow),
                f.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.t, grad_scale, int(zero_grad),
                L.stream())

@@ -1,0 +1,110 @@
+"""Shape-bucketed HIP-graph replay of the train step (tabgnn_amd/graph_step.py; reference loop main.py:41-75).
+
+1. padding changes nothing a real row sees: the padded batch's seed logits and every weight gradient equal the plain
+   batch's (up to the summation order of the BatchNorm statistics),
+2. N graph replays == N eager runs of the same body, bit for bit (weights, Adam moments, BatchNorm running statistics),
+   with batches of different true size sharing one bucket and the dropout seed / step count on the device.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(B, dtype, seed=7, dropout=0.5):
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    torch.manual_seed(seed)
+    cfg = S.make_config(128 if dtype == torch.bfloat16 else 32, 2, 4, B, backbone_dropout=dropout,
+                        head_dropout=0.083 if dropout else 0.0, compute_dtype=dtype)
+    model = T.TABGNNFusedS(cfg).to(DEV).train()
+    flat = T.FlatParams(model, shadow_dtype=dtype)
+    opt = T.FusedAdam(flat, lr=cfg["lr"])
+    return model, flat, opt, torch.tensor(cfg["loss_weights"], device=DEV)
+
+
+def _resize(batch, extra_nodes, drop_edges):
+    """The batch with ``extra_nodes`` isolated nodes appended and without its last ``drop_edges`` neighbour edges."""
+    import tabgnn_amd as T
+    node_tf, ei, edge_tf, y = batch
+    E = ei.shape[1] - drop_edges
+    feats = {k: torch.cat([v, v[:1].expand(extra_nodes, *v.shape[1:])]) for k, v in node_tf.feat_dict.items()}
+    return (T.TensorFrame(feats, node_tf.col_names_dict), ei[:, :E].contiguous(), edge_tf[slice(0, E)], y)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_padded_batch_gives_the_plain_batch_gradients(dtype):
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G, _lib as L
+    B = 48
+    model, flat, opt, lw = _model(B, dtype)
+    batch = S.make_batch(B, seed=11, device=DEV)
+    T.ops.DropoutRNG.new_step(1234)
+    flat.zero_grad()
+    logits = model(batch[0], batch[1], batch[2])
+    T.ops.weighted_cross_entropy(logits[:B], batch[3].view(-1), lw).backward()
+    want_logits, want_grad = logits[:B].detach().float().clone(), flat.grad.clone()
+    want_rm = {k: v.clone() for k, v in model.named_buffers() if "running" in k}
+
+    for k, b in model.named_buffers():           # undo the running-statistics update of the first pass
+        if "running_mean" in k:
+            b.zero_()
+        elif "running_var" in k:
+            b.fill_(1.0)
+    E, N = batch[1].shape[1], batch[0].num_rows
+    prep = G.prepare(batch, B, key=(E + 37, N + 5))
+    bucket = G._Bucket(prep, (batch[0], batch[2]), torch.device(DEV))
+    bucket.load(prep)
+    T.ops.DropoutRNG.new_step(1234)
+    flat.zero_grad()
+    L.call("tg_set_bn_row_limit", L.ptr(bucket.static["n_real"]))
+    try:
+        logits = model(bucket.node_tf, bucket.index(B), bucket.edge_tf)
+        T.ops.weighted_cross_entropy(logits[:B], bucket.static["y"], lw).backward()
+    finally:
+        L.call("tg_set_bn_row_limit", None)
+    assert logits.shape[0] == B
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    np.testing.assert_allclose(logits[:B].detach().float().cpu().numpy(), want_logits.cpu().numpy(), rtol=tol, atol=tol)
+    g, w = flat.grad, want_grad
+    err = float((g - w).norm() / w.norm())
+    assert err < (1e-4 if dtype == torch.float32 else 3e-2), err
+    for k, v in model.named_buffers():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), want_rm[k].cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_graph_replays_equal_eager_steps_bit_for_bit():
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G
+    B, steps = 64, 6
+    batches = [_resize(S.make_batch(B, seed=40 + i, device=DEV), 9 * i, 40 * i) for i in range(3)]
+    key = (G.bucket_size(max(b[1].shape[1] for b in batches)), G.bucket_size(max(b[0].num_rows for b in batches) + 1))
+    preps = [G.prepare(b, B, key=key) for b in batches]
+    frames = (batches[0][0], batches[0][2])
+    assert len({(p.e_real, p.n_real) for p in preps}) > 1        # different true sizes, one bucket
+
+    runs = {}
+    for mode in ("eager", "graph"):
+        model, flat, opt, lw = _model(B, torch.bfloat16, seed=3)
+        step = G.GraphedTrainStep(model, flat, opt, lw, B)
+        losses = []
+        for i in range(steps):
+            p = preps[i % 3]
+            loss, _ = step.run_eager(p, frames) if mode == "eager" else step(p, frames)
+            losses.append(loss.clone())
+        torch.cuda.synchronize()
+        runs[mode] = (torch.stack(losses).float().cpu(), flat.flat.clone().cpu(), opt.m.clone().cpu(), opt.v.clone().cpu(),
+                      {k: v.clone().cpu() for k, v in model.named_buffers()}, step.state.buf.clone().cpu(), opt.t)
+        G.StepState.release()
+    e, g = runs["eager"], runs["graph"]
+    assert e[6] == g[6] == steps
+    assert torch.equal(e[5], g[5])                       # device step record: seed word, t, bias corrections
+    assert torch.isfinite(e[0]).all() and float(e[0][0]) != float(e[0][3])     # same batch, another step: new masks, new weights
+    assert torch.equal(e[0], g[0]), (e[0], g[0])
+    for i in (1, 2, 3):
+        assert torch.equal(e[i], g[i]), i
+    for k in e[4]:
+        assert torch.equal(e[4][k], g[4][k]), k
