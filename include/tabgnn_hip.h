@@ -242,7 +242,9 @@ int tg_seed_pool_bwd(const void* g, const int32_t* tei, const int32_t* rowptr, v
  *      in_proj, out_proj, linear1, linear2: fused.py:83-92; PNA and edge-update projections) with the elementwise
  *      tail fused:  Y[R,N] (bf16) = epilogue(X[R,K] W[N,K]^T);  epilogue = + bias (fp32 [N] or NULL) | flags&1 ReLU |
  *      flags&2 dropout(p_drop; element index r*N+n of stream (seed, rstream), as tg_act_dropout_*) | flags&8 gate:
- *      x 1/(1-p_drop) where gate[r,n] > 0 else 0 (backward of drop(relu(.)) from its saved output) | flags&4 Y += .
+ *      x 1/(1-p_drop) where gate[r,n] > 0 else 0 (backward of drop(relu(.)) from its saved output) | flags&4 Y += |
+ *      flags&16 LeakyReLU(0.01) in place of ReLU (the fuse MLP, fused.py:199-202); with flags&8 a negative saved
+ *      output passes 0.01/(1-p_drop) (kept on the negative slope), zero = dropped.
  *      MFMA 32x32x16 bf16, fp32 accumulation.  tg_gemm_nt_supported: N % 128 == 0 and K % 128 == 0. ------------- */
 int32_t tg_gemm_nt_supported(int64_t R, int32_t N, int32_t K);
 int tg_gemm_nt_bf16(const void* X, const void* W, const float* bias, const void* gate /* flags&8, else NULL */, void* Y,

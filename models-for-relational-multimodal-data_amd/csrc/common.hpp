@@ -255,18 +255,19 @@ inline int grid_full(long long blocks, int old_cap = 256 * 8) {
   return (int)(blocks < 1 ? 1 : (blocks > 2147483647LL ? 2147483647LL : blocks));
 }
 
-// ---------------------------------------------------------------- per-unit seed-word setters (see g_seed_xor)
-typedef void (*seed_setter_fn)(const unsigned long long* src, hipStream_t st);
-void seed_tu_register(seed_setter_fn fn);          // train_ops.hip
+// ---------------------------------------------------------------- per-unit seed words (see g_seed_xor)
+// Each mask-drawing translation unit registers a function that returns the device address of ITS copy of
+// g_seed_xor (resolved lazily, on the first tg_advance_step — never at library load, which must work without a GPU);
+// k_step_advance then writes the new seed word to all of them in the same single-thread launch.
+typedef unsigned long long* (*seed_word_addr_fn)();
+void seed_tu_register(seed_word_addr_fn fn);          // train_ops.hip
 #define TG_DROPOUT_TU(NAME)                                                                                   \
   namespace tg { namespace {                                                                                  \
-  __global__ void k_seed_xor_set_##NAME(const unsigned long long* __restrict__ src) {                         \
-    if (threadIdx.x == 0 && blockIdx.x == 0) g_seed_xor = src ? src[0] : 0ull;                                \
+  unsigned long long* seed_word_addr_##NAME() {                                                               \
+    void* p = nullptr;                                                                                        \
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_seed_xor)) == hipSuccess ? (unsigned long long*)p : nullptr;  \
   }                                                                                                           \
-  void seed_xor_launch_##NAME(const unsigned long long* src, hipStream_t st) {                                \
-    hipLaunchKernelGGL(k_seed_xor_set_##NAME, dim3(1), dim3(64), 0, st, src);                                 \
-  }                                                                                                           \
-  struct SeedTu_##NAME { SeedTu_##NAME() { seed_tu_register(&seed_xor_launch_##NAME); } };                    \
+  struct SeedTu_##NAME { SeedTu_##NAME() { seed_tu_register(&seed_word_addr_##NAME); } };                     \
   SeedTu_##NAME seed_tu_instance_##NAME;                                                                      \
   } }
 

@@ -36,7 +36,7 @@ __device__ __forceinline__ nt_v8bf nt_frag(const char* tile, int row, int ch) {
   return __builtin_bit_cast(nt_v8bf, v);
 }
 
-enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4, NT_GATE = 8 };
+enum { NT_RELU = 1, NT_DROPOUT = 2, NT_ACCUM = 4, NT_GATE = 8, NT_LEAKY = 16 };
 
 __device__ __forceinline__ uint4 nt_scale8(uint4 v, float s) {   // 8 packed bf16 times s, round to nearest even
   typedef float nt_f32x8 __attribute__((ext_vector_type(8)));
@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                 \
         float u = acc[a][b][4 * g + j] + bv[a][g][j];                                                 \
         if (flags & NT_RELU) u = fmaxf(u, 0.f);                                                       \
+        if ((flags & (NT_LEAKY | NT_GATE)) == NT_LEAKY) u = u > 0.f ? u : 0.01f * u;   /* LeakyReLU(0.01) */  \
         if (flags & NT_DROPOUT) u *= drop_scale_key(key, (unsigned)e0 + j, thresh, inv_keep);         \
         v[j] = u;                                                                                     \
       }                                                                                               \
@@ -207,8 +208,12 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt_bf16(const unsigned short* _
         const unsigned gw[4] = {gt.x, gt.y, gt.z, gt.w};                                              \
         unsigned nw[4] = {o.x, o.y, o.z, o.w};                                                        \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-          float lo = __uint_as_float(gw[j] << 16) > 0.f ? __uint_as_float(nw[j] << 16) * inv_keep : 0.f; \
-          float hi = __uint_as_float(gw[j] & 0xffff0000u) > 0.f ? __uint_as_float(nw[j] & 0xffff0000u) * inv_keep : 0.f; \
+          const float glo = __uint_as_float(gw[j] << 16), ghi = __uint_as_float(gw[j] & 0xffff0000u);       \
+          /* NT_LEAKY: a negative saved output = kept on the 0.01 slope; zero = dropped either way */        \
+          float lo = glo > 0.f ? inv_keep : ((flags & NT_LEAKY) && glo < 0.f ? 0.01f * inv_keep : 0.f);       \
+          float hi = ghi > 0.f ? inv_keep : ((flags & NT_LEAKY) && ghi < 0.f ? 0.01f * inv_keep : 0.f);       \
+          lo *= __uint_as_float(nw[j] << 16);                                                             \
+          hi *= __uint_as_float(nw[j] & 0xffff0000u);                                                     \
           nw[j] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);                                    \
         }                                                                                             \
         o = make_uint4(nw[0], nw[1], nw[2], nw[3]);                                                   \

@@ -79,18 +79,43 @@ def _pad_rows(t, n):
     return torch.cat([t, t[:1].expand(n - t.shape[0], *t.shape[1:])], dim=0)
 
 
-class Prepared:
-    """One batch in bucket form: ``key`` = (E_pad, N_pad), ``tensors`` name -> tensor (host or device) for the
-    same-named static buffers, ``off`` = part offsets of the index array."""
-    __slots__ = ("key", "tensors", "off", "e_real", "n_real", "lazy")
+def _pack(tensors):
+    """All parts in ONE byte arena (256-byte aligned parts; on the GPU when any part already is): a step then moves a
+    batch into its bucket with a single copy.  Returns (arena, views by name, layout)."""
+    dev = next((v.device for v in tensors.values() if v.is_cuda), torch.device("cpu"))
+    layout, off = [], 0
+    for k, v in tensors.items():
+        layout.append((k, v.dtype, tuple(v.shape), off))
+        off += (v.numel() * v.element_size() + 255) // 256 * 256
+    arena = torch.empty(off, dtype=torch.uint8, device=dev)
+    views = _views(arena, layout)
+    for k, v in tensors.items():
+        views[k].copy_(v, non_blocking=True)
+    return arena, views, layout
 
-    def __init__(self, key, tensors, off, e_real, n_real, lazy):
-        self.key, self.tensors, self.off, self.e_real, self.n_real, self.lazy = key, tensors, off, e_real, n_real, lazy
+
+def _views(arena, layout):
+    out = {}
+    for k, dtype, shape, off in layout:
+        n = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+        out[k] = arena[off:off + n].view(dtype).view(shape)
+    return out
+
+
+class Prepared:
+    """One batch in bucket form: ``key`` = (E_pad, N_pad), ``arena`` = every part in one byte buffer (host or device),
+    ``tensors`` = the parts as views of it, ``off`` = part offsets of the index array."""
+    __slots__ = ("key", "arena", "tensors", "layout", "off", "e_real", "n_real", "lazy")
+
+    def __init__(self, key, arena, layout, off, e_real, n_real, lazy):
+        self.key, self.arena, self.layout, self.off = key, arena, layout, off
+        self.tensors = _views(arena, layout)
+        self.e_real, self.n_real, self.lazy = e_real, n_real, lazy
 
     def to(self, device):
-        """The same batch with its parts on ``device`` (uploaded ahead of the step, as a prefetching loader does)."""
-        return Prepared(self.key, {k: v.to(device, non_blocking=True) for k, v in self.tensors.items()}, self.off,
-                        self.e_real, self.n_real, self.lazy)
+        """The same batch with its arena on ``device`` (uploaded ahead of the step, as a prefetching loader does)."""
+        return Prepared(self.key, self.arena.to(device, non_blocking=True), self.layout, self.off, self.e_real,
+                        self.n_real, self.lazy)
 
 
 def prepare(batch, n_seed, key=None):
@@ -115,15 +140,16 @@ def prepare(batch, n_seed, key=None):
         for name, tf, n in (("node", node_tf, n_pad), ("edge", edge_tf, e_pad)):
             for st, v in tf.feat_dict.items():
                 t[f"{name}.{st.value}"] = _pad_rows(v, n)
-    return Prepared((e_pad, n_pad), t, off, E, N, lazy)
+    arena, _, layout = _pack(t)
+    return Prepared((e_pad, n_pad), arena, layout, off, E, N, lazy)
 
 
 class _Bucket:
     def __init__(self, prep, frames, device):
-        self.key, self.off = prep.key, prep.off
-        self.static = {k: torch.empty(v.shape, dtype=v.dtype, device=device) for k, v in prep.tensors.items()}
+        self.key, self.off, self.layout = prep.key, prep.off, prep.layout
+        self.arena = torch.empty(prep.arena.shape, dtype=torch.uint8, device=device)
+        self.static = _views(self.arena, prep.layout)
         node_tf, edge_tf = frames
-        e_pad, n_pad = prep.key
 
         def frame(name, tf):
             if prep.lazy:
@@ -134,11 +160,9 @@ class _Bucket:
         self.loss = self.logits = None
 
     def load(self, prep):
-        for k, v in prep.tensors.items():
-            dst = self.static[k]
-            if dst.shape != v.shape:
-                raise RuntimeError(f"batch part {k} {tuple(v.shape)} does not fit its bucket {tuple(dst.shape)}")
-            dst.copy_(v, non_blocking=True)
+        if prep.layout != self.layout:
+            raise RuntimeError("batch parts do not fit this bucket (different shapes or columns)")
+        self.arena.copy_(prep.arena, non_blocking=True)          # the step's only copy
 
     def index(self, n_seed):
         """Fresh index objects over the static buffers (no cached per-graph tensors from an earlier batch)."""

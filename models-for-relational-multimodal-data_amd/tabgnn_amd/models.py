@@ -117,9 +117,7 @@ class FTTransformerPNAFusedLayer(nn.Module):
             f = self.fuse
             xf0 = ops.seed_gather(x_gnn, x_tab, seeds, "fuse", sn)                  # [cls_tab, x[src], x[dst]]
             h = ops.layer_norm(xf0, f[0].weight, f[0].bias)
-            h = ops.act_dropout(ops.linear(h, f[1].weight, f[1].bias), "leaky_relu", p)
-            h = ops.act_dropout(ops.linear(h, f[4].weight, f[4].bias), "leaky_relu", p)
-            h = ops.linear(h, f[7].weight, f[7].bias)
+            h = ops.mlp_chain(h, (f[1], f[4], f[7]), "leaky_relu", p)
             xf = ops.layer_norm(h, self.fuse_norm.weight, self.fuse_norm.bias, res=xf0, alpha=0.5, beta_c=0.5)
             x_tab = ops.cls_merge(x_tab, xf)                                        # fused.py:259-260
             # in place, as fused.py:268.  The gather-fused edge update above re-reads x_gnn in its backward (x[src], x[dst]

@@ -231,7 +231,7 @@ def _sink_target(sink, shape, dtype, device):
 # --------------------------------------------------------------------------- dense projection
 
 
-NT_RELU, NT_DROPOUT, NT_ACCUM, NT_GATE = 1, 2, 4, 8
+NT_RELU, NT_DROPOUT, NT_ACCUM, NT_GATE, NT_LEAKY = 1, 2, 4, 8, 16
 
 
 def nt_ok(x2, N, K):
@@ -450,6 +450,79 @@ def mlp_relu(x, lin0, lin2):
         return _MLPRelu.apply(x, lin0.weight, lin0.bias, lin2.weight, lin2.bias, shadow(lin0.weight, dt),
                               shadow(lin2.weight, dt))
     return linear(act_dropout(linear(x, lin0.weight, lin0.bias), "relu", 0.0), lin2.weight, lin2.bias)
+
+
+class _MLPChain(torch.autograd.Function):
+    """Linear -> act -> dropout -> ... -> Linear as ONE node on the MFMA GEMMs (the fuse MLP of the fused layer,
+    fused.py:199-202: 3D -> 4*3D -> 4*3D -> 3D with LeakyReLU + Dropout; any chain whose widths are multiples of 128).
+    Activation and dropout run in the producing GEMM's epilogue (the pre-activations never exist); the backward of
+    act+dropout of layer i is the gate epilogue of layer i+1's input-gradient GEMM, read from the saved OUTPUT of
+    layer i; weight and bias gradients are accumulated in place by the split-row kernel."""
+
+    @staticmethod
+    def forward(ctx, x, act, p, n, *wb):
+        ws, bs, lws = wb[:n], wb[n:2 * n], wb[2 * n:]
+        x2 = x.reshape(-1, x.shape[-1])
+        aflag = NT_LEAKY if act == "leaky_relu" else NT_RELU
+        ctx.seed, ctx.rs = DropoutRNG.seed, []
+        hs = [x2]
+        for i in range(n):
+            last = i == n - 1
+            rs = 0 if last else DropoutRNG.next_stream()       # one stream id per act+dropout site, as act_dropout takes
+            ctx.rs.append(rs)
+            flags = 0 if last else aflag | (NT_DROPOUT if p > 0.0 else 0)
+            hs.append(gemm_nt(hs[-1], lws[i], bs[i].detach(), flags, 0.0 if last else p, ctx.seed, rs))
+        ctx.save_for_backward(*hs[:-1], *lws)
+        ctx.cfg = (aflag, p, n, x.shape)
+        ctx.params = (ws, bs)
+        return hs[-1].reshape(*x.shape[:-1], lws[-1].shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        aflag, p, n, xshape = ctx.cfg
+        saved = ctx.saved_tensors
+        hs, lws = saved[:n], saved[n:]
+        ws, bs = ctx.params
+        isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
+        d = g.reshape(-1, g.shape[-1]).contiguous()
+        dws, dbs = [None] * n, [None] * n
+        for i in range(n - 1, -1, -1):
+            dw, db = weight_grad(d, hs[i], True, isp(ws[i]), isp(bs[i]))
+            if db is None and dw is not None:
+                db = d.sum(0, dtype=torch.float32)
+            dws[i], dbs[i] = dw, db
+            if i > 0:            # (d W_i) through act+dropout of layer i-1, from that layer's saved output
+                d = gemm_nt(d, wt(lws[i], ws[i]), None, NT_GATE | (aflag & NT_LEAKY), p, gate=hs[i])
+            elif ctx.needs_input_grad[0]:
+                d = gemm_nt(d, wt(lws[0], ws[0])).reshape(xshape)
+            else:
+                d = None
+        return (d, None, None, None, *dws, *dbs, *([None] * n))
+
+
+# Below ~1 k rows the 128 x 128-tile kernel leaves the chip empty (24 workgroups at the reference's 200 seed rows) and
+# the library's small-tile GEMMs win: 3.26 vs 3.38 ms per replayed step at B = 200; equal at B = 8192 (18.2 ms/step).
+MLP_CHAIN_MIN_ROWS = int(os.environ.get("TABGNN_MLP_CHAIN_MIN_ROWS", "1024"))
+
+
+def mlp_chain(x, linears, act="leaky_relu", p_drop=0.0):
+    """``lin_k(drop(act(... drop(act(lin_0(x))))))`` for ``nn.Linear`` modules: one fused node when every width is a
+    multiple of 128 (bf16 on the GPU) and there are enough rows to fill the chip, the op-by-op composition otherwise."""
+    x2 = x.reshape(-1, x.shape[-1])
+    ok = (x2.dtype == torch.bfloat16 and x2.is_cuda and x2.is_contiguous() and x2.shape[0] > 0
+          and x2.shape[0] >= MLP_CHAIN_MIN_ROWS and x2.data_ptr() % 16 == 0
+          and all(l.bias is not None and l.weight.shape[0] % 128 == 0 and l.weight.shape[1] % 128 == 0 for l in linears))
+    if ok:
+        dt = x.dtype
+        n = len(linears)
+        return _MLPChain.apply(x, act, float(p_drop), n, *[l.weight for l in linears], *[l.bias for l in linears],
+                               *[shadow(l.weight, dt) for l in linears])
+    h = x
+    for i, l in enumerate(linears):
+        h = linear(h, l.weight, l.bias)
+        if i + 1 < len(linears):
+            h = act_dropout(h, act, p_drop)
+    return h
 
 
 # --------------------------------------------------------------------------- attention core
