@@ -194,6 +194,15 @@ int tg_pna_scale_combine_bwd(const void* gout, const int32_t* rowptr, const floa
 int tg_pna_degree_scalers(const int32_t* rowptr, const float* avg_log, float* out /*[N,2]*/, int32_t N, void* stream);
 int tg_gemm_nt_scaled_bf16(const void* X, const void* W, const float* scales, void* Y, int64_t R, int32_t N,
                            int32_t kreal, int64_t ldx, int64_t ldy, int32_t flags /*0 | 4 (Y +=)*/, void* stream);
+
+/* The same post projection, forward, as ONE MFMA-bound kernel with the x term and the bias inside (csrc/post_scaled.hip):
+ *   out[R,128] = bias + x Wx^T + agg W_0^T + amp*(agg W_1^T) + att*(agg W_2^T)
+ * three accumulator sets (one per scaler) combined in the epilogue; operands HBM/L2 -> LDS by LDS-DMA, 3-stage ring.
+ * wcat [128, 3K] bf16 in tg_pna_fold_fwd's virtual-chunk order, wx [128,128] bf16, scales fp32 [>=R][2], K % 128 == 0.
+ * (PNAConv.forward: post_nns + lin over [x | scalers x aggregators], torch_geometric 2.5.3, reached from fused.py:204-214) */
+int tg_pna_post_fwd_bf16(const void* agg, const void* x, const void* wcat, const void* wx, const float* bias,
+                         const float* scales, void* out, int64_t R, int32_t K, int64_t ld_agg, int64_t ld_x,
+                         int64_t ld_out, void* stream);
 int tg_gemm_tn_scaled_bf16(const void* G, const void* X, const float* scales, float* out, float* workspace, int64_t R,
                            int32_t mreal, int32_t N, int64_t ldg, int64_t ldx, int32_t accumulate, void* stream);
 /* The weight folds of PNAConv (torch_geometric 2.5.3 PNAConv.forward: edge_encoder -> pre_nns[0], post_nns[0] -> lin,

@@ -1,0 +1,234 @@
+// PNA post projection with the degree scalers folded in (reference: torch_geometric PNAConv.forward, reached from
+// src/nn/models/fused.py:204-214 — post_nns over [x | scalers x aggregators], then lin):
+//
+//     out[r, :] = b + x[r] Wx^T + agg[r] W_0^T + amp(r) * (agg[r] W_1^T) + att(r) * (agg[r] W_2^T)
+//
+// agg [R, K] (K = 4F = 512: mean | max | min | std), x [R, F], F = 128, (amp, att) fp32 per row.
+//
+// 206 GFLOP per launch at the bench subgraph (R = 515 k) against 0.8 GB of operands: the one GEMM of the path that is
+// MFMA-bound, not HBM-bound.  tg_gemm_nt_scaled_bf16 (gemm_nt.hip) multiplies the X tile by the row scale on its way
+// into LDS — three register-staged, VALU-rescaled copies of every X chunk, two workgroup barriers per 128-deep chunk —
+// and ran at 0.24 MFMA utilisation (370-400 us).  This kernel keeps THREE accumulator sets instead (one per scaler) and
+// combines them once in the epilogue, so the operands go HBM/L2 -> LDS by LDS-DMA untouched:
+//   * workgroup = 8 waves = 256 rows x 128 output columns; wave tile 64 rows x 64 columns x 3 sets = 192 accumulator
+//     registers (two waves per SIMD, 256 registers each),
+//   * a stage = 32 k of the row tile: X piece 256 x 32 (16 KiB) + the three W_s pieces 128 x 32 (3 x 8 KiB), fetched by
+//     `global_load_lds_dwordx4` (5 instructions per wave and stage), three stages in an LDS ring (120 KiB): the DMA of
+//     stage t+2 is issued at the top of stage t — 2 x 1536 MFMA cycles per SIMD of cover,
+//   * one workgroup barrier per stage, counted `s_waitcnt vmcnt(5)` (the next stage stays in flight),
+//   * 64-byte LDS rows, chunk position = chunk ^ ((row >> 2) & 3): the 16 rows a ds_read_b128 phase touches fall on 16
+//     different 16-byte bank groups; the DMA applies the swizzle on the SOURCE side (lane -> global chunk),
+//   * x Wx^T rides in accumulator set 0 as four more stages (X from x, W from Wx), bias in the epilogue: the separate
+//     GEMM launch and the read-modify-write of `out` go.
+#include "common.hpp"
+#include "../../include/tabgnn_hip.h"
+
+#ifndef PS_ABL
+#define PS_ABL 0      // diagnostic builds: 1 = no MFMAs, 2 = no DMA (stale LDS), 4 = no stage barrier
+#endif
+
+namespace tg {
+
+typedef __bf16 ps_v8bf __attribute__((ext_vector_type(8)));
+typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PS_ROWS = 256, PS_F = 128, PS_THREADS = 512, PS_NSTAGE = 3;
+constexpr int PS_XB = PS_ROWS * 64;             // X piece: 256 rows x 32 bf16
+constexpr int PS_WB = PS_F * 64;                // one W_s piece: 128 rows x 32 bf16
+constexpr int PS_STAGE = PS_XB + 3 * PS_WB;     // 40 KiB
+constexpr int PS_LDS = PS_NSTAGE * PS_STAGE;    // 120 KiB (the output tile, 64 KiB, is restaged in it afterwards)
+
+struct PsArgs {
+  const char* agg; const char* x; const char* wcat; const char* wx;
+  const float* bias; const float* scales;
+  unsigned short* out;
+  long long R, ld_agg, ld_x, ld_out;            // row strides in elements
+  int K;
+};
+
+__device__ __forceinline__ void ps_dma(unsigned voff, const char* sbase, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(sbase), "s"(lds_addr)
+               : "memory");
+}
+
+__device__ __forceinline__ ps_v8bf ps_frag(const char* p) {
+  if (PS_ABL & 8) { ps_v8bf z; for (int i = 0; i < 8; ++i) z[i] = (__bf16)(float)(int)((unsigned long long)p & 15); return z; }   // no LDS reads
+  return __builtin_bit_cast(ps_v8bf, *reinterpret_cast<const uint4*>(p));
+}
+
+__device__ __forceinline__ int ps_out_off(int row, int ch) {       // restaged output tile: 256-byte rows, 16 chunks
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave & 3, wn = wave >> 2;                       // wave tile: rows 64*wr.., columns 64*wn..
+  const long long r0 = (long long)blockIdx.x * PS_ROWS;
+  const int rows_here = (int)(a.R - r0 < PS_ROWS ? a.R - r0 : PS_ROWS);
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- DMA lane geometry: one instruction = 16 rows x 64 bytes; lane -> (row l >> 2, chunk position l & 3)
+  const int drow = lane >> 2;
+  const unsigned dch = 16u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3));      // source chunk of this lane's position
+  int xrow[2], wrow[3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rr = 16 * (2 * wave + i) + drow;
+    xrow[i] = rr < rows_here ? rr : rows_here - 1;               // clamped: rows past R are never stored
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) wrow[q] = 16 * ((3 * wave + q) & 7) + drow;
+  const int KT = a.K / 32, T = KT + PS_F / 32;
+
+  auto issue = [&](int t) {
+    const unsigned sb = lds0 + (unsigned)((t % PS_NSTAGE) * PS_STAGE);
+    const bool tail = t >= KT;                                   // x Wx^T stages
+    const int u = tail ? t - KT : t;
+    const char* xb = tail ? a.x + (r0 * a.ld_x + 32ll * u) * 2 : a.agg + (r0 * a.ld_agg + 32ll * u) * 2;
+    const unsigned ldx = (unsigned)((tail ? a.ld_x : a.ld_agg) * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ps_dma((unsigned)xrow[i] * ldx + dch, xb, sb + 1024u * (unsigned)(2 * wave + i));
+    const unsigned ldw = tail ? 2u * PS_F : 6u * (unsigned)a.K;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = 3 * wave + q, s = i >> 3;                    // wave-uniform: W_s, rows 16*(i & 7)..
+      // W_s[n, k] of the agg stages sits at wcat[n, ((k >> 7) * 3 + s) * 128 + (k & 127)] (virtual-chunk order of
+      // tg_pna_fold_fwd); the tail stages read Wx for every set (only set 0 is multiplied)
+      const char* wb = tail ? a.wx + 64ll * u : a.wcat + (((long long)(u >> 2) * 3 + s) * 128 + 32ll * (u & 3)) * 2;
+      ps_dma((unsigned)wrow[q] * ldw + dch, wb, sb + (unsigned)PS_XB + 1024u * (unsigned)i);
+    }
+  };
+
+  ps_f32x16 acc[3][2][2];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[s][p][b][i] = 0.f;
+
+  // fragment lane offsets inside a piece: row r = lane & 31, 16-byte chunk 2*ks + (lane >> 5), swizzled
+  const int fr = lane & 31, fh = lane >> 5;
+  int fo[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) fo[ks] = 64 * fr + 16 * ((2 * ks + fh) ^ ((fr >> 2) & 3));
+
+  // one stage: wait for its DMA (the next stage's 5 instructions stay in flight), one barrier, issue stage t+2 into the
+  // buffer every wave has just left, then the MFMAs.  NSET = 3 on the agg stages, 1 on the x Wx^T stages.
+#define PS_STAGE_BODY(NSET)                                                                           \
+  {                                                                                                   \
+    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                   \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    if (!(PS_ABL & 4)) __builtin_amdgcn_s_barrier();                                                  \
+    asm volatile("" ::: "memory");                                                                    \
+    if (!(PS_ABL & 2) && t + 2 < T) issue(t + 2);                                                     \
+    const char* xs = smem + (t % PS_NSTAGE) * PS_STAGE + (wr * 64) * 64;                              \
+    const char* ws = smem + (t % PS_NSTAGE) * PS_STAGE + PS_XB + (wn * 64) * 64;                      \
+    /* rolling fragment prefetch, one (k-step, set) group ahead: the reads of group g+1 are issued before the four   \
+       MFMAs of group g (32 fragment registers: two A pairs, two B pairs) */                                          \
+    ps_v8bf bA[2][2], aA[2][2];                                                                       \
+    bA[0][0] = ps_frag(xs + fo[0]); bA[0][1] = ps_frag(xs + 32 * 64 + fo[0]);                         \
+    aA[0][0] = ps_frag(ws + fo[0]); aA[0][1] = ps_frag(ws + 32 * 64 + fo[0]);                         \
+    _Pragma("unroll") for (int g = 0; g < 2 * (NSET); ++g) {                                          \
+      const int ks = g / (NSET), sg = g % (NSET);                                                     \
+      if (g + 1 < 2 * (NSET)) {                                                                       \
+        const int ks2 = (g + 1) / (NSET), s2 = (g + 1) % (NSET);                                      \
+        aA[(g + 1) & 1][0] = ps_frag(ws + s2 * PS_WB + fo[ks2]);                                      \
+        aA[(g + 1) & 1][1] = ps_frag(ws + s2 * PS_WB + 32 * 64 + fo[ks2]);                            \
+        if (s2 == 0) { bA[1][0] = ps_frag(xs + fo[1]); bA[1][1] = ps_frag(xs + 32 * 64 + fo[1]); }    \
+      }                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+      if (PS_ABL & 1) { acc[sg][0][0][0] += (float)aA[g & 1][0][0] + (float)aA[g & 1][1][0] + (float)bA[ks][0][0] + (float)bA[ks][1][0]; continue; } \
+      acc[sg][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][0], bA[ks][0], acc[sg][0][0], 0, 0, 0); \
+      acc[sg][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][0], bA[ks][1], acc[sg][0][1], 0, 0, 0); \
+      acc[sg][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][1], bA[ks][0], acc[sg][1][0], 0, 0, 0); \
+      acc[sg][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][1], bA[ks][1], acc[sg][1][1], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                              \
+    }                                                                                                 \
+  }
+  issue(0);
+  if (T > 1) issue(1);
+  int t = 0;
+  for (; t < KT; ++t) PS_STAGE_BODY(3)
+  for (; t < T; ++t) PS_STAGE_BODY(1)
+#undef PS_STAGE_BODY
+  __syncthreads();                                               // every wave is done reading the ring
+
+  // ---- epilogue.  C/D map of a 32x32 tile: column (-> row r) = lane & 31, row (-> feature n) = (reg & 3) +
+  // 8*(reg >> 2) + 4*(lane >> 5): 4 consecutive n per register group.  amp / att are per-lane scalars.
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int rl = wr * 64 + b * 32 + fr;
+    const long long rg = r0 + (rl < rows_here ? rl : rows_here - 1);
+    const float2 sc = *reinterpret_cast<const float2*>(a.scales + 2 * rg);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wn * 64 + p * 32 + 8 * g + 4 * fh;
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + nl);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = acc[0][p][b][4 * g + j] + bb[j] + sc.x * acc[1][p][b][4 * g + j] + sc.y * acc[2][p][b][4 * g + j];
+        uint2 pk;
+        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *reinterpret_cast<uint2*>(smem + ps_out_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {                                  // whole-row stores: piece -> (row, 16-byte chunk)
+    const int piece = tid + PS_THREADS * p, row = piece >> 4, ch = piece & 15;
+    if (row < rows_here)
+      *reinterpret_cast<uint4*>(a.out + (r0 + row) * a.ld_out + ch * 8) =
+          *reinterpret_cast<const uint4*>(smem + ps_out_off(row, ch));
+  }
+}
+
+}  // namespace tg
+
+using namespace tg;
+
+// out [R,128] (bf16) = bias + x Wx^T + agg W_0^T + amp * (agg W_1^T) + att * (agg W_2^T)
+// wcat [128, 3K] bf16 in the virtual-chunk order tg_pna_fold_fwd writes (128-column block 3c+s = W_s[:, 128c:128c+128]),
+// wx [128,128] bf16 row-major, scales fp32 [>= R][2] = (amp, att).
+extern "C" int tg_pna_post_fwd_bf16(const void* agg, const void* x, const void* wcat, const void* wx, const float* bias,
+                                    const float* scales, void* out, int64_t R, int32_t K, int64_t ld_agg, int64_t ld_x,
+                                    int64_t ld_out, void* stream) {
+  TG_CHECK(R > 0 && K > 0 && K % 128 == 0, "tg_pna_post_fwd_bf16: need K %% 128 == 0 (R=%lld K=%d)", (long long)R, K);
+  TG_CHECK(agg && x && wcat && wx && bias && scales && out, "tg_pna_post_fwd_bf16: %s", "null operand");
+  TG_CHECK(ld_agg % 8 == 0 && ld_x % 8 == 0 && ld_out % 8 == 0 && ld_agg >= K && ld_x >= PS_F && ld_out >= PS_F,
+           "tg_pna_post_fwd_bf16: %s", "bad row strides");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(agg) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wcat) |
+             reinterpret_cast<uintptr_t>(wx) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(scales) & 7) == 0,
+           "tg_pna_post_fwd_bf16: %s", "operands must be 16-byte aligned");
+  // the DMA's per-lane byte offsets are 32-bit: one row tile must span < 4 GiB of either operand
+  TG_CHECK((long long)PS_ROWS * ld_agg * 2 < (1ll << 31) && 128ll * 3 * K * 2 < (1ll << 31),
+           "tg_pna_post_fwd_bf16: %s", "row stride too large");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pna_post_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    attr = true;
+  }
+  const long long tiles = (R + PS_ROWS - 1) / PS_ROWS;
+  TG_CHECK(tiles <= 2147483647LL, "tg_pna_post_fwd_bf16: %s", "too many tiles");
+  PsArgs a;
+  a.agg = (const char*)agg; a.x = (const char*)x; a.wcat = (const char*)wcat; a.wx = (const char*)wx;
+  a.bias = bias; a.scales = scales; a.out = (unsigned short*)out;
+  a.R = R; a.ld_agg = ld_agg; a.ld_x = ld_x; a.ld_out = ld_out; a.K = K;
+  hipLaunchKernelGGL(k_pna_post_fwd, dim3((unsigned)tiles), dim3(PS_THREADS), PS_LDS, (hipStream_t)stream, a);
+  TG_LAUNCH_CHECK();
+  return 0;
+}

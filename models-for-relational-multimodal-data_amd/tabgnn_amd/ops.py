@@ -1245,6 +1245,7 @@ def degree_scalers(graph, avg_log):
 
 
 _FUSED_POST = os.environ.get("TABGNN_NO_FUSED_POST") != "1"
+_POST_FWD_KERNEL = os.environ.get("TABGNN_NO_POST_FWD_KERNEL") != "1"     # same-box A/B switch: the two-GEMM forward
 
 
 def post_scaled_ok(x, agg, agg_width=None):
@@ -1279,10 +1280,17 @@ class _PNAPostScaled(torch.autograd.Function):
             # [F, 3K], 128-column block 3c+s = W_s[:, 128c:128c+128] (the kernel's virtual-chunk order)
             w_cat = w_lp.view(3, F, K // 128, 128).permute(1, 2, 0, 3).reshape(F, 3 * K).contiguous()
             wt_cat = w_lp.permute(2, 0, 1).reshape(K, 3 * F).contiguous()      # [K, 3F] = [W_0^T | W_1^T | W_2^T]
-        out = gemm_nt(x, wx_lp, b_x.detach().float().contiguous())
         scales = degree_scalers(graph, avg_log)
-        L.call("tg_gemm_nt_scaled_bf16", L.ptr(agg), L.ptr(w_cat), L.ptr(scales), L.ptr(out), N, F, K, agg.stride(0),
-               out.stride(0), NT_ACCUM, L.stream())
+        bias = b_x.detach().float().contiguous()
+        if _POST_FWD_KERNEL and F == 128:        # one MFMA-bound kernel: x term, three scaler sets, bias (post_scaled.hip)
+            out = torch.empty(N, F, dtype=x.dtype, device=x.device)
+            _launch("tg_pna_post_fwd_bf16", L.ptr(agg), L.ptr(x), L.ptr(w_cat), L.ptr(wx_lp.contiguous()), L.ptr(bias),
+                    L.ptr(scales), L.ptr(out), N, K, agg.stride(0), x.stride(0), out.stride(0), L.stream(),
+                    nbytes=2 * N * (K + 2 * F))
+        else:
+            out = gemm_nt(x, wx_lp, bias)
+            L.call("tg_gemm_nt_scaled_bf16", L.ptr(agg), L.ptr(w_cat), L.ptr(scales), L.ptr(out), N, F, K, agg.stride(0),
+                   out.stride(0), NT_ACCUM, L.stream())
         ctx.save_for_backward(x, wx_t, agg, wt_cat, scales)
         return out
 

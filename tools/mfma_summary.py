@@ -4,7 +4,7 @@
 import collections, csv, glob, json, sys
 d = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {"how": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE of `python bench.py "

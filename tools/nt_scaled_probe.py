@@ -37,3 +37,20 @@ eb = ((dagg[:S].float() - ref_b).abs().max() / ref_b.abs().max()).item()
 fl = 2 * N * 3 * F * K
 print(f"nt_scaled forward : {tf*1e6:7.1f} us  {fl/tf/1e12:6.1f} TFLOP/s  {N*(K+F)*2/tf/1e12:5.2f} TB/s  relerr {ef:.1e}")
 print(f"nt_scaled dagg    : {tb*1e6:7.1f} us  {fl/tb/1e12:6.1f} TFLOP/s  {N*(K+F)*2/tb/1e12:5.2f} TB/s  relerr {eb:.1e}")
+
+# the one-kernel forward with the x term and the bias inside (csrc/post_scaled.hip)
+x = torch.randn(N, F, device=dev, dtype=torch.bfloat16)
+wx = (torch.randn(F, F, device=dev) * 0.05).to(torch.bfloat16)
+bias = torch.randn(F, device=dev)
+out2 = torch.zeros(N, F, device=dev, dtype=torch.bfloat16)
+post = lambda: L.call("tg_pna_post_fwd_bf16", L.ptr(agg), L.ptr(x), L.ptr(w_cat), L.ptr(wx), L.ptr(bias), L.ptr(scales),
+                      L.ptr(out2), N, K, K, F, F, L.stream())
+tp = timeit(post)
+ref_p = bias + x[:S].float() @ wx.float().t() + sum(f[s][:, None] * (agg[:S].float() @ w[s].float().t()) for s in range(3))
+ep = ((out2[:S].float() - ref_p).abs().max() / ref_p.abs().max()).item()
+tail = slice(N - 300, N)
+ft = torch.stack([torch.ones(300, device=dev), scales[tail, 0], scales[tail, 1]], 0)
+ref_t = bias + x[tail].float() @ wx.float().t() + sum(ft[s][:, None] * (agg[tail].float() @ w[s].float().t()) for s in range(3))
+et = ((out2[tail].float() - ref_t).abs().max() / ref_t.abs().max()).item()
+flp = 2 * N * F * (3 * K + F)
+print(f"post fwd (1 kernel): {tp*1e6:7.1f} us  {flp/tp/1e12:6.1f} TFLOP/s  {N*(K+2*F)*2/tp/1e12:5.2f} TB/s  relerr {ep:.1e} (last rows {et:.1e})")

@@ -5,7 +5,7 @@ import collections, csv, glob, json, sys
 
 def load(d, counter):
     acc = collections.defaultdict(list)
-    for f in glob.glob(f"{d}/*/*counter_collection.csv"):
+    for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
