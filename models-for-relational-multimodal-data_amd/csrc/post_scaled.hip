@@ -20,6 +20,11 @@
 //     different 16-byte bank groups; the DMA applies the swizzle on the SOURCE side (lane -> global chunk),
 //   * x Wx^T rides in accumulator set 0 as four more stages (X from x, W from Wx), bias in the epilogue: the separate
 //     GEMM launch and the read-modify-write of `out` go.
+// Measured at R = 524 k (tools/nt_scaled_probe.py): 313 us = 714 TFLOP/s (the two launches it replaces: 380 + 75 us).
+// PS_ABL builds: without the MFMAs 226 us (the data path: 640 half-used 128-byte lines per stage through the TA),
+// without the DMA 216 us, without DMA and fragment reads 190 us (one workgroup per CU: dispatch, prologue and epilogue
+// are not overlapped).  A persistent variant with cross-tile prefetch measured 325 us and is not kept: the MFMA waves
+// also issue the DMA and stall at the TA, so the two paths do not overlap; next are full-line DMA and producer waves.
 #include "common.hpp"
 #include "../../include/tabgnn_hip.h"
 
