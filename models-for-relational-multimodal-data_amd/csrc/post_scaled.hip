@@ -12,12 +12,14 @@
 // combines them once in the epilogue, so the operands go HBM/L2 -> LDS by LDS-DMA untouched:
 //   * workgroup = 8 waves = 256 rows x 128 output columns; wave tile 64 rows x 64 columns x 3 sets = 192 accumulator
 //     registers (two waves per SIMD, 256 registers each),
-//   * a stage = 32 k of the row tile: X piece 256 x 32 (16 KiB) + the three W_s pieces 128 x 32 (3 x 8 KiB), fetched by
-//     `global_load_lds_dwordx4` (5 instructions per wave and stage), three stages in an LDS ring (120 KiB): the DMA of
-//     stage t+2 is issued at the top of stage t — 2 x 1536 MFMA cycles per SIMD of cover,
-//   * one workgroup barrier per stage, counted `s_waitcnt vmcnt(5)` (the next stage stays in flight),
-//   * 64-byte LDS rows, chunk position = chunk ^ ((row >> 2) & 3): the 16 rows a ds_read_b128 phase touches fall on 16
-//     different 16-byte bank groups; the DMA applies the swizzle on the SOURCE side (lane -> global chunk),
+//   * a stage = 64 k of the row tile: X piece 256 x 64 (32 KiB) + the three W_s pieces 128 x 64 (3 x 16 KiB), fetched by
+//     `global_load_lds_dwordx4` (10 instructions per wave and stage, each 8 rows x one whole 128-byte line), two stages
+//     in LDS (160 KiB, all of it): the DMA of stage t+1 is issued at the top of stage t — 3 072 MFMA cycles per SIMD of
+//     cover.  (First version: 32-k stages, 64-byte rows, three-deep ring — 640 half-used lines per 32 k through the TA
+//     at ~4.5 cycles each made the data path alone take 226 us; whole lines halve that.)
+//   * one workgroup barrier per stage,
+//   * 128-byte LDS rows, chunk position = chunk ^ ((row >> 1) & 7): the 16 rows of a ds_read_b128 lane group fall on 16
+//     different 16-byte slots; the DMA applies the swizzle on the SOURCE side (lane -> global chunk),
 //   * x Wx^T rides in accumulator set 0 as four more stages (X from x, W from Wx), bias in the epilogue: the separate
 //     GEMM launch and the read-modify-write of `out` go.
 // Measured at R = 524 k (tools/nt_scaled_probe.py): 313 us = 714 TFLOP/s (the two launches it replaces: 380 + 75 us).
@@ -37,11 +39,13 @@ namespace tg {
 typedef __bf16 ps_v8bf __attribute__((ext_vector_type(8)));
 typedef float ps_f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int PS_ROWS = 256, PS_F = 128, PS_THREADS = 512, PS_NSTAGE = 3;
-constexpr int PS_XB = PS_ROWS * 64;             // X piece: 256 rows x 32 bf16
-constexpr int PS_WB = PS_F * 64;                // one W_s piece: 128 rows x 32 bf16
-constexpr int PS_STAGE = PS_XB + 3 * PS_WB;     // 40 KiB
-constexpr int PS_LDS = PS_NSTAGE * PS_STAGE;    // 120 KiB (the output tile, 64 KiB, is restaged in it afterwards)
+constexpr int PS_ROWS = 256, PS_F = 128, PS_THREADS = 512, PS_NSTAGE = 2, PS_BK = 64;
+constexpr int PS_ROWB = PS_BK * 2;              // 128-byte LDS rows = whole cache lines per DMA lane group
+constexpr int PS_XB = PS_ROWS * PS_ROWB;        // X piece: 256 rows x 64 bf16 (32 KiB)
+constexpr int PS_WB = PS_F * PS_ROWB;           // one W_s piece: 128 rows x 64 bf16 (16 KiB)
+constexpr int PS_STAGE = PS_XB + 3 * PS_WB;     // 80 KiB
+constexpr int PS_LDS = PS_NSTAGE * PS_STAGE;    // 160 KiB: the whole LDS of a CU (the output tile is restaged in it afterwards)
+constexpr int PS_NDMA = PS_STAGE / 1024 / (PS_THREADS / 64);      // DMA instructions per wave and stage (10)
 
 struct PsArgs {
   const char* agg; const char* x; const char* wcat; const char* wx;
@@ -77,35 +81,39 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
   const int rows_here = (int)(a.R - r0 < PS_ROWS ? a.R - r0 : PS_ROWS);
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
 
-  // ---- DMA lane geometry: one instruction = 16 rows x 64 bytes; lane -> (row l >> 2, chunk position l & 3)
-  const int drow = lane >> 2;
-  const unsigned dch = 16u * (unsigned)((lane & 3) ^ ((lane >> 4) & 3));      // source chunk of this lane's position
-  int xrow[2], wrow[3];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int rr = 16 * (2 * wave + i) + drow;
-    xrow[i] = rr < rows_here ? rr : rows_here - 1;               // clamped: rows past R are never stored
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) wrow[q] = 16 * ((3 * wave + q) & 7) + drow;
-  const int KT = a.K / 32, T = KT + PS_F / 32;
+  // ---- DMA lane geometry: one instruction = 8 rows x 128 bytes (whole lines); lane -> (row l >> 3, chunk position l & 7).
+  // LDS rows are 128 bytes, chunk position = chunk ^ ((row >> 1) & 7): the 16 rows of a ds_read_b128 lane group fall on
+  // 16 different 16-byte slots of the 256-byte bank row.  row = 8*j + (l >> 3): (row >> 1) & 7 = (l >> 4) ^ 4*(j & 1).
+  const int drow = lane >> 3;
+  const unsigned dpos = (unsigned)((lane & 7) ^ (lane >> 4));
+  const int KT = a.K / PS_BK, T = KT + PS_F / PS_BK;
 
   auto issue = [&](int t) {
     const unsigned sb = lds0 + (unsigned)((t % PS_NSTAGE) * PS_STAGE);
     const bool tail = t >= KT;                                   // x Wx^T stages
     const int u = tail ? t - KT : t;
-    const char* xb = tail ? a.x + (r0 * a.ld_x + 32ll * u) * 2 : a.agg + (r0 * a.ld_agg + 32ll * u) * 2;
+    const char* xb = tail ? a.x + (r0 * a.ld_x + (long long)PS_BK * u) * 2 : a.agg + (r0 * a.ld_agg + (long long)PS_BK * u) * 2;
     const unsigned ldx = (unsigned)((tail ? a.ld_x : a.ld_agg) * 2);
+    int drow_o = drow;
+    unsigned dpos_o = dpos;
+    asm volatile("" : "+v"(drow_o), "+v"(dpos_o));     // opaque: per-lane byte offsets are recomputed, not hoisted as live registers
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ps_dma((unsigned)xrow[i] * ldx + dch, xb, sb + 1024u * (unsigned)(2 * wave + i));
+    for (int i = 0; i < 4; ++i) {                      // X: 32 instructions, wave w takes j = 4w .. 4w+3
+      const int j = 4 * wave + i;
+      int rr = 8 * j + drow_o;
+      rr = rr < rows_here ? rr : rows_here - 1;        // clamped: rows past R are never stored
+      ps_dma((unsigned)rr * ldx + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), xb, sb + 1024u * (unsigned)j);
+    }
     const unsigned ldw = tail ? 2u * PS_F : 6u * (unsigned)a.K;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int i = 3 * wave + q, s = i >> 3;                    // wave-uniform: W_s, rows 16*(i & 7)..
+    for (int q = 0; q < 6; ++q) {                      // W: 3 sets x 16 instructions, wave w takes i = 6w .. 6w+5
+      const int i = 6 * wave + q, s = i >> 4, j = i & 15;
       // W_s[n, k] of the agg stages sits at wcat[n, ((k >> 7) * 3 + s) * 128 + (k & 127)] (virtual-chunk order of
       // tg_pna_fold_fwd); the tail stages read Wx for every set (only set 0 is multiplied)
-      const char* wb = tail ? a.wx + 64ll * u : a.wcat + (((long long)(u >> 2) * 3 + s) * 128 + 32ll * (u & 3)) * 2;
-      ps_dma((unsigned)wrow[q] * ldw + dch, wb, sb + (unsigned)PS_XB + 1024u * (unsigned)i);
+      const char* wb = tail ? a.wx + 2ll * PS_BK * u
+                            : a.wcat + (((long long)(u >> 1) * 3 + s) * 128 + (long long)PS_BK * (u & 1)) * 2;
+      ps_dma((unsigned)(8 * j + drow_o) * ldw + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), wb,
+             sb + (unsigned)PS_XB + 1024u * (unsigned)i);
     }
   };
 
@@ -121,45 +129,43 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
 
   // fragment lane offsets inside a piece: row r = lane & 31, 16-byte chunk 2*ks + (lane >> 5), swizzled
   const int fr = lane & 31, fh = lane >> 5;
-  int fo[2];
+  int fo[4];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) fo[ks] = 64 * fr + 16 * ((2 * ks + fh) ^ ((fr >> 2) & 3));
+  for (int ks = 0; ks < 4; ++ks) fo[ks] = PS_ROWB * fr + 16 * ((2 * ks + fh) ^ ((fr >> 1) & 7));
 
-  // one stage: wait for its DMA (the next stage's 5 instructions stay in flight), one barrier, issue stage t+2 into the
-  // buffer every wave has just left, then the MFMAs.  NSET = 3 on the agg stages, 1 on the x Wx^T stages.
+  // one stage: its DMA was issued a stage ago — wait for it, one barrier (every wave is also done with the other
+  // buffer), issue the next stage into that buffer, then the MFMAs.  NSET = 3 on the agg stages, 1 on the x Wx^T stages.
 #define PS_STAGE_BODY(NSET)                                                                           \
   {                                                                                                   \
-    if (t + 1 < T) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                   \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
     if (!(PS_ABL & 4)) __builtin_amdgcn_s_barrier();                                                  \
     asm volatile("" ::: "memory");                                                                    \
-    if (!(PS_ABL & 2) && t + 2 < T) issue(t + 2);                                                     \
-    const char* xs = smem + (t % PS_NSTAGE) * PS_STAGE + (wr * 64) * 64;                              \
-    const char* ws = smem + (t % PS_NSTAGE) * PS_STAGE + PS_XB + (wn * 64) * 64;                      \
+    if (!(PS_ABL & 2) && t + 1 < T) issue(t + 1);                                                     \
+    const char* xs = smem + (t % PS_NSTAGE) * PS_STAGE + (wr * 64) * PS_ROWB;                         \
+    const char* ws = smem + (t % PS_NSTAGE) * PS_STAGE + PS_XB + (wn * 64) * PS_ROWB;                 \
     /* rolling fragment prefetch, one (k-step, set) group ahead: the reads of group g+1 are issued before the four   \
        MFMAs of group g (32 fragment registers: two A pairs, two B pairs) */                                          \
     ps_v8bf bA[2][2], aA[2][2];                                                                       \
-    bA[0][0] = ps_frag(xs + fo[0]); bA[0][1] = ps_frag(xs + 32 * 64 + fo[0]);                         \
-    aA[0][0] = ps_frag(ws + fo[0]); aA[0][1] = ps_frag(ws + 32 * 64 + fo[0]);                         \
-    _Pragma("unroll") for (int g = 0; g < 2 * (NSET); ++g) {                                          \
+    bA[0][0] = ps_frag(xs + fo[0]); bA[0][1] = ps_frag(xs + 32 * PS_ROWB + fo[0]);                    \
+    aA[0][0] = ps_frag(ws + fo[0]); aA[0][1] = ps_frag(ws + 32 * PS_ROWB + fo[0]);                    \
+    _Pragma("unroll") for (int g = 0; g < 4 * (NSET); ++g) {                                          \
       const int ks = g / (NSET), sg = g % (NSET);                                                     \
-      if (g + 1 < 2 * (NSET)) {                                                                       \
+      if (g + 1 < 4 * (NSET)) {                                                                       \
         const int ks2 = (g + 1) / (NSET), s2 = (g + 1) % (NSET);                                      \
         aA[(g + 1) & 1][0] = ps_frag(ws + s2 * PS_WB + fo[ks2]);                                      \
-        aA[(g + 1) & 1][1] = ps_frag(ws + s2 * PS_WB + 32 * 64 + fo[ks2]);                            \
-        if (s2 == 0) { bA[1][0] = ps_frag(xs + fo[1]); bA[1][1] = ps_frag(xs + 32 * 64 + fo[1]); }    \
+        aA[(g + 1) & 1][1] = ps_frag(ws + s2 * PS_WB + 32 * PS_ROWB + fo[ks2]);                       \
+        if (s2 == 0) { bA[ks2 & 1][0] = ps_frag(xs + fo[ks2]); bA[ks2 & 1][1] = ps_frag(xs + 32 * PS_ROWB + fo[ks2]); } \
       }                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                              \
-      if (PS_ABL & 1) { acc[sg][0][0][0] += (float)aA[g & 1][0][0] + (float)aA[g & 1][1][0] + (float)bA[ks][0][0] + (float)bA[ks][1][0]; continue; } \
-      acc[sg][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][0], bA[ks][0], acc[sg][0][0], 0, 0, 0); \
-      acc[sg][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][0], bA[ks][1], acc[sg][0][1], 0, 0, 0); \
-      acc[sg][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][1], bA[ks][0], acc[sg][1][0], 0, 0, 0); \
-      acc[sg][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][1], bA[ks][1], acc[sg][1][1], 0, 0, 0); \
+      if (PS_ABL & 1) { acc[sg][0][0][0] += (float)aA[g & 1][0][0] + (float)aA[g & 1][1][0] + (float)bA[ks & 1][0][0] + (float)bA[ks & 1][1][0]; continue; } \
+      acc[sg][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][0], bA[ks & 1][0], acc[sg][0][0], 0, 0, 0); \
+      acc[sg][0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][0], bA[ks & 1][1], acc[sg][0][1], 0, 0, 0); \
+      acc[sg][1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][1], bA[ks & 1][0], acc[sg][1][0], 0, 0, 0); \
+      acc[sg][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][1], bA[ks & 1][1], acc[sg][1][1], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                              \
     }                                                                                                 \
   }
   issue(0);
-  if (T > 1) issue(1);
   int t = 0;
   for (; t < KT; ++t) PS_STAGE_BODY(3)
   for (; t < T; ++t) PS_STAGE_BODY(1)
