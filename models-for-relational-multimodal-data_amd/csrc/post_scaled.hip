@@ -22,11 +22,15 @@
 //     different 16-byte slots; the DMA applies the swizzle on the SOURCE side (lane -> global chunk),
 //   * x Wx^T rides in accumulator set 0 as four more stages (X from x, W from Wx), bias in the epilogue: the separate
 //     GEMM launch and the read-modify-write of `out` go.
-// Measured at R = 524 k (tools/nt_scaled_probe.py): 313 us = 714 TFLOP/s (the two launches it replaces: 380 + 75 us).
-// PS_ABL builds: without the MFMAs 226 us (the data path: 640 half-used 128-byte lines per stage through the TA),
-// without the DMA 216 us, without DMA and fragment reads 190 us (one workgroup per CU: dispatch, prologue and epilogue
-// are not overlapped).  A persistent variant with cross-tile prefetch measured 325 us and is not kept: the MFMA waves
-// also issue the DMA and stall at the TA, so the two paths do not overlap; next are full-line DMA and producer waves.
+// Measured at R = 524 k (tools/nt_scaled_probe.py): 299 us = 746 TFLOP/s (the two launches it replaces: 380 + 75 us;
+// the first version with 32-k stages and half-used lines: 313 us).  PS_ABL builds of that first version: without the
+// MFMAs 226 us, without the DMA 216 us, without DMA and fragment reads 190 us — and 190 us of pure MFMA + barriers is
+// already 74 % of what the MFMA pipe delivers at the clock these kernels run at (~1.5 GHz under MFMA load).
+// Also measured on the 64-k version and not kept: a persistent workgroup per CU with stage 0 of the next tile in flight
+// under the epilogue (296 us: the per-tile dispatch / prologue is not what is missing) and the next stage's ten DMA
+// instructions spread between the MFMA groups instead of issued at the stage top (318 us: each asm statement with its
+// M0 save / restore and `s_nop` breaks the rolling fragment prefetch).  What is left is producer waves (the consumers
+// would have to fit 232 registers) and a deeper ring than 160 KB allows at this tile.
 #include "common.hpp"
 #include "../../include/tabgnn_hip.h"
 
@@ -77,7 +81,8 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave & 3, wn = wave >> 2;                       // wave tile: rows 64*wr.., columns 64*wn..
-  const long long n_tiles = (a.R + PS_ROWS - 1) / PS_ROWS;
+  const long long r0 = (long long)blockIdx.x * PS_ROWS;
+  const int rows_here = (int)(a.R - r0 < PS_ROWS ? a.R - r0 : PS_ROWS);
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
 
   // ---- DMA lane geometry: one instruction = 8 rows x 128 bytes (whole lines); lane -> (row l >> 3, chunk position l & 7).
@@ -87,37 +92,44 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
   const unsigned dpos = (unsigned)((lane & 7) ^ (lane >> 4));
   const int KT = a.K / PS_BK, T = KT + PS_F / PS_BK;
 
-  // the wave's DMA instructions lo .. hi-1 (of PS_NDMA = 10: four X pieces, six W pieces) of stage t of row tile `tile`
-  auto issue = [&](long long tile, int t, int buf, int lo, int hi) {
-    const long long r0 = tile * PS_ROWS;
-    const int rows_here = (int)(a.R - r0 < PS_ROWS ? a.R - r0 : PS_ROWS);
-    const unsigned sb = lds0 + (unsigned)(buf * PS_STAGE);
+  auto issue = [&](int t) {
+    const unsigned sb = lds0 + (unsigned)((t % PS_NSTAGE) * PS_STAGE);
     const bool tail = t >= KT;                                   // x Wx^T stages
     const int u = tail ? t - KT : t;
     const char* xb = tail ? a.x + (r0 * a.ld_x + (long long)PS_BK * u) * 2 : a.agg + (r0 * a.ld_agg + (long long)PS_BK * u) * 2;
     const unsigned ldx = (unsigned)((tail ? a.ld_x : a.ld_agg) * 2);
-    const unsigned ldw = tail ? 2u * PS_F : 6u * (unsigned)a.K;
     int drow_o = drow;
     unsigned dpos_o = dpos;
     asm volatile("" : "+v"(drow_o), "+v"(dpos_o));     // opaque: per-lane byte offsets are recomputed, not hoisted as live registers
 #pragma unroll
-    for (int idx = lo; idx < hi; ++idx) {
-      if (idx < 4) {                                   // X: 32 instructions, wave w takes j = 4w .. 4w+3
-        const int j = 4 * wave + idx;
-        int rr = 8 * j + drow_o;
-        rr = rr < rows_here ? rr : rows_here - 1;      // clamped: rows past R are never stored
-        ps_dma((unsigned)rr * ldx + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), xb, sb + 1024u * (unsigned)j);
-      } else {                                         // W: 3 sets x 16 instructions, wave w takes i = 6w .. 6w+5
-        const int i = 6 * wave + (idx - 4), s = i >> 4, j = i & 15;
-        // W_s[n, k] of the agg stages sits at wcat[n, ((k >> 7) * 3 + s) * 128 + (k & 127)] (virtual-chunk order of
-        // tg_pna_fold_fwd); the tail stages read Wx for every set (only set 0 is multiplied)
-        const char* wb = tail ? a.wx + 2ll * PS_BK * u
-                              : a.wcat + (((long long)(u >> 1) * 3 + s) * 128 + (long long)PS_BK * (u & 1)) * 2;
-        ps_dma((unsigned)(8 * j + drow_o) * ldw + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), wb,
-               sb + (unsigned)PS_XB + 1024u * (unsigned)i);
-      }
+    for (int i = 0; i < 4; ++i) {                      // X: 32 instructions, wave w takes j = 4w .. 4w+3
+      const int j = 4 * wave + i;
+      int rr = 8 * j + drow_o;
+      rr = rr < rows_here ? rr : rows_here - 1;        // clamped: rows past R are never stored
+      ps_dma((unsigned)rr * ldx + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), xb, sb + 1024u * (unsigned)j);
+    }
+    const unsigned ldw = tail ? 2u * PS_F : 6u * (unsigned)a.K;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {                      // W: 3 sets x 16 instructions, wave w takes i = 6w .. 6w+5
+      const int i = 6 * wave + q, s = i >> 4, j = i & 15;
+      // W_s[n, k] of the agg stages sits at wcat[n, ((k >> 7) * 3 + s) * 128 + (k & 127)] (virtual-chunk order of
+      // tg_pna_fold_fwd); the tail stages read Wx for every set (only set 0 is multiplied)
+      const char* wb = tail ? a.wx + 2ll * PS_BK * u
+                            : a.wcat + (((long long)(u >> 1) * 3 + s) * 128 + (long long)PS_BK * (u & 1)) * 2;
+      ps_dma((unsigned)(8 * j + drow_o) * ldw + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), wb,
+             sb + (unsigned)PS_XB + 1024u * (unsigned)i);
     }
   };
+
+  ps_f32x16 acc[3][2][2];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[s][p][b][i] = 0.f;
 
   // fragment lane offsets inside a piece: row r = lane & 31, 16-byte chunk 2*ks + (lane >> 5), swizzled
   const int fr = lane & 31, fh = lane >> 5;
@@ -129,14 +141,12 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
   // buffer), issue the next stage into that buffer, then the MFMAs.  NSET = 3 on the agg stages, 1 on the x Wx^T stages.
 #define PS_STAGE_BODY(NSET)                                                                           \
   {                                                                                                   \
-    /* the stage's DMA is older than the previous tile's 8 output stores: those may stay in flight */ \
-    if (t == 0 && !first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
     if (!(PS_ABL & 4)) __builtin_amdgcn_s_barrier();                                                  \
     asm volatile("" ::: "memory");                                                                    \
-    const bool more = !(PS_ABL & 2) && t + 1 < T;                                                     \
-    const char* xs = smem + ring * PS_STAGE + (wr * 64) * PS_ROWB;                                    \
-    const char* ws = smem + ring * PS_STAGE + PS_XB + (wn * 64) * PS_ROWB;                            \
+    if (!(PS_ABL & 2) && t + 1 < T) issue(t + 1);                                                     \
+    const char* xs = smem + (t % PS_NSTAGE) * PS_STAGE + (wr * 64) * PS_ROWB;                         \
+    const char* ws = smem + (t % PS_NSTAGE) * PS_STAGE + PS_XB + (wn * 64) * PS_ROWB;                 \
     /* rolling fragment prefetch, one (k-step, set) group ahead: the reads of group g+1 are issued before the four   \
        MFMAs of group g (32 fragment registers: two A pairs, two B pairs) */                                          \
     ps_v8bf bA[2][2], aA[2][2];                                                                       \
@@ -150,9 +160,6 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
         aA[(g + 1) & 1][1] = ps_frag(ws + s2 * PS_WB + 32 * PS_ROWB + fo[ks2]);                       \
         if (s2 == 0) { bA[ks2 & 1][0] = ps_frag(xs + fo[ks2]); bA[ks2 & 1][1] = ps_frag(xs + 32 * PS_ROWB + fo[ks2]); } \
       }                                                                                               \
-      /* the next stage's DMA, spread over the groups: a burst of ten at the stage top fills the TA queue and the   \
-         issuing wave sits in it instead of feeding the MFMA pipe */                                                \
-      if (more) issue(tile, t + 1, ring ^ 1, g * PS_NDMA / (4 * (NSET)), (g + 1) * PS_NDMA / (4 * (NSET)));         \
       __builtin_amdgcn_sched_barrier(0);                                                              \
       if (PS_ABL & 1) { acc[sg][0][0][0] += (float)aA[g & 1][0][0] + (float)aA[g & 1][1][0] + (float)bA[ks & 1][0][0] + (float)bA[ks & 1][1][0]; continue; } \
       acc[sg][0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][0], bA[ks & 1][0], acc[sg][0][0], 0, 0, 0); \
@@ -161,32 +168,13 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
       acc[sg][1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA[g & 1][1], bA[ks & 1][1], acc[sg][1][1], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                                              \
     }                                                                                                 \
-    ring ^= 1;                                                                                        \
   }
-  // ---- persistent: one workgroup per CU walks its row tiles; the buffer index runs on across tiles and stage 0 of the
-  // next tile is in flight under the epilogue of this one (the other buffer restages the output tile)
-  int ring = 0;
-  bool first = true;
-  long long tile = blockIdx.x;
-  if (tile < n_tiles) issue(tile, 0, 0, 0, PS_NDMA);
-  for (; tile < n_tiles; tile += gridDim.x, first = false) {
-  const long long r0 = tile * PS_ROWS;
-  const int rows_here = (int)(a.R - r0 < PS_ROWS ? a.R - r0 : PS_ROWS);
-  ps_f32x16 acc[3][2][2];
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[s][p][b][i] = 0.f;
+  issue(0);
   int t = 0;
   for (; t < KT; ++t) PS_STAGE_BODY(3)
   for (; t < T; ++t) PS_STAGE_BODY(1)
-  __syncthreads();                                               // every wave is done reading both buffers
-  if (!(PS_ABL & 2) && tile + gridDim.x < n_tiles) issue(tile + gridDim.x, 0, ring, 0, PS_NDMA);
-  char* const ob = smem + (ring ^ 1) * PS_STAGE;                 // the free buffer restages the output tile
+#undef PS_STAGE_BODY
+  __syncthreads();                                               // every wave is done reading the ring
 
   // ---- epilogue.  C/D map of a 32x32 tile: column (-> row r) = lane & 31, row (-> feature n) = (reg & 3) +
   // 8*(reg >> 2) + 4*(lane >> 5): 4 consecutive n per register group.  amp / att are per-lane scalars.
@@ -209,7 +197,7 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
         uint2 pk;
         pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
         pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(ob + ps_out_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;
+        *reinterpret_cast<uint2*>(smem + ps_out_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;
       }
     }
   }
@@ -219,10 +207,8 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
     const int piece = tid + PS_THREADS * p, row = piece >> 4, ch = piece & 15;
     if (row < rows_here)
       *reinterpret_cast<uint4*>(a.out + (r0 + row) * a.ld_out + ch * 8) =
-          *reinterpret_cast<const uint4*>(ob + ps_out_off(row, ch));
+          *reinterpret_cast<const uint4*>(smem + ps_out_off(row, ch));
   }
-  }   // tiles (the barrier at the top of the next tile's first stage orders these LDS reads before the next DMA into `ob`)
-#undef PS_STAGE_BODY
 }
 
 }  // namespace tg
@@ -257,15 +243,7 @@ extern "C" int tg_pna_post_fwd_bf16(const void* agg, const void* x, const void* 
   a.agg = (const char*)agg; a.x = (const char*)x; a.wcat = (const char*)wcat; a.wx = (const char*)wx;
   a.bias = bias; a.scales = scales; a.out = (unsigned short*)out;
   a.R = R; a.ld_agg = ld_agg; a.ld_x = ld_x; a.ld_out = ld_out; a.K = K;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);       // persistent: one workgroup per CU walks its tiles
-  hipLaunchKernelGGL(k_pna_post_fwd, dim3(grid), dim3(PS_THREADS), PS_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(k_pna_post_fwd, dim3((unsigned)tiles), dim3(PS_THREADS), PS_LDS, (hipStream_t)stream, a);
   TG_LAUNCH_CHECK();
   return 0;
 }
