@@ -478,6 +478,156 @@ __global__ void __launch_bounds__(256) k_attn_mfma_bwd_dkv(const AmArgs a_) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- backward, one pass
+// dQ, dK and dV from ONE recompute of S^T / P^T / dP^T per (key tile, query tile) pair: a wave owns a whole (row, head),
+// walks the key tiles outside and the query tiles inside (as the dKV kernel does for its one key tile), and keeps the
+// dQ^T accumulator tiles of ALL query tiles of the row in wave-private LDS (fp32, the HD/2 accumulator registers a lane
+// really uses, chunk-major so that lanes are 16 bytes apart): a tile is loaded as the C operand of its two MFMAs and
+// written back.  Saves the second recompute (the dQ kernel: 8.9 of 21.5 ms of attention backward on tabgnn-arxiv).
+// LDS sets the shapes: HD = 16 with up to 5 query tiles (S <= 160): 4 waves x (4 tiles + 10 KiB of accumulators) = 80 KiB,
+// two workgroups per CU — the occupancy the dKV kernel has; HD = 32 with up to 3 query tiles (S <= 96): 3 waves x
+// (4 tiles + 12 KiB) = 66 KiB, two workgroups per CU (6 waves instead of 8).  Longer rows keep the two kernels.
+template <int HD> constexpr int am_one_ntmax() { return HD == 16 ? 5 : 3; }
+template <int HD> constexpr int am_one_waves() { return HD == 16 ? 4 : 3; }
+template <int HD> constexpr int am_one_wave_lds() { return 4 * AM_TILE + am_one_ntmax<HD>() * 64 * (HD / 2) * 4; }
+
+template <int HD, int DROP>
+__global__ void __launch_bounds__(64 * am_one_waves<HD>()) k_attn_mfma_bwd_one(const AmArgs a_) {
+  constexpr int WAVES = am_one_waves<HD>();
+  AmArgs a = a_;
+  a.seed = live_seed(a_.seed);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int DQC = HD / 8;                          // 16-byte chunks of accumulator registers per lane and tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tl = lane & 31, h = lane >> 5;
+  char* tq_tile = smem + wave * am_one_wave_lds<HD>();   // Q tile (row-major), dO tile, transpose tile, K tile, dQ accumulators
+  char* tdo_tile = tq_tile + AM_TILE;
+  char* tt = tq_tile + 2 * AM_TILE;
+  char* tk_tile = tq_tile + 3 * AM_TILE;
+  char* dq_acc = tq_tile + 4 * AM_TILE + 16 * lane;      // chunk c of query tile qt: + ((qt * DQC + c) * 64) * 16
+  const int troff = AM_ROWB * (4 * h + ((lane & 15) >> 2)) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  char* tw = tt + AM_ROWB * tl + 8 * h;
+  const char* ttr = tt + troff;
+  constexpr int NS = HD / 16;
+  const int S = a.S, H = a.H, C = a.C, ld = 3 * C;
+  const int nt = (S + 31) / 32;
+  const long long n_items = a.R * H;
+  const float c2 = a.scale * 1.4426950408889634f;
+  const float keep = DROP ? a.inv_keep : 1.f;
+  for (long long rh = (long long)blockIdx.x * WAVES + wave; rh < n_items; rh += (long long)gridDim.x * WAVES) {
+    const int hd = (int)(rh % H);
+    const long long r = rh / H;
+    const long long t0 = r * S, t_last = t0 + S - 1;
+    AmKeys kk{};
+    if constexpr (DROP == 1) kk = am_keys((unsigned long long)rh * S * (unsigned long long)S, a);
+    for (int kt = 0; kt < nt; ++kt) {
+      const int key = 32 * kt + tl;
+      const long long tk = t0 + (key < S ? key : S - 1);
+      am_v8bf kf[NS], vf[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        kf[s] = am_load_frag(a.qkv, tk, ld, C + hd * HD + 16 * s + 8 * h);
+        vf[s] = am_load_frag(a.qkv, tk, ld, 2 * C + hd * HD + 16 * s + 8 * h);
+      }
+      {
+        AmStage<HD> ks;                                                          // K tile -> K^T fragments of the dQ product
+        am_stage_load<HD>(ks, a.qkv, t0 + 32 * kt, t_last, ld, C + hd * HD, lane);
+        am_stage_write<HD>(ks, tk_tile, lane);
+      }
+      am_f32x16 dk = am_zero(), dv = am_zero();
+      am_v8bf qf_n[NS], dof_n[NS], of_n[NS];
+      AmStage<HD> qs_n, dos_n;
+      float lse_n;
+#define AM_ONE_LOAD(QT)                                                                               \
+      {                                                                                               \
+        const int q_ = 32 * (QT) + tl;                                                                \
+        const long long tq_ = t0 + (q_ < S ? q_ : S - 1);                                             \
+        _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                              \
+          qf_n[s] = am_load_frag(a.qkv, tq_, ld, hd * HD + 16 * s + 8 * h);                           \
+          dof_n[s] = am_load_frag(a.dout, tq_, C, hd * HD + 16 * s + 8 * h);                          \
+          of_n[s] = am_load_frag(a.o, tq_, C, hd * HD + 16 * s + 8 * h);                              \
+        }                                                                                             \
+        am_stage_load<HD>(qs_n, a.qkv, t0 + 32 * (QT), t_last, ld, hd * HD, lane);                    \
+        am_stage_load<HD>(dos_n, a.dout, t0 + 32 * (QT), t_last, C, hd * HD, lane);                   \
+        lse_n = q_ < S ? a.lse[rh * S + q_] * 1.4426950408889634f : INFINITY;                         \
+      }
+      AM_ONE_LOAD(0)
+      for (int qt = 0; qt < nt; ++qt) {
+        const int q = 32 * qt + tl;
+        const bool q_ok = q < S;
+        am_v8bf qf[NS], dof[NS];
+        float delta = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          qf[s] = qf_n[s]; dof[s] = dof_n[s];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) delta += (float)dof_n[s][j] * (float)of_n[s][j];
+        }
+        delta += am_xor32(delta);
+        const float lse2 = lse_n;
+        am_stage_write<HD>(qs_n, tq_tile, lane);
+        am_stage_write<HD>(dos_n, tdo_tile, lane);
+        if (qt + 1 < nt) AM_ONE_LOAD(qt + 1)
+        am_f32x16 pd, ds;
+        const unsigned long long e0 = ((unsigned long long)rh * S + (unsigned long long)(q_ok ? q : 0)) * (unsigned long long)S
+                                      + (unsigned long long)(32 * kt + 4 * h);
+        am_bwd_front<HD, DROP>(kf, qf, vf, dof, lse2, delta, c2, a.scale, keep, 32 * kt, h, S, e0, kk, a, pd, ds);
+        // dQ^T[d, q] += K^T[d, key] dS^T[key, q]: the tile's accumulator lives in LDS between key tiles
+        am_f32x16 dq = am_zero();
+        char* dqp = dq_acc + qt * (DQC * 64 * 16);
+        if (kt > 0) {
+#pragma unroll
+          for (int c = 0; c < DQC; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(dqp + c * 64 * 16);
+            dq[4 * c] = v.x; dq[4 * c + 1] = v.y; dq[4 * c + 2] = v.z; dq[4 * c + 3] = v.w;
+          }
+        }
+        dq = AM_MFMA(am_tr_frag(tk_tile + troff, 0), am_pack<0>(ds), dq);
+        dq = AM_MFMA(am_tr_frag(tk_tile + troff, 1), am_pack<1>(ds), dq);
+#pragma unroll
+        for (int c = 0; c < DQC; ++c)
+          *reinterpret_cast<float4*>(dqp + c * 64 * 16) = make_float4(dq[4 * c], dq[4 * c + 1], dq[4 * c + 2], dq[4 * c + 3]);
+        am_v8bf p0, p1, s0, s1;
+        am_transpose32(am_pack<0>(pd), am_pack<1>(pd), tw, ttr, p0, p1);          // Pd [k = q][col = key]
+        am_transpose32(am_pack<0>(ds), am_pack<1>(ds), tw, ttr, s0, s1);          // dS [k = q][col = key]
+        dv = AM_MFMA(am_tr_frag(tdo_tile + troff, 0), p0, dv);                    // dV^T[d, key] += dO^T[d, q] Pd[q, key]
+        dv = AM_MFMA(am_tr_frag(tdo_tile + troff, 1), p1, dv);
+        dk = AM_MFMA(am_tr_frag(tq_tile + troff, 0), s0, dk);                     // dK^T[d, key] += Q^T[d, q] dS[q, key]
+        dk = AM_MFMA(am_tr_frag(tq_tile + troff, 1), s1, dk);
+      }
+#undef AM_ONE_LOAD
+      if (key < S) {
+        unsigned short* drow = a.dqkv + (t0 + key) * ld + hd * HD + 4 * h;
+#pragma unroll
+        for (int g = 0; g < HD / 8; ++g) {
+          typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          v4f v, w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] = dk[4 * g + j]; w[j] = dv[4 * g + j]; }
+          *reinterpret_cast<uint2*>(drow + C + 8 * g) = __builtin_bit_cast(uint2, __builtin_convertvector(v, v4bf));
+          *reinterpret_cast<uint2*>(drow + 2 * C + 8 * g) = __builtin_bit_cast(uint2, __builtin_convertvector(w, v4bf));
+        }
+      }
+    }
+    for (int qt = 0; qt < nt; ++qt) {                    // the row's dQ tiles: fp32 accumulators -> bf16 rows
+      const int q = 32 * qt + tl;
+      if (q < S) {
+        unsigned short* drow = a.dqkv + (t0 + q) * ld + hd * HD + 4 * h;
+        const char* dqp = dq_acc + qt * (DQC * 64 * 16);
+#pragma unroll
+        for (int g = 0; g < DQC; ++g) {
+          typedef __bf16 v4bf __attribute__((ext_vector_type(4)));
+          typedef float v4f __attribute__((ext_vector_type(4)));
+          const float4 t = *reinterpret_cast<const float4*>(dqp + g * 64 * 16);
+          v4f v;
+          v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          *reinterpret_cast<uint2*>(drow + 8 * g) = __builtin_bit_cast(uint2, __builtin_convertvector(v, v4bf));
+        }
+      }
+    }
+  }
+}
+
 template <int HD, int DROP> static void am_launch(const AmArgs& a, int which, hipStream_t st) {
   const int nt = (a.S + 31) / 32;
   const long long items = a.R * a.H * nt;
@@ -486,6 +636,28 @@ template <int HD, int DROP> static void am_launch(const AmArgs& a, int which, hi
   if (which == 0) hipLaunchKernelGGL((k_attn_mfma_fwd<HD, DROP>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else if (which == 1) hipLaunchKernelGGL((k_attn_mfma_bwd_dq<HD, DROP>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((k_attn_mfma_bwd_dkv<HD, DROP>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+}
+template <int HD, int DROP> static void am_launch_one(const AmArgs& a, hipStream_t st) {
+  constexpr int WAVES = am_one_waves<HD>();
+  const int lds = WAVES * am_one_wave_lds<HD>();
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_mfma_bwd_one<HD, DROP>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr = true;
+  }
+  const long long items = a.R * a.H;
+  long long blocks = (items + WAVES - 1) / WAVES;
+  if (blocks > 256 * 2) blocks = 256 * 2;          // two resident workgroups per CU, every wave walks its (row, head) items
+  hipLaunchKernelGGL((k_attn_mfma_bwd_one<HD, DROP>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, a);
+}
+template <int HD> static void am_launch_one_d(const AmArgs& a, hipStream_t st) {
+  switch (drop_mode(a.thresh)) {
+    case 0: am_launch_one<HD, 0>(a, st); break;
+    case 1: am_launch_one<HD, 1>(a, st); break;
+    case 8: am_launch_one<HD, 8>(a, st); break;
+    default: am_launch_one<HD, 16>(a, st); break;
+  }
 }
 template <int HD> static void am_launch_d(const AmArgs& a, int which, hipStream_t st) {
   switch (drop_mode(a.thresh)) {
@@ -516,7 +688,11 @@ void attn_mfma_bwd(const void* qkv, const void* o, const void* dout, const float
   a.qkv = (const unsigned short*)qkv; a.o = (const unsigned short*)o; a.dout = (const unsigned short*)dout;
   a.lse = const_cast<float*>(lse); a.dqkv = (unsigned short*)dqkv; a.R = R; a.S = S; a.H = H; a.C = C;
   a.scale = scale; a.thresh = thresh; a.inv_keep = inv_keep; a.seed = seed; a.rstream = rstream;
-  if (C / H == 16) { am_launch_d<16>(a, 1, st); am_launch_d<16>(a, 2, st); }
+  static const bool two_pass = getenv("TABGNN_ATTN_TWO_PASS") != nullptr;     // same-box A/B switch
+  if (C / H == 16 && S <= 32 * am_one_ntmax<16>() && !two_pass) am_launch_one_d<16>(a, st);      // dQ, dK, dV from one recompute
+  // (HD = 32 with three-wave workgroups was measured on wide64-c256: 34.7 -> 34.5 ms/step — with dropout the kernel needs
+  //  > 128 registers and LDS for 6 waves per CU at most, which eats what the saved recompute gives; those rows keep two kernels)
+  else if (C / H == 16) { am_launch_d<16>(a, 1, st); am_launch_d<16>(a, 2, st); }
   else { am_launch_d<32>(a, 1, st); am_launch_d<32>(a, 2, st); }
 }
 
