@@ -108,3 +108,45 @@ def test_graph_replays_equal_eager_steps_bit_for_bit():
         assert torch.equal(e[i], g[i]), i
     for k in e[4]:
         assert torch.equal(e[4][k], g[4][k]), k
+
+
+def test_graph_step_with_data_parallel_keeps_allreduce_and_adam_eager():
+    """With a DataParallel the graph ends after the backward; the (RCCL) all-reduce and the Adam launch run eagerly
+    behind the replay and read the device-resident step record.  World size 1: the result must equal the all-in-graph
+    step bit for bit."""
+    import os
+    import torch.distributed as dist
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G, ops
+    B, steps = 64, 4
+    batches = [_resize(S.make_batch(B, seed=60 + i, device=DEV), 5 * i, 30 * i) for i in range(2)]
+    key = (G.bucket_size(max(b[1].shape[1] for b in batches)), G.bucket_size(max(b[0].num_rows for b in batches) + 1))
+    preps = [G.prepare(b, B, key=key) for b in batches]
+    frames = (batches[0][0], batches[0][2])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    os.environ["TABGNN_FORCE_ALLREDUCE"] = "1"
+    seed0 = ops.DropoutRNG.seed
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        out = {}
+        for mode in ("plain", "ddp"):
+            model, flat, opt, lw = _model(B, torch.bfloat16, seed=5)
+            ddp = T.DataParallel(model, flat) if mode == "ddp" else None
+            ops.DropoutRNG.seed = seed0                        # (DataParallel derives a per-rank seed: same for rank 0 here)
+            if ddp is not None:
+                assert ddp.active
+                ops.DropoutRNG.seed = seed0
+            step = G.GraphedTrainStep(model, flat, opt, lw, B, ddp=ddp)
+            step.host_seed = seed0
+            for i in range(steps):
+                loss, _ = step(preps[i % 2], frames)
+            torch.cuda.synchronize()
+            out[mode] = (flat.flat.clone().cpu(), opt.m.clone().cpu(), opt.t, float(loss), None if ddp is None else ddp.calls)
+            G.StepState.release()
+        assert out["ddp"][4] >= steps and out["plain"][2] == out["ddp"][2] == steps
+        assert torch.equal(out["plain"][0], out["ddp"][0]) and torch.equal(out["plain"][1], out["ddp"][1])
+    finally:
+        os.environ.pop("TABGNN_FORCE_ALLREDUCE", None)
+        ops.DropoutRNG.seed = seed0
+        dist.destroy_process_group()
