@@ -87,7 +87,9 @@ def _pack(tensors):
     for k, v in tensors.items():
         layout.append((k, v.dtype, tuple(v.shape), off))
         off += (v.numel() * v.element_size() + 255) // 256 * 256
-    arena = torch.empty(off, dtype=torch.uint8, device=dev)
+    # host arenas are pinned when a GPU is there: the step's one upload is then a true asynchronous copy
+    pin = dev.type == "cpu" and torch.cuda.is_available()
+    arena = torch.empty(off, dtype=torch.uint8, device=dev, pin_memory=pin)
     views = _views(arena, layout)
     for k, v in tensors.items():
         views[k].copy_(v, non_blocking=True)
@@ -142,6 +144,22 @@ def prepare(batch, n_seed, key=None):
                 t[f"{name}.{st.value}"] = _pad_rows(v, n)
     arena, _, layout = _pack(t)
     return Prepared((e_pad, n_pad), arena, layout, off, E, N, lazy)
+
+
+def prepare_sample(eid, edge_index, nodes, y, n_seed, key=None):
+    """The sampler's output (``NeighborSampler.sample``: edge ids, local ``edge_index``, node ids — host tensors, seed
+    edges first) and the seed labels as a bucket-form batch of LAZY frames: the frames' rows are ids into the
+    HBM-resident tables (``ColumnStore``), so a batch is ids + index parts, one pinned arena, one upload.  Pure host
+    work that releases the GIL in its heavy parts: run it in the sampler thread."""
+    E, N = int(eid.numel()), int(nodes.numel())
+    e_pad, n_pad = key if key is not None else (bucket_size(E), bucket_size(N + 1))
+    ei = pad_edges(edge_index, N, e_pad, n_pad)
+    flat, off, ei = host_batch_index(ei, n_pad, n_seed)
+    t = {"flat": torch.from_numpy(flat), "ei": torch.from_numpy(ei), "n_real": torch.tensor([N], dtype=torch.int32),
+         "y": y.reshape(-1).cpu(), "node.ids": _pad_rows(nodes.reshape(-1).cpu(), n_pad),
+         "edge.ids": _pad_rows(eid.reshape(-1).cpu(), e_pad)}
+    arena, _, layout = _pack(t)
+    return Prepared((e_pad, n_pad), arena, layout, off, E, N, True)
 
 
 class _Bucket:

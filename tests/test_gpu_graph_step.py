@@ -150,3 +150,42 @@ def test_graph_step_with_data_parallel_keeps_allreduce_and_adam_eager():
         os.environ.pop("TABGNN_FORCE_ALLREDUCE", None)
         ops.DropoutRNG.seed = seed0
         dist.destroy_process_group()
+
+
+def test_sampled_lazy_batches_replay_over_several_buckets():
+    """The whole loop of the reference at its default batch (ibm_transactions_for_aml.py:159-180 -> main.py:41-75):
+    native sampler -> prepare_sample (ids + index parts, padded to a bucket) -> one upload -> replay, with the frames
+    reading the HBM-resident tables by id.  Batches fall into several buckets; replays equal the eager runs of the same
+    body bit for bit."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G
+    from tabgnn_amd.frame import stype
+    from tabgnn_amd.sampler import ColumnStore, NeighborSampler
+    rs = np.random.RandomState(3)
+    N, E, B, steps = 4000, 30000, 32, 8
+    ei = np.stack([rs.randint(0, N, E), rs.randint(0, N, E)])
+    num, cat, ts = S.edge_table(E, 0)
+    labels = torch.from_numpy((rs.rand(E) < 0.05).astype(np.int64))
+    store = ColumnStore({stype.numerical: torch.from_numpy(num), stype.categorical: torch.from_numpy(cat),
+                         stype.timestamp: torch.from_numpy(ts)}, S.EDGE_COLS,
+                        {stype.relation: torch.ones(N, 1)}, S.NODE_COLS, labels).to(DEV)
+    sampler = NeighborSampler(ei, N, (6, 4), num_threads=1)
+    preps = []
+    for i in range(steps):
+        seeds = rs.choice(E, B, replace=False)
+        eid, lei, nodes = sampler.sample(seeds, i)
+        preps.append(G.prepare_sample(eid, lei, nodes, labels[eid[:B]], B))
+    assert preps[0].arena.is_pinned() and len({p.key for p in preps}) >= 2
+    frames = (T.TensorFrame(store.node_feats, store.node_cols, None, torch.zeros(1, dtype=torch.int64, device=DEV)),
+              T.TensorFrame(store.edge_feats, store.edge_cols, None, torch.zeros(1, dtype=torch.int64, device=DEV)))
+    runs = {}
+    for mode in ("eager", "graph"):
+        model, flat, opt, lw = _model(B, torch.bfloat16, seed=9)
+        step = G.GraphedTrainStep(model, flat, opt, lw, B)
+        losses = [(step.run_eager(p, frames) if mode == "eager" else step(p, frames))[0].clone() for p in preps]
+        torch.cuda.synchronize()
+        runs[mode] = (torch.stack(losses).float().cpu(), flat.flat.clone().cpu(), len(step.buckets))
+        G.StepState.release()
+    assert runs["graph"][2] == len({p.key for p in preps})
+    assert torch.isfinite(runs["eager"][0]).all()
+    assert torch.equal(runs["eager"][0], runs["graph"][0]) and torch.equal(runs["eager"][1], runs["graph"][1])
