@@ -193,9 +193,12 @@ class GraphedTrainStep:
     ``step(prepare(batch, n_seed))`` -> (loss, logits of the padded batch; rows [:n_seed] are the seed edges).  With a
     ``DataParallel`` the graph ends after the backward and the all-reduce + Adam run eagerly behind it."""
 
-    def __init__(self, model, flat, opt, loss_weight, n_seed, ddp=None, state=None, warmup=2):
+    def __init__(self, model, flat, opt, loss_weight, n_seed, ddp=None, state=None, warmup=2, index=True):
         self.model, self.flat, self.opt, self.loss_weight = model, flat, opt, loss_weight
         self.n_seed, self.ddp, self.warmup = int(n_seed), ddp, int(warmup)
+        # index=False: hand the wrapper the plain int64 edge_index (GNN / TABGNNS of utils.py take nothing else): the batch's
+        # CSRs are then built by the index kernels INSIDE the graph, from the bucket's static edge_index
+        self.index = bool(index)
         self.device = flat.flat.device
         self.state = state if state is not None else StepState(self.device, t=opt.t)
         self.buckets = {}
@@ -209,7 +212,8 @@ class GraphedTrainStep:
         self.state.advance(self.opt.lr, self.opt.betas)         # ... the device seed word makes the masks differ
         L.call("tg_set_bn_row_limit", L.ptr(b.static["n_real"]))       # read by BatchNorm's forward AND backward kernels
         try:
-            logits = self.model(b.node_tf, b.index(self.n_seed), b.edge_tf)
+            ops.take_index_errors()          # (flags of index structures built inside a captured body are not read back)
+            logits = self.model(b.node_tf, b.index(self.n_seed) if self.index else b.static["ei"], b.edge_tf)
             loss = ops.weighted_cross_entropy(logits[:self.n_seed], b.static["y"], self.loss_weight)
             loss.backward()
         finally:

@@ -189,3 +189,32 @@ def test_sampled_lazy_batches_replay_over_several_buckets():
     assert runs["graph"][2] == len({p.key for p in preps})
     assert torch.isfinite(runs["eager"][0]).all()
     assert torch.equal(runs["eager"][0], runs["graph"][0]) and torch.equal(runs["eager"][1], runs["graph"][1])
+
+
+def test_graph_step_for_a_wrapper_that_takes_the_plain_edge_index():
+    """``GNN(config)`` (utils.py:111-233, --model pna) only takes the int64 edge_index: with ``index=False`` the bucket's
+    static edge_index goes in and the CSR kernels run inside the graph.  Replays == eager runs, bit for bit."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G
+    B, steps = 48, 4
+    batches = [_resize(S.make_batch(B, seed=80 + i, device=DEV), 4 * i, 25 * i) for i in range(2)]
+    key = (G.bucket_size(max(b[1].shape[1] for b in batches)), G.bucket_size(max(b[0].num_rows for b in batches) + 1))
+    preps = [G.prepare(b, B, key=key) for b in batches]
+    frames = (batches[0][0], batches[0][2])
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(13)
+        cfg = S.make_config(128, 2, 4, B, head_dropout=0.083, compute_dtype=torch.bfloat16)
+        cfg.update(model="pna", emlps=True)
+        model = T.GNN(cfg).to(DEV).train()
+        flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+        opt = T.FusedAdam(flat, lr=1e-3)
+        lw = torch.tensor([1.0, 9.23], device=DEV)
+        step = G.GraphedTrainStep(model, flat, opt, lw, B, index=False)
+        losses = [(step.run_eager(preps[i % 2], frames) if mode == "eager" else step(preps[i % 2], frames))[0].clone()
+                  for i in range(steps)]
+        torch.cuda.synchronize()
+        runs[mode] = (torch.stack(losses).float().cpu(), flat.flat.clone().cpu())
+        G.StepState.release()
+    assert torch.isfinite(runs["eager"][0]).all() and float(runs["eager"][0][0]) != float(runs["eager"][0][2])
+    assert torch.equal(runs["eager"][0], runs["graph"][0]) and torch.equal(runs["eager"][1], runs["graph"][1])
