@@ -57,3 +57,29 @@ def test_prepare_keeps_the_real_rows_and_their_csr():
     if b2[1].shape[1] <= e_pad and b2[0].num_rows < n_pad:
         p2 = G.prepare(b2, B, key=p.key)
         assert (p2.off == p.off).all() and p2.tensors["flat"].shape == p.tensors["flat"].shape
+
+
+def test_prepare_sample_builds_a_lazy_bucket_batch_from_sampler_output():
+    from tabgnn_amd import graph_step as G
+    from tabgnn_amd.sampler import NeighborSampler
+    rs = np.random.RandomState(3)
+    N, E, B = 3000, 20000, 24
+    ei = np.stack([rs.randint(0, N, E), rs.randint(0, N, E)])
+    sampler = NeighborSampler(ei, N, (5, 3), num_threads=1)
+    labels = torch.from_numpy((rs.rand(E) < 0.1).astype(np.int64))
+    keys, layouts = set(), {}
+    for i in range(6):
+        eid, lei, nodes = sampler.sample(rs.choice(E, B, replace=False), i)
+        p = G.prepare_sample(eid, lei, nodes, labels[eid[:B]], B)
+        assert p.lazy and (p.e_real, p.n_real) == (eid.numel(), nodes.numel())
+        e_pad, n_pad = p.key
+        t = p.tensors
+        assert t["edge.ids"].shape == (e_pad,) and t["node.ids"].shape == (n_pad,) and t["y"].shape == (B,)
+        assert torch.equal(t["edge.ids"][:p.e_real], eid) and torch.equal(t["node.ids"][:p.n_real], nodes)
+        assert bool((t["edge.ids"][p.e_real:] == eid[0]).all())            # padding rows repeat a valid id
+        assert torch.equal(t["ei"][:, :p.e_real], lei) and int(t["n_real"][0]) == p.n_real
+        assert all(off % 256 == 0 for _, _, _, off in p.layout)            # every part 256-byte aligned in the arena
+        keys.add(p.key)
+        layouts.setdefault(p.key, p.layout)
+        assert layouts[p.key] == p.layout                                  # one layout per bucket: one static arena
+    assert 1 <= len(keys) <= 4
