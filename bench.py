@@ -287,7 +287,10 @@ def reference_batch(args, cdt, dev):
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "reference-batch-graph", "--dtype", args.dtype,
            "--hidden", str(args.hidden), "--layers", str(args.layers), "--nhead", str(args.nhead)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        env = {k: v for k, v in os.environ.items()      # the child is a plain single-process run on this GPU
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TABGNN_FORCE_ALLREDUCE",
+                            "TABGNN_DIST_BACKEND", "TABGNN_ONE_DEVICE", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK")}
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         g = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
     except Exception as e:      # noqa: BLE001 - reported, never fatal for the bench line
         r, g = None, None

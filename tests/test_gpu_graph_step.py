@@ -123,8 +123,11 @@ def test_graph_step_with_data_parallel_keeps_allreduce_and_adam_eager():
     key = (G.bucket_size(max(b[1].shape[1] for b in batches)), G.bucket_size(max(b[0].num_rows for b in batches) + 1))
     preps = [G.prepare(b, B, key=key) for b in batches]
     frames = (batches[0][0], batches[0][2])
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29571")
+    import socket
+    with socket.socket() as sk:                    # a free port: other tests of the suite start process groups too
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["TABGNN_FORCE_ALLREDUCE"] = "1"
     seed0 = ops.DropoutRNG.seed
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
