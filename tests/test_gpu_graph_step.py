@@ -127,6 +127,7 @@ def test_graph_step_with_data_parallel_keeps_allreduce_and_adam_eager():
     with socket.socket() as sk:                    # a free port: other tests of the suite start process groups too
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    saved_env = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["TABGNN_FORCE_ALLREDUCE"] = "1"
     seed0 = ops.DropoutRNG.seed
@@ -151,6 +152,11 @@ def test_graph_step_with_data_parallel_keeps_allreduce_and_adam_eager():
         assert torch.equal(out["plain"][0], out["ddp"][0]) and torch.equal(out["plain"][1], out["ddp"][1])
     finally:
         os.environ.pop("TABGNN_FORCE_ALLREDUCE", None)
+        for k, v in saved_env.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         ops.DropoutRNG.seed = seed0
         dist.destroy_process_group()
 
