@@ -312,6 +312,19 @@ int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void* z2, void*
                             void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S, int32_t tail,
                             float beta_c, float eps, float p_drop, uint64_t seed, const uint32_t* rs, float* lnp,
                             void* stream);
+/* The same half with the feed-forward WEIGHT GRADIENTS INSIDE the kernel (autograd of linear1 / linear2 of
+ * nn.TransformerEncoderLayer, src/nn/models/fused.py:83-92): writes d_x1 only; d_y2, h, d_hpre, x1 are staged in LDS and
+ * contracted over the workgroup's tokens by MFMA into per-workgroup fp32 partials — dwp [nblk][2][128][128] (dW1 | dW2,
+ * [out][in]) and dbp [nblk][2][128] (db1 | db2), nblk = tg_encoder_dw_blocks(R, S); lnp as above with the same nblk.
+ * tg_encoder_dw_reduce sums nw weights' partials in block order (deterministic) into out_w[i] / out_b[i] (NULL = skip;
+ * accumulate = 1: += , .grad semantics). */
+int64_t tg_encoder_dw_blocks(int64_t R, int32_t S);
+int tg_encoder_bwd_ffn_dw_bf16(const void* g, const void* z1, const void* z2, void* dx1, const void* wpack,
+                               const float* prm, int64_t R, int32_t S, int32_t tail, float beta_c, float eps,
+                               float p_drop, uint64_t seed, const uint32_t* rs, float* lnp, float* dwp, float* dbp,
+                               void* stream);
+int tg_encoder_dw_reduce(const float* dwp, const float* dbp, int64_t nblk, int32_t nw, float* const* out_w /*host [nw]*/,
+                         float* const* out_b /*host [nw]*/, int32_t accumulate, void* stream);
 /* backward of the fused layer, attention half (4 or 8 heads): d_x1 -> LayerNorm-1 backward -> output projection
  * backward -> attention backward with q / k / v / probabilities recomputed from x.  Writes dx (partial:
  * tg_gemm_nt_bf16 then adds d_qkv W_in), the operands of the weight-gradient GEMMs: dy, o [R,S,128] and dqkv [R,S,384],

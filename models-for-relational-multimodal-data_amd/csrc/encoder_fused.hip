@@ -55,6 +55,9 @@ constexpr int EF_STAGE_BYTES = 4 * EF_PART_BYTES;     // 128 rows (34 KiB)
 #ifndef EF_DBUF
 #define EF_DBUF 0
 #endif
+#ifndef EF_WG_PER_CU
+#define EF_WG_PER_CU 2       // resident workgroups per CU the kernels are built for (waves per SIMD with EF_WAVES_N = 4)
+#endif
 // Geometry: EF_WAVES_N waves per workgroup.  4 waves + ONE stage buffer (72 KiB of LDS) lets two workgroups share
 // a CU: their barriers, stage DMAs and input loads overlap each other (measured against 8 waves + two buffers, one
 // workgroup per CU, whose waves all stall together).  EF_DBUF = 1: double-buffered stages (needs EF_WAVES_N = 8 to pay).
@@ -392,7 +395,7 @@ struct EfArgs {
   }
 #define EF_UNIT_NEXT(U, VALID, U2, BYTES) EF_UNIT_NEXT_K(U, VALID, U2, BYTES, EF_WAIT_VM(0))
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
-__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_fwd(const EfArgs a_) {
+__global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const EfArgs a_) {
   EfArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -806,11 +809,20 @@ struct EbArgs {
   unsigned rs2, rs3;
   int small_idx;
   float* lnp;                    // [grid][4][128] partial sums: d gamma2, d beta2, d gamma_t, d beta_t
+  float *dwp, *dbp;              // DW variant: [grid][2][128][128] / [grid][2][128] partial weight / bias gradients (W1, W2)
 };
+// every LDS write of this wave has landed (before a barrier that publishes staged tiles to the other waves)
+#define EF_LDS_DONE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ void ef_dot2c(float& acc, unsigned a, unsigned b) {      // acc += a.lo*b.lo + a.hi*b.hi (bf16 pairs)
   asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
 }
+// gfx950 data hazard: the result of a DOT instruction may be read by a different VALU opcode only 3 wait states later
+// (back-to-back accumulation by the same DOT opcode is fine).  hipcc inserts those for its own DOT instructions, not for
+// inline asm: every accumulator of an ef_dot2c chain passes through this before anything else reads it.  (Round 4: with
+// another schedule of the same source the last v_dot2c of the d-beta sums was followed directly by its v_add — the
+// gradient of tail.bias lost the tokens of the last read, 15 % off, while every other sum was right.)
+#define EF_DOT_SETTLE4(A, B, C, D) asm volatile("s_nop 3" : "+v"(A), "+v"(B), "+v"(C), "+v"(D))
 typedef short ef_v4s __attribute__((ext_vector_type(4)));
 typedef ef_v4s __attribute__((address_space(3))) * ef_lds_v4s_ptr;
 
@@ -888,6 +900,7 @@ __device__ __forceinline__ void ef_ln_bwd(const ef_v8bf (&dy)[8], const ef_v8bf 
         ef_dot2c(ga, dv.x, xv.x); ef_dot2c(gb, dv.y, xv.y);
         ef_dot2c(ba, dv.x, 0x3f803f80u); ef_dot2c(bb, dv.y, 0x3f803f80u);
       }
+      EF_DOT_SETTLE4(ga, gb, ba, bb);
       acc[2 * half] += (ga + gb) * dy_scale;
       acc[2 * half + 1] += (ba + bb) * dy_scale;
     }
@@ -911,8 +924,91 @@ __device__ __forceinline__ void ef_ln_partials(const float (&q)[8], float* red /
   }
 }
 
-template <int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
-__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs a_) {
+// ---- weight gradients INSIDE the chained backward kernels (DW variants, round 4)
+// dW[n][k] = sum over tokens G[t][n] X[t][k] contracts over TOKENS, which sit on the lanes of a wave tile: the MFMA
+// operands are the transposes of what a wave holds, and a wave alone would need all 16 accumulator tiles of a
+// [128,128] weight.  So the four waves of a workgroup stage their G and X tiles as [token][channel] bf16 rows in LDS
+// (ef_stage_tile: the same writes ef_store_rows makes on the way to HBM), and after a unit-boundary barrier wave
+// (wr, wc) = (wave >> 1, wave & 1) accumulates rows 64 wr .., columns 64 wc .. of dW over all 128 token slots of the
+// iteration: fragments by ds_read_b64_tr_b16 (lane = channel, 4 tokens per read; the token order of a k-step is the
+// same for both operands, which is all a contraction needs), 4 accumulator tiles per weight that live across the
+// persistent loop (AGPRs: the DW kernels are built for ONE workgroup per CU, 512 registers per wave), written once per
+// workgroup as fp32 partials [grid][weights][128][128] and summed in block order by k_ef_dw_reduce.  Bias gradients
+// (column sums of G) come from the A fragments by v_dot2c with ones in the wc == 0 waves.
+// The operand tensors (d_y2, h, d_hpre, x1 | d_y, o, d_qkv) are never written to HBM and the four / two weight-gradient
+// GEMMs per layer that read them back are gone.
+constexpr int EF_HALF_B = 32 * EF_STG_ROWB;           // 4608: one staged [32 token][64 channel] block
+constexpr int EF_TILE_B = 2 * EF_HALF_B;              // 9216: a staged [32 token][128 channel] tile
+constexpr int EF_WAVE_LDS_FFN_DW = 3 * EF_TILE_B;     // G | X | X1 regions of a wave (feed-forward half)
+constexpr int EF_DW_TILE_FLOATS = 128 * 128;
+
+__device__ __forceinline__ void ef_stage_tile(const ef_v8bf (&zp)[8], char* sw /* region + 144 * tl + 8 * h */) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int ff = 0; ff < 4; ++ff) {
+      const uint4 v = __builtin_bit_cast(uint4, zp[4 * half + ff]);
+      *reinterpret_cast<uint2*>(sw + EF_HALF_B * half + 32 * ff) = make_uint2(v.x, v.y);
+      *reinterpret_cast<uint2*>(sw + EF_HALF_B * half + 32 * ff + 16) = make_uint2(v.z, v.w);
+    }
+}
+// fragment (lane = channel c of a 32-channel block, 8 tokens {4h'+0..3, 8+4h'+0..3} of a 16-token k-step) of a staged tile
+__device__ __forceinline__ ef_v8bf ef_tr_frag(const char* p) {
+  const uint2 r0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ef_lds_v4s_ptr)(p)));
+  const uint2 r1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ef_lds_v4s_ptr)(p + 8 * EF_STG_ROWB)));
+  return __builtin_bit_cast(ef_v8bf, make_uint4(r0.x, r0.y, r1.x, r1.y));
+}
+// ga / xa: stg_all + region offset + EF_HALF_B * (wr | wc) + the lane's transposed-read base (ef_tr_lane); WL = wave stride
+__device__ __forceinline__ int ef_tr_lane(int lane) {
+  return EF_STG_ROWB * (4 * (lane >> 5) + ((lane & 15) >> 2)) + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+}
+template <int WL, bool BIAS>
+__device__ __forceinline__ void ef_dw_phase(ef_f32x16 (&acc)[4], float (&bsum)[2], const char* ga, const char* xa) {
+#pragma unroll
+  for (int ws = 0; ws < EF_WAVES; ++ws) {          // source wave
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                  // tokens 16 t .. 16 t + 15 of its tile
+      const int o = ws * WL + 16 * t * EF_STG_ROWB;
+      const ef_v8bf a0 = ef_tr_frag(ga + o), a1 = ef_tr_frag(ga + o + 64);
+      const ef_v8bf b0 = ef_tr_frag(xa + o), b1 = ef_tr_frag(xa + o + 64);
+      acc[0] = EF_MFMA(a0, b0, acc[0]);
+      acc[1] = EF_MFMA(a0, b1, acc[1]);
+      acc[2] = EF_MFMA(a1, b0, acc[2]);
+      acc[3] = EF_MFMA(a1, b1, acc[3]);
+      if constexpr (BIAS) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          ef_dot2c(bsum[0], ef_dw(a0, d), 0x3f803f80u);
+          ef_dot2c(bsum[1], ef_dw(a1, d), 0x3f803f80u);
+        }
+      }
+    }
+  }
+}
+// the workgroup's partial of one weight: tile (i, j) of wave (wr, wc) = rows 64 wr + 32 i .., columns 64 wc + 32 j ..
+__device__ __forceinline__ void ef_dw_write(const ef_f32x16 (&acc)[4], float* dst /* [128][128] of this block and weight */,
+                                            int wr, int wc, int lane) {
+  const int tl = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dst[(64 * wr + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3)) * 128 + 64 * wc + 32 * j + tl] = acc[2 * i + j][r];
+}
+__device__ __forceinline__ void ef_db_write(const float (&bsum)[2], float* dst /* [128] */, int wr, int lane) {
+  float b0 = bsum[0], b1 = bsum[1];
+  asm volatile("s_nop 3" : "+v"(b0), "+v"(b1));          // (DOT result -> other VALU hazard, see EF_DOT_SETTLE4)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float v = (i ? b1 : b0) + ef_xor32(i ? b1 : b0);
+    if (lane < 32) dst[64 * wr + 32 * i + lane] = v;
+  }
+}
+
+template <int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */, bool DW /* weight gradients inside */>
+__global__ void __launch_bounds__(EF_THREADS, DW ? 1 : EF_WG_PER_CU) k_encoder_bwd_ffn(const EbArgs a_) {
   EbArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -920,7 +1016,19 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
   char* stg_all = smem + 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tl = lane & 31, h = lane >> 5, h4 = 4 * h, lane16 = 16 * lane;
-  char* stg = stg_all + wave * EF_WAVE_LDS;
+  constexpr int WL = DW ? EF_WAVE_LDS_FFN_DW : EF_WAVE_LDS;
+  char* stg = stg_all + wave * WL;
+  // DW: accumulator tiles of dW2 (G = d_y2, X = h) and dW1 (G = d_hpre, X = x1) + bias column sums
+  const int wr = wave >> 1, wc = wave & 1;
+  ef_f32x16 dw2[4], dw1[4];
+  float db2[2] = {0.f, 0.f}, db1[2] = {0.f, 0.f};
+  if constexpr (DW) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { dw2[i] = ef_zero16(); dw1[i] = ef_zero16(); }
+  }
+  const char* tr_g = stg_all + EF_HALF_B * wr + ef_tr_lane(lane);                  // G region, this wave's row blocks
+  const char* tr_x = stg_all + EF_TILE_B + EF_HALF_B * wc + ef_tr_lane(lane);     // X region, this wave's column blocks
+  const char* tr_x1 = tr_x + EF_TILE_B;                                          // X1 region
   const int S = a.S;
   const int RW = 32 / S;
   const long long n_wt = (a.R + RW - 1) / RW;
@@ -1000,7 +1108,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         return r;
       });
     }
-    ef_store_rows(gf, la, ef_tile_rsrc(a.dy2, tok0, nvalid));            // d_y2: operand of dW2 (and db2)
+    if constexpr (DW) ef_stage_tile(gf, la.sw);                          // d_y2 -> G region: operand of dW2 (and db2)
+    else ef_store_rows(gf, la, ef_tile_rsrc(a.dy2, tok0, nvalid));
 
     // ---- x1 = LN1(z1) (recomputed), written as the X operand of dW1
     ef_v8bf x1f[8];
@@ -1015,7 +1124,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         EF_FENCE();
         x1f[f] = ef_ln_apply(zf[f], nmr1, rstd1, pf + EF_P_G1 + 16 * f, pf + EF_P_BE1 + 16 * f);
       }
-      ef_store_rows(x1f, la, ef_tile_rsrc(a.x1out, tok0, nvalid));
+      if constexpr (DW) ef_stage_tile(x1f, la.sw + 2 * EF_TILE_B);       // -> X1 region (read by the dW1 phase below)
+      else ef_store_rows(x1f, la, ef_tile_rsrc(a.x1out, tok0, nvalid));
     }
 
     // ---- units 0, 1 (W1): h = drop(relu(W1 x1 + b1)) (recomputed), written as the X operand of dW2
@@ -1032,7 +1142,9 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         if (m == 1) {
           // issued since the DMA of unit 1 (end of the previous tile): its 8 d_x1 stores, this tile's 48 loads (all
           // consumed by now) and the 16 stores of d_y2 and x1
-          EF_UNIT_NEXT_K(0, true, 2, EF_UNIT_BYTES, EF_WAIT_VM(16))
+          // (DW: nothing was stored since; the loads are consumed, so the count is zero)
+          if constexpr (DW) { EF_UNIT_NEXT_K(0, true, 2, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
+          else { EF_UNIT_NEXT_K(0, true, 2, EF_UNIT_BYTES, EF_WAIT_VM(16)) }
         } else if (m == 3) {
           EF_UNIT_NEXT(1, true, 3, EF_UNIT_BYTES)
         }
@@ -1047,7 +1159,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         hf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
-      ef_store_rows(hf, la, ef_tile_rsrc(a.hout, tok0, nvalid));
+      if constexpr (DW) ef_stage_tile(hf, la.sw + EF_TILE_B);            // h -> X region
+      else ef_store_rows(hf, la, ef_tile_rsrc(a.hout, tok0, nvalid));
     }
 
     // ---- units 2, 3 (W2^T): d_h = d_y2 W2, gated by the recomputed h: d_hpre (G operand of dW1, and db1)
@@ -1058,7 +1171,16 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         ef_f32x16 acc = ef_zero16();
         EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), gf)
         if (m == 1) {
-          EF_UNIT_NEXT_K(2, true, 4, EF_UNIT_BYTES, EF_WAIT_VM(8))       // since the DMA of unit 3: the 8 stores of h
+          if constexpr (DW) {
+            // this barrier publishes every wave's d_y2 and h tiles; the dW2 phase runs between it and the next one, after
+            // which the G / X regions are free again
+            EF_LDS_DONE();
+            EF_UNIT_NEXT_K(2, true, 4, EF_UNIT_BYTES, EF_WAIT_VM(0))
+            if (wc == 0) ef_dw_phase<WL, true>(dw2, db2, tr_g, tr_x);
+            else ef_dw_phase<WL, false>(dw2, db2, tr_g, tr_x);
+          } else {
+            EF_UNIT_NEXT_K(2, true, 4, EF_UNIT_BYTES, EF_WAIT_VM(8))     // since the DMA of unit 3: the 8 stores of h
+          }
         } else if (m == 3) {
           EF_UNIT_NEXT(3, true, 5, EF_UNIT_BYTES)
         }
@@ -1068,7 +1190,8 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         hf[2 * m + 1] = ef_pack<1>(acc);
         EF_FENCE();
       }
-      ef_store_rows(hf, la, ef_tile_rsrc(a.dhpre, tok0, nvalid));
+      if constexpr (DW) ef_stage_tile(hf, la.sw);                        // d_hpre -> G region (after the unit-3 barrier)
+      else ef_store_rows(hf, la, ef_tile_rsrc(a.dhpre, tok0, nvalid));
     }
 
     // ---- units 4, 5 (W1^T): d_x1 = d_z2 + d_hpre W1
@@ -1081,9 +1204,16 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
         for (int i = 0; i < 16; ++i) acc[i] = ef_bf(dzf[2 * m + (i >> 3)], i & 7);
         EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), hf)
         if (m == 1) {
-          EF_UNIT_NEXT_K(4, has_next, 0, EF_UNIT_BYTES, EF_WAIT_VM(8))   // since the DMA of unit 5: the 8 stores of d_hpre
+          if constexpr (DW) {
+            EF_LDS_DONE();                                               // publishes d_hpre (x1 has been there since the top)
+            EF_UNIT_NEXT_K(4, has_next, 0, EF_UNIT_BYTES, EF_WAIT_VM(0))
+            if (wc == 0) ef_dw_phase<WL, true>(dw1, db1, tr_g, tr_x1);
+            else ef_dw_phase<WL, false>(dw1, db1, tr_g, tr_x1);
+          } else {
+            EF_UNIT_NEXT_K(4, has_next, 0, EF_UNIT_BYTES, EF_WAIT_VM(8)) // since the DMA of unit 5: the 8 stores of d_hpre
+          }
         } else if (m == 3) {
-          EF_UNIT_NEXT(5, has_next, 1, EF_UNIT_BYTES)
+          EF_UNIT_NEXT(5, has_next, 1, EF_UNIT_BYTES)                    // (DW: every wave is past its dW1 reads here)
         }
         dzf[2 * m] = ef_pack<0>(acc);
         dzf[2 * m + 1] = ef_pack<1>(acc);
@@ -1095,6 +1225,16 @@ __global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_ffn(const EbArgs 
   {
     const float q[8] = {q2[0], q2[2], q2[1], q2[3], qt[0], qt[2], qt[1], qt[3]};      // [d gamma2 | d beta2 | d gamma_t | d beta_t] x halves
     ef_ln_partials(q, reinterpret_cast<float*>(stg_all), a.lnp, wave, lane, tid);
+  }
+  if constexpr (DW) {       // this workgroup's partial weight gradients: [block][dW1 | dW2][128][128], [block][db1 | db2][128]
+    float* wp = a.dwp + (size_t)blockIdx.x * 2 * EF_DW_TILE_FLOATS;
+    ef_dw_write(dw1, wp, wr, wc, lane);
+    ef_dw_write(dw2, wp + EF_DW_TILE_FLOATS, wr, wc, lane);
+    if (wc == 0) {
+      float* bp = a.dbp + (size_t)blockIdx.x * 2 * 128;
+      ef_db_write(db1, bp, wr, lane);
+      ef_db_write(db2, bp + 128, wr, lane);
+    }
   }
 }
 
@@ -1170,7 +1310,7 @@ __device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* b
 }
 
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
-__global__ void __launch_bounds__(EF_THREADS, 2) k_encoder_bwd_attn(const EaArgs a_) {
+__global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(const EaArgs a_) {
   EaArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1535,6 +1675,66 @@ __global__ void __launch_bounds__(1024) k_ef_reduce(const float* __restrict__ pa
   }
 }
 
+// Sum of the DW kernels' per-workgroup partial weight gradients in block order (deterministic): part [nblk][nw][128][128],
+// partb [nblk][nw][128].  Blocks [0, 16 nw): 1024 floats of weight blockIdx / 16 each (thread = one float4, four groups of
+// 256 threads split the block range); blocks [16 nw, 17 nw): the bias vector of weight blockIdx - 16 nw.
+struct EwOut { float* w[4]; float* b[4]; };
+__global__ void __launch_bounds__(1024) k_ef_dw_reduce(const float* __restrict__ part, const float* __restrict__ partb, int nblk,
+                                                       int nw, const EwOut o, int accumulate) {
+  __shared__ float4 red[4][256];
+  const int grp = threadIdx.x >> 8, t = threadIdx.x & 255;
+  if ((int)blockIdx.x < 16 * nw) {
+    const int w = blockIdx.x >> 4;
+    float* dst = o.w[w];
+    if (!dst) return;
+    const size_t e = (size_t)(blockIdx.x & 15) * 1024 + 4 * t;
+    const float* p = part + (size_t)w * EF_DW_TILE_FLOATS + e;
+    const size_t stride = (size_t)nw * EF_DW_TILE_FLOATS;
+    float4 u[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int b = grp;
+    for (; b + 12 < nblk; b += 16) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (size_t)(b + 4 * k) * stride);
+        u[k].x += v.x; u[k].y += v.y; u[k].z += v.z; u[k].w += v.w;
+      }
+    }
+    for (; b < nblk; b += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)b * stride);
+      u[0].x += v.x; u[0].y += v.y; u[0].z += v.z; u[0].w += v.w;
+    }
+    red[grp][t] = make_float4((u[0].x + u[1].x) + (u[2].x + u[3].x), (u[0].y + u[1].y) + (u[2].y + u[3].y),
+                              (u[0].z + u[1].z) + (u[2].z + u[3].z), (u[0].w + u[1].w) + (u[2].w + u[3].w));
+    __syncthreads();
+    if (grp == 0) {
+      float4 r = red[0][t];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) { r.x += red[k][t].x; r.y += red[k][t].y; r.z += red[k][t].z; r.w += red[k][t].w; }
+      float4* d = reinterpret_cast<float4*>(dst + e);
+      if (accumulate) { const float4 c = *d; r.x += c.x; r.y += c.y; r.z += c.z; r.w += c.w; }
+      *d = r;
+    }
+  } else {
+    const int w = blockIdx.x - 16 * nw;
+    float* dst = o.b[w];
+    if (!dst) return;
+    float* redf = reinterpret_cast<float*>(red);        // [8][128]
+    const int c = threadIdx.x & 127, g8 = threadIdx.x >> 7;
+    float v = 0.f;
+    for (int b = g8; b < nblk; b += 8) v += partb[((size_t)b * nw + w) * 128 + c];
+    redf[g8 * 128 + c] = v;
+    __syncthreads();
+    if (g8 == 0) {
+      float r = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r += redf[k * 128 + c];
+      dst[c] = accumulate ? dst[c] + r : r;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- generic tile pack
 struct EfTileList {
   const unsigned short* src[8];    // [128 rows][128] bf16 row-major tiles (row stride ld[i])
@@ -1617,7 +1817,7 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  const long long slots = (long long)n_cu * (EF_WAVES >= 8 ? 1 : 2);
+  const long long slots = (long long)n_cu * (EF_WAVES >= 8 ? 1 : EF_WG_PER_CU);
   const unsigned grid = (unsigned)(n_it < slots ? n_it : slots);
   const size_t lds = 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
   // DROP template value: 0 = no dropout, else the hash bits per element the threshold allows (common.hpp)
@@ -1658,7 +1858,8 @@ extern "C" int tg_encoder_pack_tiles(const void* const* tiles, const int32_t* ld
 }
 
 static size_t ef_lds_bytes() { return 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4 + EF_WAVES * EF_WAVE_LDS; }
-static unsigned ef_grid(long long R, int S) {
+static size_t ef_lds_bytes_ffn_dw() { return 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4 + EF_WAVES * EF_WAVE_LDS_FFN_DW; }
+static unsigned ef_grid(long long R, int S, int wg_per_cu = EF_WG_PER_CU) {
   const int RW = 32 / S;
   const long long n_wt = (R + RW - 1) / RW, n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   static int n_cu = 0;
@@ -1668,20 +1869,17 @@ static unsigned ef_grid(long long R, int S) {
     (void)hipGetDevice(&dev);
     n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
   }
-  const long long slots = (long long)n_cu * (EF_WAVES >= 8 ? 1 : 2);
+  const long long slots = (long long)n_cu * (EF_WAVES >= 8 ? 1 : wg_per_cu);
   return (unsigned)(n_it < slots ? n_it : slots);
 }
 
 // Feed-forward half of the layer backward (see k_encoder_bwd_ffn).  g = d out [R,S,128]; z1, z2 from the forward;
 // wpack = tg_encoder_pack_tiles(W1, W2^T, W1^T); prm = the forward's parameter block.  Writes d_x1 and the weight-gradient
 // operands d_y2, h, d_hpre, x1 (all [R,S,128] bf16).  rs: the forward's dropout streams.
-extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void* z2, void* dx1, void* dy2, void* hout,
-                                       void* dhpre, void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S,
-                                       int32_t tail, float beta_c, float eps, float p_drop, uint64_t seed,
-                                       const uint32_t* rs, float* lnp, void* stream) {
-  TG_CHECK(S >= 2 && S <= 32, "tg_encoder_bwd_ffn_bf16: unsupported S=%d", S);
-  TG_CHECK(g && z1 && z2 && dx1 && dy2 && hout && dhpre && x1out && wpack && prm && rs && lnp, "tg_encoder_bwd_ffn_bf16: null operand");
-  if (R <= 0) return 0;
+static int ef_launch_bwd_ffn(bool dw, const void* g, const void* z1, const void* z2, void* dx1, void* dy2, void* hout,
+                             void* dhpre, void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S,
+                             int32_t tail, float beta_c, float eps, float p_drop, uint64_t seed, const uint32_t* rs,
+                             float* lnp, float* dwp, float* dbp, void* stream) {
   EbArgs a;
   a.g = (const unsigned short*)g; a.z1 = (const unsigned short*)z1; a.z2 = (const unsigned short*)z2;
   a.dx1 = (unsigned short*)dx1; a.dy2 = (unsigned short*)dy2; a.hout = (unsigned short*)hout; a.dhpre = (unsigned short*)dhpre;
@@ -1691,22 +1889,66 @@ extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void
   a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
   a.seed = seed; a.rs2 = rs[2]; a.rs3 = rs[3];
   a.small_idx = (double)(R + 32) * S * 128.0 < 4294967296.0 ? 1 : 0;
-  a.lnp = lnp;
-  const size_t lds = ef_lds_bytes();
-  const unsigned grid = ef_grid(R, S);
+  a.lnp = lnp; a.dwp = dwp; a.dbp = dbp;
+  const size_t lds = dw ? ef_lds_bytes_ffn_dw() : ef_lds_bytes();
+  const unsigned grid = ef_grid(R, S, dw ? 1 : EF_WG_PER_CU);
   const int drop = drop_mode(a.thresh);      // DROP template value (common.hpp)
-#define EF_LAUNCH_B(DR_)                                                                                       \
+#define EF_LAUNCH_B(DR_, DW_)                                                                                  \
   {                                                                                                            \
     static bool attr_done = false;                                                                             \
     if (!attr_done) {                                                                                          \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_ffn<DR_>),                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_bwd_ffn<DR_, DW_>),                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
       attr_done = true;                                                                                        \
     }                                                                                                          \
-    hipLaunchKernelGGL((k_encoder_bwd_ffn<DR_>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);                    \
+    hipLaunchKernelGGL((k_encoder_bwd_ffn<DR_, DW_>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a);  \
   }
-  if (drop == 0) EF_LAUNCH_B(0) else if (drop == 1) EF_LAUNCH_B(1) else if (drop == 8) EF_LAUNCH_B(8) else EF_LAUNCH_B(16)
+  if (dw) {
+    if (drop == 0) EF_LAUNCH_B(0, true) else if (drop == 1) EF_LAUNCH_B(1, true) else if (drop == 8) EF_LAUNCH_B(8, true) else EF_LAUNCH_B(16, true)
+  } else {
+    if (drop == 0) EF_LAUNCH_B(0, false) else if (drop == 1) EF_LAUNCH_B(1, false) else if (drop == 8) EF_LAUNCH_B(8, false) else EF_LAUNCH_B(16, false)
+  }
 #undef EF_LAUNCH_B
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_encoder_bwd_ffn_bf16(const void* g, const void* z1, const void* z2, void* dx1, void* dy2, void* hout,
+                                       void* dhpre, void* x1out, const void* wpack, const float* prm, int64_t R, int32_t S,
+                                       int32_t tail, float beta_c, float eps, float p_drop, uint64_t seed,
+                                       const uint32_t* rs, float* lnp, void* stream) {
+  TG_CHECK(S >= 2 && S <= 32, "tg_encoder_bwd_ffn_bf16: unsupported S=%d", S);
+  TG_CHECK(g && z1 && z2 && dx1 && dy2 && hout && dhpre && x1out && wpack && prm && rs && lnp, "tg_encoder_bwd_ffn_bf16: null operand");
+  if (R <= 0) return 0;
+  return ef_launch_bwd_ffn(false, g, z1, z2, dx1, dy2, hout, dhpre, x1out, wpack, prm, R, S, tail, beta_c, eps, p_drop, seed,
+                           rs, lnp, nullptr, nullptr, stream);
+}
+
+// The same half with the FFN weight gradients INSIDE (k_encoder_bwd_ffn<., true>): writes d_x1 only; the operand tensors
+// d_y2, h, d_hpre, x1 stay in LDS.  nblk = tg_encoder_dw_blocks(R, S) workgroups leave lnp [nblk][4][128] (as above),
+// dwp [nblk][2][128][128] (partial dW1 | dW2, [out][in]) and dbp [nblk][2][128] (partial db1 | db2); tg_encoder_dw_reduce
+// sums them in block order.
+extern "C" int64_t tg_encoder_dw_blocks(int64_t R, int32_t S) { return S >= 1 && S <= 32 && R > 0 ? (int64_t)ef_grid(R, S, 1) : 0; }
+extern "C" int tg_encoder_bwd_ffn_dw_bf16(const void* g, const void* z1, const void* z2, void* dx1, const void* wpack,
+                                          const float* prm, int64_t R, int32_t S, int32_t tail, float beta_c, float eps,
+                                          float p_drop, uint64_t seed, const uint32_t* rs, float* lnp, float* dwp,
+                                          float* dbp, void* stream) {
+  TG_CHECK(S >= 2 && S <= 32, "tg_encoder_bwd_ffn_dw_bf16: unsupported S=%d", S);
+  TG_CHECK(g && z1 && z2 && dx1 && wpack && prm && rs && lnp && dwp && dbp, "tg_encoder_bwd_ffn_dw_bf16: null operand");
+  if (R <= 0) return 0;
+  return ef_launch_bwd_ffn(true, g, z1, z2, dx1, nullptr, nullptr, nullptr, nullptr, wpack, prm, R, S, tail, beta_c, eps,
+                           p_drop, seed, rs, lnp, dwp, dbp, stream);
+}
+// out_w[i] (fp32 [128][128]) / out_b[i] (fp32 [128]) (+)= sum over blocks of weight i's partials; NULL = not wanted
+extern "C" int tg_encoder_dw_reduce(const float* dwp, const float* dbp, int64_t nblk, int32_t nw, float* const* out_w,
+                                    float* const* out_b, int32_t accumulate, void* stream) {
+  TG_CHECK(dwp && dbp && out_w && out_b && nblk >= 0 && nw >= 1 && nw <= 4, "tg_encoder_dw_reduce: bad arguments");
+  if (nblk == 0) return 0;
+  EwOut o;
+  for (int i = 0; i < 4; ++i) { o.w[i] = i < nw ? out_w[i] : nullptr; o.b[i] = i < nw ? out_b[i] : nullptr; }
+  for (int i = 0; i < nw; ++i)
+    TG_CHECK((reinterpret_cast<uintptr_t>(o.w[i]) & 15) == 0, "tg_encoder_dw_reduce: weight gradient %d must be 16-byte aligned", i);
+  hipLaunchKernelGGL(k_ef_dw_reduce, dim3(17 * nw), dim3(1024), 0, (hipStream_t)stream, dwp, dbp, (int)nblk, (int)nw, o, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }

@@ -24,6 +24,7 @@ from . import ops
 _FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B switch
 _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B switch: the one-kernel layer (encoder_fused.hip)
 _FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
+_DW_FFN = os.environ.get("TABGNN_NO_DW_FFN") != "1"      # A/B: feed-forward weight gradients inside the chained backward kernel
 
 
 STATS = {"fused_fwd": 0, "fused_bwd": 0, "fused_bwd_attn": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
@@ -292,6 +293,28 @@ def _ln_reduce(lnp, nblk, params):
     return res
 
 
+def _dw_reduce(dwp, dbp, nblk, pairs):
+    """Sum the per-workgroup partial weight / bias gradients of the DW backward kernels (tg_encoder_dw_reduce).  ``pairs`` =
+    ((weight, bias), ...) in the kernel's order (Parameters or None).  When every parameter owns a gradient buffer the sums
+    are ADDED there (returns Nones), else fresh fp32 tensors are returned: (dW_0, db_0, dW_1, db_1, ...)."""
+    dev = dwp.device
+    nw = len(pairs)
+    tw = [ops._grad_target(w) if isinstance(w, torch.nn.Parameter) else None for w, _ in pairs]
+    tb = [ops._grad_target(b) if isinstance(b, torch.nn.Parameter) else None for _, b in pairs]
+    acc = all(t is not None and t.shape == (128, 128) for t in tw) and all(t is not None for t in tb)
+    if not acc:
+        tw = [torch.empty(128, 128, dtype=torch.float32, device=dev) for _ in pairs]
+        tb = [torch.empty(128, dtype=torch.float32, device=dev) for _ in pairs]
+    aw = (ctypes.c_void_p * nw)(*[t.data_ptr() for t in tw])
+    ab = (ctypes.c_void_p * nw)(*[t.data_ptr() for t in tb])
+    L.call("tg_encoder_dw_reduce", L.ptr(dwp), L.ptr(dbp), nblk, nw, ctypes.addressof(aw), ctypes.addressof(ab), int(acc),
+           L.stream())
+    out = []
+    for w, b in zip(tw, tb):
+        out += [None, None] if acc else [w, b]
+    return out
+
+
 def _fused_backward(ctx, g):
     """Backward of the one-kernel layer: everything is recomputed from (x, z1, z2) by two chained kernels — the
     feed-forward half (tg_encoder_bwd_ffn_bf16) and the attention half (tg_encoder_bwd_attn_bf16, 4 or 8 heads) — which
@@ -313,22 +336,39 @@ def _fused_backward(ctx, g):
     tp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tiles])
     ld = (ctypes.c_int32 * 3)(*[t.stride(0) for t in tiles])
     L.call("tg_encoder_pack_tiles", ctypes.addressof(tp), ctypes.addressof(ld), 3, L.ptr(wpack_b), L.stream())
-    d_x1, d_y2, h, d_hpre, x1 = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(5))
-    lnp = torch.empty(nblk * 512, dtype=torch.float32, device=dev)
-    ops._launch("tg_encoder_bwd_ffn_bf16", L.ptr(g), L.ptr(z1), L.ptr(z2), L.ptr(d_x1), L.ptr(d_y2), L.ptr(h), L.ptr(d_hpre),
-                L.ptr(x1), L.ptr(wpack_b), L.ptr(prm), R, S, int(tail), float(beta_c), 1e-5, float(p), int(seed),
-                ctypes.addressof(rs_arr), L.ptr(lnp), L.stream(), nbytes=2 * T * C * 8)
-    STATS["fused_bwd"] += 1
     gg2, gb2, ggt, gbt = ctx.ln_params[1][0], ctx.ln_params[1][1], ctx.ln_params[2][0], ctx.ln_params[2][1]
-    dg2, dbe2, dgt, dbt = _ln_reduce(lnp, nblk, (gg2, gb2, ggt if tail else None, gbt if tail else None))
-    dw2, db2 = ops.weight_grad(d_y2, h, True, p_2, pb_2)
-    if db2 is None and dw2 is not None:
-        db2 = d_y2.sum(0, dtype=torch.float32)
-    del d_y2, h
-    dw1, db1 = ops.weight_grad(d_hpre, x1, True, p_1, pb_1)
-    if db1 is None and dw1 is not None:
-        db1 = d_hpre.sum(0, dtype=torch.float32)
-    del d_hpre, x1
+    if _DW_FFN:
+        # weight gradients inside the kernel: d_y2, h, d_hpre, x1 never reach HBM; per-workgroup partials summed in block order
+        nblk = lib.tg_encoder_dw_blocks(R, S)
+        d_x1 = torch.empty(T, C, dtype=g.dtype, device=dev)
+        lnp = torch.empty(nblk * 512, dtype=torch.float32, device=dev)
+        dwp = torch.empty(nblk * 2 * 128 * 128, dtype=torch.float32, device=dev)
+        dbp = torch.empty(nblk * 2 * 128, dtype=torch.float32, device=dev)
+        ops._launch("tg_encoder_bwd_ffn_dw_bf16", L.ptr(g), L.ptr(z1), L.ptr(z2), L.ptr(d_x1), L.ptr(wpack_b), L.ptr(prm), R, S,
+                    int(tail), float(beta_c), 1e-5, float(p), int(seed), ctypes.addressof(rs_arr), L.ptr(lnp), L.ptr(dwp),
+                    L.ptr(dbp), L.stream(), nbytes=2 * T * C * 4)
+        STATS["fused_bwd"] += 1
+        STATS["fused_bwd_dw"] = STATS.get("fused_bwd_dw", 0) + 1
+        dg2, dbe2, dgt, dbt = _ln_reduce(lnp, nblk, (gg2, gb2, ggt if tail else None, gbt if tail else None))
+        dw1, db1, dw2, db2 = _dw_reduce(dwp, dbp, nblk, ((p_1, pb_1), (p_2, pb_2)))
+        del dwp, dbp
+    else:
+        d_x1, d_y2, h, d_hpre, x1 = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(5))
+        lnp = torch.empty(nblk * 512, dtype=torch.float32, device=dev)
+        ops._launch("tg_encoder_bwd_ffn_bf16", L.ptr(g), L.ptr(z1), L.ptr(z2), L.ptr(d_x1), L.ptr(d_y2), L.ptr(h), L.ptr(d_hpre),
+                    L.ptr(x1), L.ptr(wpack_b), L.ptr(prm), R, S, int(tail), float(beta_c), 1e-5, float(p), int(seed),
+                    ctypes.addressof(rs_arr), L.ptr(lnp), L.stream(), nbytes=2 * T * C * 8)
+        STATS["fused_bwd"] += 1
+        dg2, dbe2, dgt, dbt = _ln_reduce(lnp, nblk, (gg2, gb2, ggt if tail else None, gbt if tail else None))
+        dw2, db2 = ops.weight_grad(d_y2, h, True, p_2, pb_2)
+        if db2 is None and dw2 is not None:
+            db2 = d_y2.sum(0, dtype=torch.float32)
+        del d_y2, h
+        dw1, db1 = ops.weight_grad(d_hpre, x1, True, p_1, pb_1)
+        if db1 is None and dw1 is not None:
+            db1 = d_hpre.sum(0, dtype=torch.float32)
+        del d_hpre, x1
+    nblk = lib.tg_encoder_ln_partial_blocks(R, S)
     # ---- attention half: LayerNorm-1 backward, output-projection backward, attention backward on recomputed q/k/v/P
     p_bo = ctx.params[7]
     wo_t = ops.wt(lw_o, p_o)
