@@ -365,7 +365,6 @@ def reference_batch_sampled_loop(cfg, cdt, dev, B, steps=120, warm=60):
         edges += prep.e_real
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    G.StepState.release()
     return dict(ms_per_step=1e3 * dt / steps, value=edges / dt, unit="edges/s", steps=steps, edges_per_step=edges / steps,
                 buckets=len(step.buckets), buckets_captured_inside_the_timed_steps=new_after_warm,
                 host_ms_per_batch=1e3 * float(np.mean(t_host[warm:])), sampler_threads=n_workers, final_loss=float(loss),

@@ -18,7 +18,13 @@
 #define TABGNN_HIP_H_
 #include <stdint.h>
 
-#define TABGNN_HIP_ABI_VERSION 5
+#define TABGNN_HIP_ABI_VERSION 6
+
+/* The `uint64_t seed` argument of every entry point that draws dropout masks is either the seed itself (bit 63 clear)
+ * or TG_SEED_DEVICE(p): the device address p of a 64-bit seed word that the kernel reads when it RUNS (word 0 of a
+ * step record, see tg_advance_step) — what a captured HIP graph needs, since its kernel arguments are frozen.  The
+ * library keeps no seed state of its own (ABI v5 had a hidden device word per translation unit). */
+#define TG_SEED_DEVICE(p) (0x8000000000000000ULL | (uint64_t)(uintptr_t)(p))
 
 #ifdef __cplusplus
 extern "C" {
@@ -126,8 +132,11 @@ int tg_bn_partials_floats(int64_t N, int32_t F);
 int tg_bn_act_res_fwd(const void* x, const void* res, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, float* mean, float* rstd, void* out, float* partials, int64_t N, int32_t F,
                       int32_t training, float momentum, float eps, int32_t relu, float alpha, float beta_c,
-                      int64_t n_stat, int32_t phase, int32_t dt, void* stream);
-/* phase 0: everything (n_stat ignored).  Synchronised BatchNorm across data-parallel ranks (optional):
+                      int64_t n_stat, int32_t phase, const int32_t* row_limit, int32_t dt, void* stream);
+/* row_limit (device int32, or NULL = every row counts; training, phase 0 only): padded batches — the statistics are
+ * taken over the first *row_limit rows and the padding rows get a zero input gradient.  Read by the kernels at run
+ * time, so one captured graph serves batches of different true size.  (An explicit argument since ABI v6.)
+ * phase 0: everything (n_stat ignored).  Synchronised BatchNorm across data-parallel ranks (optional):
  * phase 1 = local statistics only -> (sum x, sum x^2) at partials + 512*2*F, which the caller all-reduces in place;
  * phase 2 = finalize with n_stat = rows of ALL ranks (running statistics updated from the global batch) + apply.
  * Backward: phase 1 = local (sum dz, sum dz*xhat) -> dparams, caller all-reduces a COPY (the parameter gradients stay
@@ -135,7 +144,7 @@ int tg_bn_act_res_fwd(const void* x, const void* res, const float* gamma, const 
 int tg_bn_act_res_bwd(const void* x, const void* dout, const float* gamma, const float* beta, const float* mean,
                       const float* rstd, void* dx, void* dres, float* dparams /*[2F]: dbeta,dgamma*/, float* partials,
                       int64_t N, int32_t F, int32_t training, int32_t relu, float alpha, float beta_c, int64_t n_stat,
-                      int32_t phase, int32_t dt, void* stream);
+                      int32_t phase, const int32_t* row_limit, int32_t dt, void* stream);
 
 /* ---- activation + dropout after a Linear (encoder FFN; fuse MLP fused.py:224-231; heads decoder.py:14-15)
  *      act: 0 none, 1 relu, 2 leaky_relu(0.01) ------------------------------------------------------------ */
@@ -360,20 +369,14 @@ int tg_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
  * the step is bound by that launch work, not by the GPU)
  * `state` = 4 x uint64 in device memory: [0] dropout seed word, [1] optimiser step count t, [2] two floats
  * (lr/(1-beta1^t), 1/sqrt(1-beta2^t)), [3] reserved.  tg_advance_step: one single-thread kernel moves the record to
- * the next step (seed <- LCG(seed), t += 1, Adam's bias corrections for the new t), then every translation unit that
- * draws dropout masks takes the seed word (it is XOR-ed into the `seed` argument of every kernel).
- * tg_seed_source_sync(NULL) returns to host seeds alone. */
+ * the next step (seed <- LCG(seed) with bit 63 clear, t += 1, Adam's bias corrections for the new t).  Kernels of the
+ * step take the seed word through seed = TG_SEED_DEVICE(state): nothing is shared between two records. */
 int tg_advance_step(uint64_t* state, float lr, float beta1, float beta2, void* stream);
-int tg_seed_source_sync(const uint64_t* state, void* stream);
 /* tg_adam_step with the step-dependent scalars read from `state` (written by tg_advance_step in the same stream) */
 int tg_adam_step_dev(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float beta1, float beta2,
                      float eps, const uint64_t* state, float grad_scale, int32_t zero_grad, void* stream);
 /* stream-ordered zero fill by a kernel (bytes % 4 == 0): the package never records a library memset node */
 int tg_zero(void* p, int64_t bytes, void* stream);
-/* padded batches: BatchNorm (tg_bn_act_res_fwd/bwd, training, unsynchronised) takes its statistics over the first
- * *limit_dev rows only and gives the padding rows a zero input gradient; NULL (default) = every row counts.
- * The pointer is read by the kernels at run time: one captured graph serves batches of different true size. */
-int tg_set_bn_row_limit(const int32_t* limit_dev);
 /* one launch: transposed bf16 copies of all 2-D parameters (table int64 [n][3] = element offset, rows, cols inside
  * src/dst) — the input-gradient GEMMs read W^T as their row-major weight */
 int tg_transpose_batched_bf16(const void* src, void* dst, const int64_t* table, int32_t n, void* stream);

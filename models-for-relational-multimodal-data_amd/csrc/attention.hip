@@ -374,4 +374,3 @@ extern "C" int tg_attn_bwd(const void* qkv, const void* o, const void* dout, con
   return 0;
 }
 
-TG_DROPOUT_TU(attention)

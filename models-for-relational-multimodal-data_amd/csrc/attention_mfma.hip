@@ -698,4 +698,3 @@ void attn_mfma_bwd(const void* qkv, const void* o, const void* dout, const float
 
 }  // namespace tg
 
-TG_DROPOUT_TU(attention_mfma)

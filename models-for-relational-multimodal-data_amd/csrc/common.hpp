@@ -123,13 +123,16 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 __device__ __forceinline__ unsigned rng_key(unsigned long long seed, unsigned stream, unsigned hi) {
   return mix32((unsigned)seed ^ (stream * 0x9E3779B9U) ^ mix32(hi + (unsigned)(seed >> 32) + 0x85ebca6bU));
 }
-// Device-resident seed word (tg_seed_source_sync / tg_advance_step): every kernel that draws a dropout mask XORs its
-// seed argument with it ONCE at its top (live_seed).  A captured HIP graph bakes the host-side seed argument into its
-// kernel nodes; this word is read at run time, so a replay draws the masks of its own step.  Zero (the start value)
-// leaves the host seed as it is.  One copy per translation unit (no relocatable device code): TG_DROPOUT_TU(name)
-// registers the unit's setter kernel, and tg_seed_source_sync launches every registered setter.
-static __device__ unsigned long long g_seed_xor = 0ull;
-__device__ __forceinline__ unsigned long long live_seed(unsigned long long seed) { return seed ^ g_seed_xor; }
+// The seed ARGUMENT of every mask-drawing entry point is either the seed itself (bit 63 clear) or — TG_SEED_DEVICE of
+// include/tabgnn_hip.h, bit 63 set — the device address of a 64-bit seed word, read ONCE at the top of the kernel
+// (live_seed).  A captured HIP graph bakes its kernels' arguments in; the word behind the pointer is advanced by the
+// graph's first node (tg_advance_step), so every replay draws the masks of its own step.  There is no library-side
+// state: two graphs with two step records do not see each other (ABI v6; v5 kept one hidden copy of the word per
+// translation unit, written by tg_seed_source_sync).
+__device__ __forceinline__ unsigned long long live_seed(unsigned long long seed) {
+  if (seed >> 63) seed = *reinterpret_cast<const unsigned long long*>(seed & 0x7fffffffffffffffull);     // (wave-uniform)
+  return seed;
+}
 __device__ __forceinline__ unsigned rng_u32(unsigned long long seed, unsigned stream, unsigned long long idx) {
   return mix32((unsigned)idx ^ rng_key(seed, stream, (unsigned)(idx >> 32)));
 }
@@ -254,21 +257,5 @@ inline int grid_full(long long blocks, int old_cap = 256 * 8) {
   if (off_) return grid_cap(blocks, old_cap);
   return (int)(blocks < 1 ? 1 : (blocks > 2147483647LL ? 2147483647LL : blocks));
 }
-
-// ---------------------------------------------------------------- per-unit seed words (see g_seed_xor)
-// Each mask-drawing translation unit registers a function that returns the device address of ITS copy of
-// g_seed_xor (resolved lazily, on the first tg_advance_step — never at library load, which must work without a GPU);
-// k_step_advance then writes the new seed word to all of them in the same single-thread launch.
-typedef unsigned long long* (*seed_word_addr_fn)();
-void seed_tu_register(seed_word_addr_fn fn);          // train_ops.hip
-#define TG_DROPOUT_TU(NAME)                                                                                   \
-  namespace tg { namespace {                                                                                  \
-  unsigned long long* seed_word_addr_##NAME() {                                                               \
-    void* p = nullptr;                                                                                        \
-    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_seed_xor)) == hipSuccess ? (unsigned long long*)p : nullptr;  \
-  }                                                                                                           \
-  struct SeedTu_##NAME { SeedTu_##NAME() { seed_tu_register(&seed_word_addr_##NAME); } };                     \
-  SeedTu_##NAME seed_tu_instance_##NAME;                                                                      \
-  } }
 
 }  // namespace tg

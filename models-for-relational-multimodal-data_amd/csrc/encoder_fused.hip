@@ -2015,4 +2015,3 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
   return 0;
 }
 
-TG_DROPOUT_TU(encoder_fused)

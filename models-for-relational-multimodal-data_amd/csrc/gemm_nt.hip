@@ -591,4 +591,3 @@ extern "C" int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bia
   return 0;
 }
 
-TG_DROPOUT_TU(gemm_nt)

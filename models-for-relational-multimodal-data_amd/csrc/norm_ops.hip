@@ -299,7 +299,6 @@ __global__ void __launch_bounds__(1024) k_reduce_partials_acc3(const float* __re
 }
 
 // ------------------------------------------------------------------ BatchNorm (+ReLU, + residual average)
-extern const int* g_bn_row_limit;       // train_ops.hip:tg_set_bn_row_limit (device-side row count of a padded batch)
 // column statistics: each lane owns VEC channels, rows strided over lane groups and blocks
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) k_col_stats(const T* __restrict__ x, const T* __restrict__ y2,
@@ -911,13 +910,14 @@ extern "C" int tg_bn_partials_floats(int64_t N, int32_t F) { return 513 * 2 * F;
 extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float* mean, float* rstd, void* out,
                                  float* partials, int64_t N, int32_t F, int32_t training, float momentum, float eps,
-                                 int32_t relu, float alpha, float beta_c, int64_t n_stat, int32_t phase, int32_t dt,
-                                 void* stream) {
+                                 int32_t relu, float alpha, float beta_c, int64_t n_stat, int32_t phase,
+                                 const int32_t* row_limit, int32_t dt, void* stream) {
   TG_CHECK(F % 8 == 0 && F <= 1024 && N > 0, "tg_bn_act_res_fwd: bad F=%d N=%lld", F, (long long)N);
   TG_CHECK(phase >= 0 && phase <= 2 && (phase == 0 || training), "tg_bn_act_res_fwd: bad phase %d", phase);
   hipStream_t st = (hipStream_t)stream;
   if (n_stat <= 0 || phase == 0) n_stat = N;
-  const int* nlim = phase == 0 && training ? g_bn_row_limit : nullptr;   // (not combined with the synchronised phases)
+  TG_CHECK(row_limit == nullptr || (phase == 0 && training), "tg_bn_act_res_fwd: %s", "row_limit needs training, phase 0");
+  const int* nlim = (const int*)row_limit;      // device-side row count of a padded batch (not combined with the synchronised phases)
   DISPATCH_T(dt, {
     TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_fwd: F/VEC must divide 256 (F=%d)", F);
     float* sums = partials + (size_t)512 * 2 * F;      // (sum x, sum x^2): the vector a synchronised BN all-reduces
@@ -952,12 +952,14 @@ extern "C" int tg_bn_act_res_fwd(const void* x, const void* res, const float* ga
 extern "C" int tg_bn_act_res_bwd(const void* x, const void* dout, const float* gamma, const float* beta,
                                  const float* mean, const float* rstd, void* dx, void* dres, float* dparams,
                                  float* partials, int64_t N, int32_t F, int32_t training, int32_t relu, float alpha,
-                                 float beta_c, int64_t n_stat, int32_t phase, int32_t dt, void* stream) {
+                                 float beta_c, int64_t n_stat, int32_t phase, const int32_t* row_limit, int32_t dt,
+                                 void* stream) {
   TG_CHECK(F % 8 == 0 && F <= 1024 && N > 0, "tg_bn_act_res_bwd: bad F=%d N=%lld", F, (long long)N);
   TG_CHECK(phase >= 0 && phase <= 2, "tg_bn_act_res_bwd: bad phase %d", phase);
   hipStream_t st = (hipStream_t)stream;
   if (n_stat <= 0 || phase == 0) n_stat = N;
-  const int* nlim = phase == 0 && training ? g_bn_row_limit : nullptr;
+  TG_CHECK(row_limit == nullptr || (phase == 0 && training), "tg_bn_act_res_bwd: %s", "row_limit needs training, phase 0");
+  const int* nlim = (const int*)row_limit;
   DISPATCH_T(dt, {
     TG_CHECK(256 % (F / VEC) == 0, "tg_bn_act_res_bwd: F/VEC must divide 256 (F=%d)", F);
     if (phase != 2) {
@@ -1032,4 +1034,3 @@ extern "C" int tg_cls_merge_fwd(const void* xtab, const void* xf, void* out, int
   return 0;
 }
 
-TG_DROPOUT_TU(norm_ops)

@@ -165,72 +165,31 @@ extern "C" int tg_adam_step(float* p, float* g, float* m, float* v, void* p_bf16
 // ---------------------------------------------------------------- device-resident step state (HIP-graph replay)
 // A captured graph bakes every host-side scalar into its kernel nodes.  The three scalars of the train step that
 // change from step to step therefore live in a 32-byte device record `state`:
-//   word 0 (u64)  dropout seed word (XOR-ed into every kernel's seed argument: common.hpp:g_seed_xor)
+//   word 0 (u64)  dropout seed word (kernels read it through a TG_SEED_DEVICE seed argument: common.hpp:live_seed)
 //   word 1 (i64)  optimiser step count t
 //   word 2        two floats: lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)   (Adam's bias corrections for this t)
 //   word 3        reserved
-// tg_advance_step (one single-thread kernel, first node of the graph) moves the record to the next step and copies the
-// seed word into every translation unit that draws masks; tg_adam_step_dev reads the corrections from it.
+// tg_advance_step (one single-thread kernel, first node of the graph) moves the record to the next step;
+// tg_adam_step_dev reads the corrections from it.
 namespace tg {
-constexpr int SEED_TUS = 8;
-struct SeedWords { unsigned long long* w[SEED_TUS]; };
-// state == NULL: every unit's word back to zero.  advance == 0: only copy state[0] to the units.
-__global__ void k_step_advance(unsigned long long* __restrict__ state, float lr, float beta1, float beta2, int advance,
-                               const SeedWords words) {
+__global__ void k_step_advance(unsigned long long* __restrict__ state, float lr, float beta1, float beta2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned long long seed = 0ull;
-  if (state) {
-    if (advance) {
-      state[0] = state[0] * 6364136223846793005ULL + 1442695040888963407ULL;
-      const long long t = (long long)state[1] + 1;
-      state[1] = (unsigned long long)t;
-      const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
-      float* c = reinterpret_cast<float*>(state + 2);
-      c[0] = (float)((double)lr / bc1);
-      c[1] = (float)(1.0 / sqrt(bc2));
-    }
-    seed = state[0];
-  }
-#pragma unroll
-  for (int i = 0; i < SEED_TUS; ++i)
-    if (words.w[i]) *words.w[i] = seed;
-}
-static seed_word_addr_fn g_seed_addr_fns[SEED_TUS];
-static int g_n_seed_tus = 0;
-void seed_tu_register(seed_word_addr_fn fn) {
-  if (g_n_seed_tus < SEED_TUS) g_seed_addr_fns[g_n_seed_tus++] = fn;
-}
-static int seed_words(SeedWords& out) {
-  static SeedWords cached;
-  static bool have = false;
-  if (!have) {
-    for (int i = 0; i < SEED_TUS; ++i) {
-      cached.w[i] = i < g_n_seed_tus ? g_seed_addr_fns[i]() : nullptr;
-      if (i < g_n_seed_tus && !cached.w[i]) return -1;
-    }
-    have = true;
-  }
-  out = cached;
-  return 0;
-}
-static int step_advance(uint64_t* state, float lr, float beta1, float beta2, int advance, void* stream) {
-  SeedWords w;
-  TG_CHECK(seed_words(w) == 0, "tg_advance_step: %s", "could not resolve a unit's seed word");
-  hipLaunchKernelGGL(k_step_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)state, lr, beta1,
-                     beta2, advance, w);
-  TG_LAUNCH_CHECK();
-  return 0;
+  // (bit 63 stays clear: a seed word with it set would read as a device address, common.hpp:live_seed)
+  state[0] = (state[0] * 6364136223846793005ULL + 1442695040888963407ULL) & 0x7fffffffffffffffULL;
+  const long long t = (long long)state[1] + 1;
+  state[1] = (unsigned long long)t;
+  const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+  float* c = reinterpret_cast<float*>(state + 2);
+  c[0] = (float)((double)lr / bc1);
+  c[1] = (float)(1.0 / sqrt(bc2));
 }
 }  // namespace tg
 
-// every mask-drawing translation unit takes its seed word from state[0] (NULL: back to zero = host seeds alone)
-extern "C" int tg_seed_source_sync(const uint64_t* state, void* stream) {
-  return tg::step_advance(const_cast<uint64_t*>(state), 0.f, 0.f, 0.f, 0, stream);
-}
-
 extern "C" int tg_advance_step(uint64_t* state, float lr, float beta1, float beta2, void* stream) {
   TG_CHECK(state != nullptr, "tg_advance_step: %s", "state is NULL");
-  return tg::step_advance(state, lr, beta1, beta2, 1, stream);
+  hipLaunchKernelGGL(tg::k_step_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)state, lr, beta1, beta2);
+  TG_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int tg_adam_step_dev(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, float beta1,
@@ -253,13 +212,6 @@ extern "C" int tg_zero(void* p, int64_t bytes, void* stream) {
   return 0;
 }
 
-// Device-side row limit of the BatchNorm statistics (norm_ops.hip): rows >= *limit of a padded batch are left out of
-// the batch statistics and get a zero input gradient.  NULL (the default) = every row counts.
-namespace tg { const int* g_bn_row_limit = nullptr; }
-extern "C" int tg_set_bn_row_limit(const int32_t* limit_dev) {
-  tg::g_bn_row_limit = (const int*)limit_dev;
-  return 0;
-}
 
 extern "C" int tg_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
   if (n == 0) return 0;

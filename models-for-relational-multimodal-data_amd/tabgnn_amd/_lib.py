@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TABGNN_LIB_PATH") or os.path.join(_HERE, "libtabgnn_hip.so")     # (override: kernel A/B builds)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i32, _i64, _f32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
 
@@ -40,9 +40,9 @@ SIGNATURES = {
                           _u32, _vp, _i32, _vp],
     "tg_bn_partials_floats": [_i64, _i32],
     "tg_bn_act_res_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _i32, _f32,
-                          _f32, _i64, _i32, _i32, _vp],
+                          _f32, _i64, _i32, _vp, _i32, _vp],
     "tg_bn_act_res_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _i64,
-                          _i32, _i32, _vp],
+                          _i32, _vp, _i32, _vp],
     "tg_act_dropout_fwd": [_vp, _vp, _i64, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_act_dropout_bwd": [_vp, _vp, _vp, _i64, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_axpby": [_vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp],
@@ -100,10 +100,8 @@ SIGNATURES = {
     "tg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "tg_pna_post_fwd_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
     "tg_advance_step": [_vp, _f32, _f32, _f32, _vp],
-    "tg_seed_source_sync": [_vp, _vp],
     "tg_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i32, _vp],
     "tg_zero": [_vp, _i64, _vp],
-    "tg_set_bn_row_limit": [_vp],
     "tg_transpose_batched_bf16": [_vp, _vp, _vp, _i32, _vp],
 }
 _RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,

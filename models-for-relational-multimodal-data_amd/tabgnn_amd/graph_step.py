@@ -43,10 +43,10 @@ class StepState:
     def advance(self, lr, betas):
         L.call("tg_advance_step", L.ptr(self.buf), float(lr), float(betas[0]), float(betas[1]), L.stream())
 
-    @staticmethod
-    def release():
-        """Back to host seeds alone (kernels stop reading the seed word)."""
-        L.call("tg_seed_source_sync", None, L.stream())
+    def seed_arg(self):
+        """The ``seed`` argument that makes a kernel read THIS record's seed word when it runs
+        (``include/tabgnn_hip.h:TG_SEED_DEVICE``): an explicit per-launch argument, no library-side state."""
+        return (1 << 63) | self.buf.data_ptr()
 
 
 def bucket_size(n, floor=64):
@@ -176,6 +176,7 @@ class _Bucket:
         self.node_tf, self.edge_tf = frame("node", node_tf), frame("edge", edge_tf)
         self.graph = None
         self.loss = self.logits = None
+        self.err = []            # out-of-range flags of index structures built INSIDE the body (index=False), static memory
 
     def load(self, prep):
         if prep.layout != self.layout:
@@ -200,24 +201,32 @@ class GraphedTrainStep:
         # CSRs are then built by the index kernels INSIDE the graph, from the bucket's static edge_index
         self.index = bool(index)
         self.device = flat.flat.device
-        self.state = state if state is not None else StepState(self.device, t=opt.t)
+        self.host_seed = ops.DropoutRNG.seed         # (per rank under DataParallel)
+        # the record's seed word starts from the host seed, so ranks (and differently seeded runs) draw different masks
+        self.state = state if state is not None else StepState(self.device, seed=0x1234ABCD ^ self.host_seed, t=opt.t)
         self.buckets = {}
         self.pool = None
-        self.host_seed = ops.DropoutRNG.seed         # (per rank under DataParallel)
+        self.captured = None                 # (lr, betas) frozen into the graphs' tg_advance_step nodes
+        self.t_next = None                   # opt.t the device record expects at the next step (None: not stepped yet)
         flat.zero_grad()                     # afterwards every Adam launch leaves the gradients zeroed
 
     # ---- the step itself: every launch below is a kernel on the current stream
     def _body(self, b):
-        ops.DropoutRNG.new_step(self.host_seed)                 # host seed and stream ids: the same in every step ...
-        self.state.advance(self.opt.lr, self.opt.betas)         # ... the device seed word makes the masks differ
-        L.call("tg_set_bn_row_limit", L.ptr(b.static["n_real"]))       # read by BatchNorm's forward AND backward kernels
+        # every dropout launch of the body takes seed = TG_SEED_DEVICE(this record): the stream ids are the same in every
+        # step, the device seed word (advanced by the first node) makes the masks differ
+        ops.DropoutRNG.new_step(self.state.seed_arg())
+        self.state.advance(self.opt.lr, self.opt.betas)
+        ops.StepContext.set_bn_row_limit(b.static["n_real"])    # argument of BatchNorm's forward AND backward launches
+        pending = ops.take_index_errors()                       # flags of earlier eager work: handed back below, not dropped
         try:
-            ops.take_index_errors()          # (flags of index structures built inside a captured body are not read back)
             logits = self.model(b.node_tf, b.index(self.n_seed) if self.index else b.static["ei"], b.edge_tf)
             loss = ops.weighted_cross_entropy(logits[:self.n_seed], b.static["y"], self.loss_weight)
             loss.backward()
         finally:
-            L.call("tg_set_bn_row_limit", None)
+            ops.StepContext.set_bn_row_limit(None)
+            ops.DropoutRNG.new_step(self.host_seed)             # eager code after the step draws from host seeds again
+            b.err = ops.take_index_errors()                     # (index=False: the in-body conversions' flags, static memory)
+            ops.restore_index_errors(pending)
         if self.ddp is None:
             self.opt.step(zero_grad=True, state=self.state)
         return loss.detach(), logits.detach()
@@ -259,17 +268,39 @@ class GraphedTrainStep:
         g = torch.cuda.CUDAGraph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self.pool):
+        # thread_local: sampler threads keep running ``prepare_sample`` while a new bucket is captured, and their pinned
+        # allocations (hipHostMalloc / event queries of the caching host allocator) are refused under the default global
+        # capture mode — a worker would die and the loop would wait on its queue for ever
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
             b.loss, b.logits = self._body(b)
         b.graph = g
         torch.cuda.synchronize()
         self._restore(snap)
+        self.captured = (float(self.opt.lr), tuple(float(x) for x in self.opt.betas))
         self.buckets[prep.key] = b
         return b
+
+    def _check(self, prep):
+        """What a graph froze or assumes and the caller may have changed since (raise instead of silently ignoring it)."""
+        n_y = int(prep.tensors["y"].numel())
+        if n_y != self.n_seed:
+            raise ValueError(f"batch has {n_y} seed rows, this GraphedTrainStep was built for n_seed={self.n_seed} "
+                             "(a short last batch of an epoch needs its own instance or train_step)")
+        if self.captured is not None:
+            now = (float(self.opt.lr), tuple(float(x) for x in self.opt.betas))
+            if now != self.captured:
+                raise RuntimeError(f"opt.lr / opt.betas changed from {self.captured} to {now} after capture: the graphs hold "
+                                   "the old values (tg_advance_step node); build a new GraphedTrainStep")
+        if self.t_next is not None and self.opt.t != self.t_next:
+            raise RuntimeError(f"opt.t = {self.opt.t}, but the device step record is at {self.t_next}: an eager opt.step() ran "
+                               "between replays (Adam's bias corrections would go out of step)")
 
     def __call__(self, prep, frames=None):
         """``frames`` = (node_tf, edge_tf) templates, needed the first time a bucket is seen (column names, and for lazy
         frames the HBM-resident tables)."""
+        from .train import IndexGuard
+        IndexGuard.check()                   # raises for bad ids of an EARLIER step once their flag copy has landed
+        self._check(prep)
         b = self.buckets.get(prep.key)
         if b is None:
             if frames is None:
@@ -280,6 +311,10 @@ class GraphedTrainStep:
         if self.ddp is None:
             self.opt.t += 1                  # the Adam node ran inside the graph: mirror its device-side step count
         self._tail()
+        self.t_next = self.opt.t
+        if b.err:                            # index=False: the replay rewrote the flags of its in-graph index build
+            ops.restore_index_errors(b.err)
+            IndexGuard.collect()             # non-blocking copy; checked at the next step
         return b.loss, b.logits
 
     def run_eager(self, prep, frames):
@@ -288,7 +323,9 @@ class GraphedTrainStep:
         if b is None:
             b = _Bucket(prep, frames, self.device)
             self.buckets[prep.key] = b
+        self._check(prep)
         b.load(prep)
         loss, logits = self._body(b)
         self._tail()
+        self.t_next = self.opt.t
         return loss, logits

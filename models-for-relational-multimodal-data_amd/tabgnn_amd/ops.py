@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -20,7 +21,7 @@ class DropoutRNG:
     """Counter-based dropout: a mask is a pure function of (seed, stream id, element index), so the
     backward recomputes it.  ``seed`` advances once per training step, ``stream`` once per dropout site."""
     BASE_SEED = 0x5EED
-    seed = 0x5EED
+    seed = 0x5EED           # < 2^63: bit 63 of a seed argument marks a device seed word (include/tabgnn_hip.h:TG_SEED_DEVICE)
     _stream = 0
 
     @classmethod
@@ -30,8 +31,23 @@ class DropoutRNG:
 
     @classmethod
     def new_step(cls, seed=None):
-        cls.seed = (cls.seed * 6364136223846793005 + 1442695040888963407) & ((1 << 64) - 1) if seed is None else seed
+        cls.seed = (cls.seed * 6364136223846793005 + 1442695040888963407) & ((1 << 63) - 1) if seed is None else seed
         cls._stream = 0
+
+
+class StepContext:
+    """Per-step device-side inputs that a captured graph reads at run time, handed to the entry points as explicit
+    arguments (ABI v6: the library holds no such state): ``bn_row_limit`` = device int32 with the real row count of a padded
+    batch (BatchNorm statistics, ``tg_bn_act_res_fwd/bwd``) or None.  Thread-local: ``graph_step`` sets it around its body."""
+    _tl = threading.local()
+
+    @classmethod
+    def bn_row_limit(cls):
+        return getattr(cls._tl, "bn_row_limit", None)
+
+    @classmethod
+    def set_bn_row_limit(cls, t):
+        cls._tl.bn_row_limit = t
 
 
 _index_errors = []          # device error words of the index conversions since the last take_index_errors()
@@ -43,6 +59,12 @@ def take_index_errors():
     global _index_errors
     out, _index_errors = _index_errors, []
     return out
+
+
+def restore_index_errors(flags):
+    """Put flags taken by ``take_index_errors`` back in front of the pending list (a caller that only wanted to look)."""
+    global _index_errors
+    _index_errors = list(flags) + _index_errors
 
 
 class KernelTimer:
@@ -630,14 +652,16 @@ class _BatchNormActRes(torch.autograd.Function):
         n_stat = N
         if sync:
             import torch.distributed as dist
-            L.call("tg_bn_act_res_fwd", *args, 0, 1, L.dt(x), L.stream())
+            L.call("tg_bn_act_res_fwd", *args, 0, 1, None, L.dt(x), L.stream())
             vec = partials[512 * 2 * F:512 * 2 * F + 2 * F + 1]      # (sum x, sum x^2) + one slot for the row count
             vec[2 * F] = float(N)
             dist.all_reduce(vec, group=group)
             n_stat = int(round(float(vec[2 * F])))
-            L.call("tg_bn_act_res_fwd", *args, n_stat, 2, L.dt(x), L.stream())
+            L.call("tg_bn_act_res_fwd", *args, n_stat, 2, None, L.dt(x), L.stream())
         else:
-            L.call("tg_bn_act_res_fwd", *args, 0, 0, L.dt(x), L.stream())
+            # padded batch of a shape bucket: the statistics stop at the device-side real row count (forward AND backward)
+            ctx.row_limit = StepContext.bn_row_limit() if training else None
+            L.call("tg_bn_act_res_fwd", *args, 0, 0, L.ptr(ctx.row_limit), L.dt(x), L.stream())
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         ctx.cfg = (N, F, int(training), int(relu), alpha, beta_c, res is not None, group if sync else None, n_stat)
         return out
@@ -659,12 +683,12 @@ class _BatchNormActRes(torch.autograd.Function):
         tail = (L.ptr(partials), N, F, training, relu, alpha, beta_c)
         if group is not None:
             import torch.distributed as dist
-            L.call("tg_bn_act_res_bwd", *head, L.ptr(dparams), *tail, 0, 1, L.dt(x), L.stream())
+            L.call("tg_bn_act_res_bwd", *head, L.ptr(dparams), *tail, 0, 1, None, L.dt(x), L.stream())
             glob = dparams.clone()                 # parameter gradients stay LOCAL sums (the DP all-reduce averages them)
             dist.all_reduce(glob, group=group)
-            L.call("tg_bn_act_res_bwd", *head, L.ptr(glob), *tail, n_stat, 2, L.dt(x), L.stream())
+            L.call("tg_bn_act_res_bwd", *head, L.ptr(glob), *tail, n_stat, 2, None, L.dt(x), L.stream())
         else:
-            L.call("tg_bn_act_res_bwd", *head, L.ptr(dparams), *tail, 0, 0, L.dt(x), L.stream())
+            L.call("tg_bn_act_res_bwd", *head, L.ptr(dparams), *tail, 0, 0, L.ptr(ctx.row_limit), L.dt(x), L.stream())
         if add_res is not None:
             add_res.add_(dres)
         return (dx, dres if ret_res else None, dparams[1], dparams[0], None, None, None, None, None, None, None, None, None,

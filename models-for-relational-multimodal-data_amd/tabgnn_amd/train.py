@@ -140,7 +140,7 @@ class DataParallel:
         self.calls = self.bytes = 0        # collective bookkeeping (bench.py's `collective` object)
         if dist.is_initialized():       # per-rank dropout stream (fixed base + rank): ranks never share a mask,
             # and constructing a second DataParallel in the same process gives the same stream again
-            ops.DropoutRNG.seed = (ops.DropoutRNG.BASE_SEED + 0x9E3779B97F4A7C15 * dist.get_rank()) & ((1 << 64) - 1)
+            ops.DropoutRNG.seed = (ops.DropoutRNG.BASE_SEED + 0x9E3779B97F4A7C15 * dist.get_rank()) & ((1 << 63) - 1)
         if self.active:
             dist.broadcast(flat.flat, src=0)
             if sync_buffers:

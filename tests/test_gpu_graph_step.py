@@ -59,12 +59,12 @@ def test_padded_batch_gives_the_plain_batch_gradients(dtype):
     bucket.load(prep)
     T.ops.DropoutRNG.new_step(1234)
     flat.zero_grad()
-    L.call("tg_set_bn_row_limit", L.ptr(bucket.static["n_real"]))
+    T.ops.StepContext.set_bn_row_limit(bucket.static["n_real"])     # handed to the BatchNorm launches as their row_limit argument
     try:
         logits = model(bucket.node_tf, bucket.index(B), bucket.edge_tf)
         T.ops.weighted_cross_entropy(logits[:B], bucket.static["y"], lw).backward()
     finally:
-        L.call("tg_set_bn_row_limit", None)
+        T.ops.StepContext.set_bn_row_limit(None)
     assert logits.shape[0] == B
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     np.testing.assert_allclose(logits[:B].detach().float().cpu().numpy(), want_logits.cpu().numpy(), rtol=tol, atol=tol)
@@ -98,7 +98,6 @@ def test_graph_replays_equal_eager_steps_bit_for_bit():
         torch.cuda.synchronize()
         runs[mode] = (torch.stack(losses).float().cpu(), flat.flat.clone().cpu(), opt.m.clone().cpu(), opt.v.clone().cpu(),
                       {k: v.clone().cpu() for k, v in model.named_buffers()}, step.state.buf.clone().cpu(), opt.t)
-        G.StepState.release()
     e, g = runs["eager"], runs["graph"]
     assert e[6] == g[6] == steps
     assert torch.equal(e[5], g[5])                       # device step record: seed word, t, bias corrections
@@ -147,7 +146,6 @@ def test_graph_step_with_data_parallel_keeps_allreduce_and_adam_eager():
                 loss, _ = step(preps[i % 2], frames)
             torch.cuda.synchronize()
             out[mode] = (flat.flat.clone().cpu(), opt.m.clone().cpu(), opt.t, float(loss), None if ddp is None else ddp.calls)
-            G.StepState.release()
         assert out["ddp"][4] >= steps and out["plain"][2] == out["ddp"][2] == steps
         assert torch.equal(out["plain"][0], out["ddp"][0]) and torch.equal(out["plain"][1], out["ddp"][1])
     finally:
@@ -194,7 +192,6 @@ def test_sampled_lazy_batches_replay_over_several_buckets():
         losses = [(step.run_eager(p, frames) if mode == "eager" else step(p, frames))[0].clone() for p in preps]
         torch.cuda.synchronize()
         runs[mode] = (torch.stack(losses).float().cpu(), flat.flat.clone().cpu(), len(step.buckets))
-        G.StepState.release()
     assert runs["graph"][2] == len({p.key for p in preps})
     assert torch.isfinite(runs["eager"][0]).all()
     assert torch.equal(runs["eager"][0], runs["graph"][0]) and torch.equal(runs["eager"][1], runs["graph"][1])
@@ -224,6 +221,103 @@ def test_graph_step_for_a_wrapper_that_takes_the_plain_edge_index():
                   for i in range(steps)]
         torch.cuda.synchronize()
         runs[mode] = (torch.stack(losses).float().cpu(), flat.flat.clone().cpu())
-        G.StepState.release()
     assert torch.isfinite(runs["eager"][0]).all() and float(runs["eager"][0][0]) != float(runs["eager"][0][2])
     assert torch.equal(runs["eager"][0], runs["graph"][0]) and torch.equal(runs["eager"][1], runs["graph"][1])
+
+
+def test_two_graphed_steps_alive_in_one_process_do_not_share_state():
+    """ABI v6: the seed word and the BatchNorm row limit are ARGUMENTS of the launches (TG_SEED_DEVICE / row_limit), not
+    library globals — two GraphedTrainSteps with their own StepState, stepped alternately (replays of one between the
+    replays of the other, different true batch sizes in flight), end exactly where each ends when it runs alone."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G
+    B, steps = 48, 4
+    batches = [_resize(S.make_batch(B, seed=90 + i, device=DEV), 7 * i, 33 * i) for i in range(2)]
+    key = (G.bucket_size(max(b[1].shape[1] for b in batches)), G.bucket_size(max(b[0].num_rows for b in batches) + 1))
+    preps = [G.prepare(b, B, key=key) for b in batches]
+    frames = (batches[0][0], batches[0][2])
+
+    def make(seed):
+        model, flat, opt, lw = _model(B, torch.bfloat16, seed=seed)
+        return G.GraphedTrainStep(model, flat, opt, lw, B, state=G.StepState(DEV, seed=1000 + seed)), flat
+
+    alone = {}
+    for seed in (21, 22):
+        step, flat = make(seed)
+        for i in range(steps):
+            step(preps[(i + seed) % 2], frames)
+        torch.cuda.synchronize()
+        alone[seed] = (flat.flat.clone().cpu(), step.state.buf.clone().cpu())
+    a, fa = make(21)
+    b, fb = make(22)
+    for i in range(steps):                         # interleaved; the two see batches of different true size at the same time
+        a(preps[(i + 21) % 2], frames)
+        b(preps[(i + 22) % 2], frames)
+    torch.cuda.synchronize()
+    assert torch.equal(fa.flat.cpu(), alone[21][0]) and torch.equal(a.state.buf.cpu(), alone[21][1])
+    assert torch.equal(fb.flat.cpu(), alone[22][0]) and torch.equal(b.state.buf.cpu(), alone[22][1])
+    assert not torch.equal(alone[21][1][:1], alone[22][1][:1])        # two seed words
+    assert T.ops.DropoutRNG.seed < (1 << 63)                          # eager code after a step draws from host seeds again
+
+
+def test_capture_of_a_new_bucket_while_a_sampler_thread_pins_memory():
+    """A sampler thread keeps building pinned arenas (``prepare`` -> hipHostMalloc / event queries in the caching host
+    allocator) while the main thread captures a bucket: with capture_error_mode='thread_local' neither side fails."""
+    import threading
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G
+    B = 32
+    model, flat, opt, lw = _model(B, torch.bfloat16, seed=4)
+    step = G.GraphedTrainStep(model, flat, opt, lw, B)
+    host_batches = [S.make_batch(B, seed=70 + i) for i in range(3)]
+    errors, stop = [], threading.Event()
+
+    def worker():
+        k = 0
+        try:
+            while not stop.is_set():
+                b = host_batches[k % 3]
+                E, N = b[1].shape[1], b[0].num_rows
+                G.prepare(b, B, key=(G.bucket_size(E) + 64 * (k % 17), G.bucket_size(N + 1) + 32 * (k % 13)))   # ever new arena sizes
+                k += 1
+        except Exception as e:                      # noqa: BLE001 - the test reports it
+            errors.append(e)
+
+    th = threading.Thread(target=worker)
+    th.start()
+    try:
+        for i in range(3):                          # three buckets captured while the worker allocates
+            batch = tuple(t.to(DEV) if hasattr(t, "to") else t for t in host_batches[i])
+            E, N = batch[1].shape[1], batch[0].num_rows
+            prep = G.prepare(batch, B, key=(G.bucket_size(E) + 128 * i, G.bucket_size(N + 1) + 64 * i))
+            loss, _ = step(prep, (batch[0], batch[2]))
+            assert torch.isfinite(loss).item()
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    assert len(step.buckets) == 3
+
+
+def test_graphed_step_refuses_what_its_graphs_cannot_follow():
+    """Frozen or assumed values the caller changed: seed-row count of the batch, lr after capture, an eager optimiser step
+    between replays."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S, graph_step as G
+    B = 32
+    model, flat, opt, lw = _model(B, torch.bfloat16, seed=6)
+    step = G.GraphedTrainStep(model, flat, opt, lw, B)
+    batch = S.make_batch(B, seed=5, device=DEV)
+    prep = G.prepare(batch, B)
+    frames = (batch[0], batch[2])
+    step(prep, frames)
+    short = S.make_batch(B - 8, seed=6, device=DEV)
+    with pytest.raises(ValueError, match="seed rows"):
+        step(G.prepare(short, B - 8), frames)
+    opt.t += 1                                      # as an eager opt.step() would
+    with pytest.raises(RuntimeError, match="device step record"):
+        step(prep, frames)
+    opt.t -= 1
+    opt.lr *= 0.5
+    with pytest.raises(RuntimeError, match="after capture"):
+        step(prep, frames)
