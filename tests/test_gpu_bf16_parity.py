@@ -32,6 +32,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GATES = {"bf16": dict(c1=(0.17, 2e-3), c3=(0.28, 2e-3), c4=(0.17, 2e-3)), "fp32": dict(c1=(2e-3, 1e-5), c3=(2e-3, 1e-5), c4=(2e-3, 1e-5))}
 REL, ABS = 0.17, 2e-3
+SPREAD_GATE = 0.15          # bf16 vs fp32 on a state with spread node inputs: measured 0.07-0.115 on the first PNA layer's weights
+TWIN_GATE = 0.05            # benched (fused) bf16 kernels vs the plain bf16 composition of single-op kernels, same masks
+SUM_GATE = 0.05             # gradient sum over 16 batches, benched bf16 vs fp32 kernels (single batch: 0.07-0.15)
 LOGIT_ABS = {"bf16": 0.06, "fp32": 1e-4}
 DT = {"bf16": torch.bfloat16, "fp32": torch.float32}
 
@@ -40,13 +43,17 @@ def _feats(tf):
     return {k.value: v for k, v in tf.feat_dict.items()}
 
 
-def compare_gradients(model, want, flat=None, rel=REL, abs_=ABS, min_tensors=20, label=""):
-    """Every parameter gradient of ``model`` (after backward) against ``want`` (dict key -> fp32 oracle gradient)."""
+def compare_gradients(model, want, flat=None, rel=REL, abs_=ABS, min_tensors=20, label="", got=None):
+    """Every parameter gradient of ``model`` (after backward; or the saved copies ``got``) against ``want`` (dict key ->
+    reference gradient)."""
     gscale = max(v.double().norm().item() for v in want.values())
     rows = []
     for k, p in model.named_parameters():
         ref = want[k]
-        g = p.grad.detach().float().cpu() if p.grad is not None else torch.zeros_like(ref)
+        if got is not None:
+            g = got[k]
+        else:
+            g = p.grad.detach().float().cpu() if p.grad is not None else torch.zeros_like(ref)
         if flat is not None and p.grad is not None:
             assert flat.grad.data_ptr() <= p.grad.data_ptr() < flat.grad.data_ptr() + 4 * flat.grad.numel(), k
         den = ref.double().norm().item()
@@ -221,3 +228,146 @@ def test_configs4_wide64_c256_every_gradient(dt):
     assert (out.detach().float().cpu() - logits).abs().max().item() <= LOGIT_ABS[dt]
     assert abs(dl.item() - loss) <= (2e-2 if dt == "bf16" else 1e-4) * abs(loss)
     compare_gradients(model, want, flat, *GATES[dt]["c4"], min_tensors=120, label=f"configs[4] C=256 {dt}")
+
+
+@pytest.mark.parametrize("H", [4])
+def test_configs1_spread_state_bf16_gradients(H):
+    """the SAME benched bf16 kernels (fused column-transformer chain incl. the in-kernel feed-forward
+    weight gradients, gather-fused PNA projections, one-kernel post projection, MLP chain) on a NON-degenerate state: the
+    node ``relation`` input is drawn per node (the reference feeds a constant 1, ``ibm_transactions_for_aml.py:296-319``,
+    so at random init every node embedding in front of the first BatchNorm is the same row and bf16 rounding of the
+    common part was thought to dominate the gradient's small covariance).  MEASURED (round 4): it does not — with spread
+    node inputs the worst parameters are the same first-layer PNA weights at 0.07-0.115 (H = 4 / 8) as on the constant
+    input (0.07-0.094): the single-batch bf16 noise is flip noise (see the many-batch tests below), so this state keeps a
+    gate of SPREAD_GATE and the tight bound comes from the gradient sums.  H = 4 is the benched configuration."""
+    import tabgnn_amd as T
+    import tabgnn_amd.encoder_layer as EL
+    from oracle import step as ostep
+    from tabgnn_amd import synthetic as S
+    B = 1024
+    torch.manual_seed(41 + H)
+    cfg = S.make_config(128, 2, H, B, backbone_dropout=0.0, head_dropout=0.0, compute_dtype=torch.bfloat16)
+    model = T.TABGNNFusedS(cfg).train()
+    node_tf, ei, edge_tf, y = S.make_batch(B, seed=37, p_pos=0.3)
+    g = torch.Generator().manual_seed(5)
+    node_tf = T.TensorFrame({T.stype.relation: torch.randn(node_tf.num_rows, 1, generator=g) * 1.5 + 0.5}, node_tf.col_names_dict)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    lw = torch.tensor(cfg["loss_weights"])
+
+    def fwd(sd_):
+        lg = ostep.wrapper_forward(sd_, H, B, _feats(node_tf), ei, _feats(edge_tf), training=True)
+        return lg, ostep.weighted_ce(lg[:B], y.view(-1), lw)
+    logits, loss, want = _oracle_grads(sd, fwd)
+    model.to(DEV)
+    flat = T.FlatParams(model, shadow_dtype=torch.bfloat16)
+    flat.zero_grad()
+    n0 = dict(EL.STATS)
+    out = model(node_tf.to(DEV), ei.to(DEV), edge_tf.to(DEV))
+    dl = T.ops.weighted_cross_entropy(out[:B], y.to(DEV), lw.to(DEV))
+    dl.backward()
+    assert EL.STATS["fused_fwd"] > n0["fused_fwd"] and EL.STATS.get("fused_bwd_dw", 0) > n0.get("fused_bwd_dw", 0)
+    assert (out.detach().float().cpu() - logits).abs().max().item() <= LOGIT_ABS["bf16"]
+    compare_gradients(model, want, flat, SPREAD_GATE, 2e-3, min_tensors=90, label=f"configs[1] H={H} bf16, spread node inputs")
+
+
+class _plain_bf16_composition:
+    """Every fusion of the bf16 path switched off (the A/B switches of the package, flipped as module attributes): one-kernel
+    column-transformer layer and its chained backward, in-kernel weight gradients, fused tail LayerNorm, gradient sinks,
+    gather-fused GEMMs, one-kernel / scaled post projection, weight-fold kernel, MLP chain, timestamp GEMMs.  What is left
+    is the composition of single-op kernels that tests/test_gpu_ops.py, test_gpu_round2_ops.py pin one by one."""
+    SW = (("encoder_layer", "_FUSED_LAYER", False), ("encoder_layer", "_FUSED_TRAIN", False), ("encoder_layer", "_FUSED_TAIL", False),
+          ("encoder_layer", "_DW_FFN", False), ("ops", "GRAD_SINKS", False), ("ops", "_GATHER_GEMM", False),
+          ("ops", "_FUSED_POST", False), ("ops", "_POST_FWD_KERNEL", False), ("ops", "_FOLD_HIP", False),
+          ("ops", "MLP_CHAIN_MIN_ROWS", 1 << 40), ("encoders", "_TS_GEMM", False))
+
+    def __enter__(self):
+        import importlib
+        self.saved = []
+        for mod, name, val in self.SW:
+            m = importlib.import_module("tabgnn_amd." + mod)
+            self.saved.append((m, name, getattr(m, name)))
+            setattr(m, name, val)
+
+    def __exit__(self, *exc):
+        for m, name, val in self.saved:
+            setattr(m, name, val)
+
+
+def _accumulated(cfg_dtype, H, p_drop, batches, B, plain=False):
+    """Sum of the parameter gradients over ``batches`` (no zero_grad in between: .grad accumulation) for a model built from
+    torch seed 61 + H in compute dtype ``cfg_dtype``; returns also the gradients after the first batch alone."""
+    import contextlib
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    torch.manual_seed(61 + H)
+    cfg = S.make_config(128, 2, H, B, backbone_dropout=p_drop, head_dropout=0.083 if p_drop else 0.0, compute_dtype=cfg_dtype)
+    model = T.TABGNNFusedS(cfg).to(DEV).train()
+    flat = T.FlatParams(model, shadow_dtype=cfg_dtype)
+    lw = torch.tensor(cfg["loss_weights"], device=DEV)
+    flat.zero_grad()
+    first = None
+    with (_plain_bf16_composition() if plain else contextlib.nullcontext()):
+        for i, (node_tf, ei, edge_tf, y) in enumerate(batches):
+            T.ops.DropoutRNG.new_step(900 + i)
+            out = model(node_tf, ei, edge_tf)
+            T.ops.weighted_cross_entropy(out[:B], y, lw).backward()
+            if i == 0:
+                first = {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+    return model, flat, first, {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("H,p_drop", [(4, 0.0), (8, 0.0)])
+def test_benched_bf16_gradients_are_unbiased_over_many_batches(H, p_drop):
+    """VERDICT r03 weak 1b / item 4 — a step-level bound on any WRONG TERM in the benched bf16 kernels that is tighter than
+    the single-batch bf16 gate.  Measured this round: a single batch disagrees by 0.07-0.15 per parameter not only with
+    fp32 but also between two bf16 paths (benched kernels vs the plain composition of single-op bf16 kernels, identical
+    masks), and drawing the node inputs per node does not change that — the noise is discrete decisions flipping under
+    bf16 rounding (ReLU / LeakyReLU gates, max / min argmax routing of the PNA aggregators), each a 100 % local change, not
+    the degenerate BatchNorm input.  Such flips are independent from batch to batch while a wrong or mis-scaled term is
+    not: over K = 16 batches the gradient SUM (.grad accumulation, what an optimiser with gradient accumulation consumes)
+    of the benched bf16 path must agree with the fp32 kernels' sum (pinned to the oracle at 2e-3 by the fp32 twins above)
+    within SUM_GATE per parameter — well below the single-batch noise, which the test prints beside it.  Dropout 0 here (the
+    fp32 path allocates its dropout streams in another order, so its masks differ); the dropout-on twin is the next test."""
+    from tabgnn_amd import synthetic as S
+    import tabgnn_amd.encoder_layer as EL
+    B, K = 1024, 16
+    batches = [S.make_batch(B, seed=300 + i, device=DEV, p_pos=0.3) for i in range(K)]
+    n0 = dict(EL.STATS)
+    model, flat, first_b, sum_b = _accumulated(torch.bfloat16, H, p_drop, batches, B)
+    assert EL.STATS["fused_fwd"] > n0["fused_fwd"] and EL.STATS.get("fused_bwd_dw", 0) > n0.get("fused_bwd_dw", 0)
+    _, _, first_f, sum_f = _accumulated(torch.float32, H, p_drop, batches, B)
+    single = compare_gradients(model, first_f, None, 1.0, 1e-3, min_tensors=90, label=f"ONE batch, benched bf16 vs fp32 kernels, H={H} p={p_drop}",
+                               got=first_b)
+    rows = compare_gradients(model, sum_f, None, SUM_GATE, 1e-3, min_tensors=90,
+                             label=f"SUM over {K} batches, benched bf16 vs fp32 kernels, H={H} p={p_drop}", got=sum_b)
+    w1 = max(r[1] for r in single if r[2] >= 0.01)
+    wk = max(r[1] for r in rows if r[2] >= 0.01)
+    print(f"   worst large-tensor error: one batch {w1:.4f}, sum of {K} {wk:.4f}")
+    assert wk < 0.75 * w1                              # the disagreement averages out: noise, not bias
+
+
+@pytest.mark.parametrize("H", [4, 8])
+def test_benched_bf16_kernels_against_the_plain_bf16_composition(H):
+    """The dropout-ON twin (reference defaults 0.5 backbone / 0.083 head): the benched path against the plain composition of
+    single-op bf16 kernels — same weights, same batches, the SAME counter-based masks (every fused kernel draws the masks of
+    the ops it replaces; a mask mismatch shows as an error of order 1, as the fp32 path with its own stream order does).
+    Both carry bf16 rounding at slightly different points (the fused kernels keep q/k/v, the hidden activation and the PNA
+    concatenations in fp32 registers), so ONE batch differs by the same flip noise as above; the sum over K = 16 batches
+    must agree within TWIN_GATE per parameter."""
+    from tabgnn_amd import synthetic as S
+    import tabgnn_amd.encoder_layer as EL
+    B, K = 1024, 16
+    batches = [S.make_batch(B, seed=400 + i, device=DEV, p_pos=0.3) for i in range(K)]
+    n0 = dict(EL.STATS)
+    model, flat, first_b, sum_b = _accumulated(torch.bfloat16, H, 0.5, batches, B)
+    assert EL.STATS["fused_fwd"] > n0["fused_fwd"] and EL.STATS.get("fused_bwd_dw", 0) > n0.get("fused_bwd_dw", 0)
+    n1 = dict(EL.STATS)
+    _, _, first_p, sum_p = _accumulated(torch.bfloat16, H, 0.5, batches, B, plain=True)
+    assert EL.STATS["fused_fwd"] == n1["fused_fwd"]                       # the plain run took no fused kernel
+    single = compare_gradients(model, first_p, None, 0.4, 1e-3, min_tensors=90, label=f"ONE batch, benched vs plain bf16, H={H} p=0.5",
+                               got=first_b)
+    rows = compare_gradients(model, sum_p, None, TWIN_GATE, 1e-3, min_tensors=90,
+                             label=f"SUM over {K} batches, benched vs plain bf16, H={H} p=0.5", got=sum_b)
+    w1 = max(r[1] for r in single if r[2] >= 0.01)
+    wk = max(r[1] for r in rows if r[2] >= 0.01)
+    print(f"   worst large-tensor error: one batch {w1:.4f}, sum of {K} {wk:.4f}")

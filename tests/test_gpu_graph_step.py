@@ -34,18 +34,21 @@ def _resize(batch, extra_nodes, drop_edges):
     return (T.TensorFrame(feats, node_tf.col_names_dict), ei[:, :E].contiguous(), edge_tf[slice(0, E)], y)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_padded_batch_gives_the_plain_batch_gradients(dtype):
+@pytest.mark.parametrize("dtype,B", [(torch.float32, 48), (torch.bfloat16, 48), (torch.bfloat16, 1024)])
+def test_padded_batch_gives_the_plain_batch_gradients(dtype, B):
+    """The tie between a bucket's padded body and the unpadded step: same logits on the seed rows, same BatchNorm running
+    statistics, and EVERY parameter gradient (reported per parameter; B = 1024 is the size of the bf16 parity tests, where
+    the wide GEMM forms, the hub passes and several workgroups per kernel are in play)."""
     import tabgnn_amd as T
     from tabgnn_amd import synthetic as S, graph_step as G, _lib as L
-    B = 48
     model, flat, opt, lw = _model(B, dtype)
     batch = S.make_batch(B, seed=11, device=DEV)
     T.ops.DropoutRNG.new_step(1234)
     flat.zero_grad()
     logits = model(batch[0], batch[1], batch[2])
     T.ops.weighted_cross_entropy(logits[:B], batch[3].view(-1), lw).backward()
-    want_logits, want_grad = logits[:B].detach().float().clone(), flat.grad.clone()
+    want_logits = logits[:B].detach().float().clone()
+    want = {k: p.grad.detach().float().clone() for k, p in model.named_parameters()}
     want_rm = {k: v.clone() for k, v in model.named_buffers() if "running" in k}
 
     for k, b in model.named_buffers():           # undo the running-statistics update of the first pass
@@ -54,7 +57,7 @@ def test_padded_batch_gives_the_plain_batch_gradients(dtype):
         elif "running_var" in k:
             b.fill_(1.0)
     E, N = batch[1].shape[1], batch[0].num_rows
-    prep = G.prepare(batch, B, key=(E + 37, N + 5))
+    prep = G.prepare(batch, B, key=(E + 37 + B, N + 5 + B // 8))
     bucket = G._Bucket(prep, (batch[0], batch[2]), torch.device(DEV))
     bucket.load(prep)
     T.ops.DropoutRNG.new_step(1234)
@@ -68,9 +71,18 @@ def test_padded_batch_gives_the_plain_batch_gradients(dtype):
     assert logits.shape[0] == B
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     np.testing.assert_allclose(logits[:B].detach().float().cpu().numpy(), want_logits.cpu().numpy(), rtol=tol, atol=tol)
-    g, w = flat.grad, want_grad
-    err = float((g - w).norm() / w.norm())
-    assert err < (1e-4 if dtype == torch.float32 else 3e-2), err
+    gscale = max(float(v.norm()) for v in want.values())
+    # (bf16 at B = 48 the two runs take different small-problem GEMM routes: 0.5 %; at B = 1024 they agree to 1e-4)
+    rel, abs_ = (1e-4, 1e-6) if dtype == torch.float32 else ((3e-2, 1e-3) if B < 1024 else (2e-3, 1e-4))
+    rows = []
+    for k, p in model.named_parameters():
+        err, den = float((p.grad.float() - want[k]).norm()), float(want[k].norm())
+        rows.append((err / (rel * den + abs_ * gscale), err / max(den, 1e-30), den / gscale, k))
+    rows.sort(reverse=True)
+    print(f"padded vs plain batch, {dtype}, B={B}: worst 5 (gate ratio, rel. error, ||g||/max||g||, name)")
+    for r in rows[:5]:
+        print("   %.3f  %.5f  %.2e  %s" % r)
+    assert len(rows) > 90 and rows[0][0] <= 1.0, rows[:4]
     for k, v in model.named_buffers():
         if "running" in k:
             np.testing.assert_allclose(v.cpu().numpy(), want_rm[k].cpu().numpy(), rtol=1e-4, atol=1e-5)
