@@ -144,10 +144,14 @@ def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
     def work(w):
         for i in range(w, total, n_workers):
             ahead.acquire()
-            t0 = time.perf_counter()
-            eid, lei, nodes = samplers[w].sample(seeds[i], i)
-            pre = host_batch_index(lei, nodes.numel(), batch_size)      # the batch's CSRs, in the sampler thread
-            t_sample[i] = time.perf_counter() - t0
+            try:
+                t0 = time.perf_counter()
+                eid, lei, nodes = samplers[w].sample(seeds[i], i)
+                pre = host_batch_index(lei, nodes.numel(), batch_size)      # the batch's CSRs, in the sampler thread
+                t_sample[i] = time.perf_counter() - t0
+            except BaseException as e:      # noqa: BLE001 - handed to the consumer, which re-raises
+                slots[i].put(e)
+                return
             slots[i].put((eid, lei, nodes, pre))
 
     for w in range(n_workers):
@@ -156,7 +160,10 @@ def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
     timer = T.ops.KernelTimer(only=("tg_pna_aggregate_fwd",))      # 2 event pairs per step: the named kernel on THIS shape
     t_model = []
     for i in range(total):
-        eid, lei, nodes, pre = slots[i].get()
+        item = slots[i].get()
+        if isinstance(item, BaseException):
+            raise RuntimeError(f"sampler thread failed at batch {i}") from item
+        eid, lei, nodes, pre = item
         ahead.release()
         if i == warm:
             torch.cuda.synchronize(); t0 = time.perf_counter(); edges = n_nodes = 0
@@ -246,6 +253,31 @@ def count_launches(fn):
         return None
 
 
+def _child_env():
+    """Environment of a plain single-process child run on this GPU (no process-group variables of the parent)."""
+    return {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TABGNN_FORCE_ALLREDUCE",
+                         "TABGNN_DIST_BACKEND", "TABGNN_ONE_DEVICE", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK")}
+
+
+def fp32_twin(args):
+    """The SAME step (same workload, batch size, model) in fp32 — the reference's arithmetic (no mixed
+    precision anywhere in it) — beside the bf16 `value`: `python bench.py --dtype fp32 --steps 5 --warmup 2 --no-extras`
+    in a child process after the timed region.  fp32 activations, library GEMMs, the op-by-op column transformer."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp32", "--steps", "5", "--warmup", "2", "--no-extras",
+           "--batch-size", str(args.batch_size), "--hidden", str(args.hidden), "--layers", str(args.layers),
+           "--nhead", str(args.nhead), "--index", args.index]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=_child_env())
+        g = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"dtype": "fp32", "value": g["value"], "unit": g["unit"], "ms_per_step": g["ms_per_step"], "steps": g["steps"],
+                "peak_hbm_gb": g["config"].get("peak_hbm_gb"),
+                "what": "same B, E, N, model and step definition as `value`, fp32 storage and arithmetic (parity mode)"}
+    except Exception as e:      # noqa: BLE001 - reported, never fatal for the bench line
+        return {"error": repr(e)[:300]}
+
+
 def reference_batch(args, cdt, dev):
     """The reference's default batch (``utils.py:40-44``: --batch_size 200 -> E = 10 702 sampled edges): step time,
     edges/s and device launches per step of the same train step.  Outside the timed region of `value`."""
@@ -287,10 +319,7 @@ def reference_batch(args, cdt, dev):
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", "reference-batch-graph", "--dtype", args.dtype,
            "--hidden", str(args.hidden), "--layers", str(args.layers), "--nhead", str(args.nhead)]
     try:
-        env = {k: v for k, v in os.environ.items()      # the child is a plain single-process run on this GPU
-               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TABGNN_FORCE_ALLREDUCE",
-                            "TABGNN_DIST_BACKEND", "TABGNN_ONE_DEVICE", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK")}
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_child_env())
         g = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else None
     except Exception as e:      # noqa: BLE001 - reported, never fatal for the bench line
         r, g = None, None
@@ -343,10 +372,14 @@ def reference_batch_sampled_loop(cfg, cdt, dev, B, steps=120, warm=60):
     def work(w):
         for i in range(w, total, n_workers):
             ahead.acquire()
-            t0 = time.perf_counter()
-            eid, lei, nodes = samplers[w].sample(seeds[i], i)
-            prep = G.prepare_sample(eid, lei, nodes, labels[eid[:B]], B)
-            t_host[i] = time.perf_counter() - t0
+            try:
+                t0 = time.perf_counter()
+                eid, lei, nodes = samplers[w].sample(seeds[i], i)
+                prep = G.prepare_sample(eid, lei, nodes, labels[eid[:B]], B)
+                t_host[i] = time.perf_counter() - t0
+            except BaseException as e:      # noqa: BLE001 - handed to the consumer, which re-raises (never a silent hang on the queue)
+                slots[i].put(e)
+                return
             slots[i].put(prep)
 
     for w in range(n_workers):
@@ -355,6 +388,8 @@ def reference_batch_sampled_loop(cfg, cdt, dev, B, steps=120, warm=60):
     new_after_warm = 0
     for i in range(total):
         prep = slots[i].get()
+        if isinstance(prep, BaseException):
+            raise RuntimeError(f"sampler thread failed at batch {i}") from prep
         ahead.release()
         if i == warm:
             torch.cuda.synchronize(); t0 = time.perf_counter(); edges = 0
@@ -607,19 +642,37 @@ def step_roofline(E, N, B, S, C, F, L, b, n_params, ms_per_step):
                            "outputs once, no traffic for intermediates inside an operator (SURVEY 8d)")
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources of this tree (the GPU box has no .git): what a committed PMC summary is checked
+    against (tools/publish_profiles.py stamps the same hash into the file)."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(PKG, "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def pmc_profile(args, E_mean):
     """Counter-derived HBM bytes per launch from the newest committed PMC summary that matches this workload
-    (profiles/rNN_pmc_hbm_traffic.json; collected by separate rocprofv3 --pmc passes, never in this run)."""
+    (profiles/rNN_pmc_hbm_traffic.json; collected by separate rocprofv3 --pmc passes, never in this run).  A summary
+    collected from OTHER kernel sources than this tree's is refused (returns its path and the reason; `traffic` stays
+    null): VERDICT r03 found the r03 file one commit behind the kernels it was quoted for."""
     import glob
+    sha = kernel_source_sha()
+    stale = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
         try:
             pmc = json.load(open(path))
             wl = pmc["workload"]
             if (wl["batch_size"], wl["F"], wl["dtype"]) == (args.batch_size, args.hidden, args.dtype) and abs(wl["E"] - E_mean) < 1:
-                return os.path.relpath(path, ROOT), pmc
+                if pmc.get("kernel_source_sha256") != sha:
+                    stale = stale or (os.path.relpath(path, ROOT) + ": collected from other kernel sources (" +
+                                      str(pmc.get("commit", "no commit stamp"))[:12] + ") than this tree's: not quoted")
+                    continue
+                return os.path.relpath(path, ROOT), pmc, None
         except Exception:
             continue
-    return None, None
+    return None, None, stale
 
 
 def main():
@@ -717,7 +770,7 @@ def main():
     agg_ms = timer.mean_ms("tg_pna_aggregate_fwd")
     achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
     rows = E_mean + args.layers * args.batch_size
-    pmc_path, pmc = pmc_profile(args, E_mean)
+    pmc_path, pmc, pmc_stale = pmc_profile(args, E_mean)
     traffic = None
     if pmc is not None:
         key = [k for k in pmc["kernels"] if "k_pna_aggregate_fwd" in k]
@@ -742,7 +795,7 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (f"{pmc_path}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                         "command on this workload (committed file, NOT measured in this run)")
-                     if traffic is not None else None,
+                     if traffic is not None else pmc_stale,
                      "algorithmic_bytes_per_launch": agg_bytes, "avg_launch_ms": agg_ms,
                      "launches_timed": timer.count("tg_pna_aggregate_fwd"),
                      "bwd_avg_launch_ms": timer.mean_ms("tg_pna_aggregate_bwd")},
@@ -764,7 +817,7 @@ def main():
     # the headline number ~0.5 ms
     if extras and args.dtype == "bf16":
         names = ("tg_gemm_nt_bf16", "tg_gemm_tn_bf16", "tg_gemm_nt_gather3_bf16", "tg_gemm_tn_gather3_bf16",
-                 "tg_encoder_fwd_bf16", "tg_encoder_bwd_ffn_bf16", "tg_encoder_bwd_attn_bf16")
+                 "tg_encoder_fwd_bf16", "tg_encoder_bwd_ffn_bf16", "tg_encoder_bwd_ffn_dw_bf16", "tg_encoder_bwd_attn_bf16")
         gt = ops.KernelTimer(only=names)
         ops.KernelTimer.active = gt
         run(3, args.warmup + args.steps)
@@ -819,6 +872,14 @@ def main():
     if extras and not args.no_e2e and args.dtype == "bf16":
         out["end_to_end"] = end_to_end(model, flat, opt, loss_w, args.batch_size, args.e2e_steps, dev)
         out["roofline_sampled"] = out["end_to_end"].pop("roofline_sampled")
+        # (the driver keeps `config` whole but only the key names of extra objects: the aggregation's fraction on the
+        # batch the package's own sampler draws — fewer, denser destination rows — travels in the workload text)
+        rsf = out["roofline_sampled"].get("frac")
+        if rsf is not None:
+            out["config"]["workload"] += (f"; SpMM roofline frac {out['roofline']['frac']:.3f} on this synthetic batch, "
+                                          f"{rsf:.3f} on the sampler-drawn batch (roofline_sampled)")
+    if extras and args.dtype == "bf16":
+        out["fp32_twin"] = fp32_twin(args)
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
