@@ -11,7 +11,7 @@ rounding noise measured for it).  Per parameter
 
     ||g - g_ref||_F  <=  REL * ||g_ref||_F  +  ABS * max_k ||g_ref_k||_F
 
-Measured bf16 noise (round 3, tools/dbg_parity.py; dropout 0, random init): the error grows along the backward chain —
+Measured bf16 noise (round 3; dropout 0, random init): the error grows along the backward chain —
 configs[1]: decoder 0.0001 / 0.002 / 0.006 / 0.02, fuse MLP 0.03 -> 0.09, first PNA layer 0.10-0.14 (its post / message
 projection weights, whose gradient norms are 10-25 % of the model's largest: NOT small tensors), median 0.04;
 configs[3] (S = 130, loss over all 2 100 sampled nodes): 0.005 at the last decoder layer, 0.05-0.08 two layers up,

@@ -150,7 +150,7 @@ def test_fused_training_gradients_match_op_by_op_kernels(S, H, R, use_tail, alph
         worst.append((_relerr(g_f[k], g_u[k]), k))
     worst.sort(reverse=True)
     # linear1's gradients carry the ReLU gate: hidden units within bf16 rounding of zero flip between the two paths
-    # (both are 3-4 % from the fp32 gradient there, ~1 % elsewhere: tools/dbg_grad.py)
+    # (both are 3-4 % from the fp32 gradient there, ~1 % elsewhere; measured in round 3)
     assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
 
 

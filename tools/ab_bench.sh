@@ -1,6 +1,6 @@
 #!/bin/bash
-# same-box A/B of the default bench step: tools/r4_ab.sh "<env assignments of variant A>" "<... of variant B>" [bench args]
-# e.g. tools/r4_ab.sh "" "TABGNN_NO_DW_FFN=1"
+# same-box A/B of the default bench step: tools/ab_bench.sh "<env assignments of variant A>" "<... of variant B>" [bench args]
+# e.g. tools/ab_bench.sh "" "TABGNN_NO_DW_FFN=1"
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r4_ab; mkdir -p $OUT
 A="$1"; B="$2"; shift 2
 cd $R
