@@ -1270,6 +1270,9 @@ struct EaArgs {
   float* lnp;                    // [grid][4][128] partial sums: d gamma1, d beta1, 0, 0
 };
 
+#ifndef EA_TR_RECOMPUTE
+#define EA_TR_RECOMPUTE 0        // 1: round 3's second-orientation recompute of K / Q / V / dO (A/B builds)
+#endif
 constexpr int EF_T_ROWB = 80;    // transpose tile: 32 rows x 32 bf16 (64 B) padded to 80 B
 // Transpose of a 32 x 32 bf16 tile held as two packed fragments (lane (c, h), fragment s, element j <-> X[16s + 8(j>>2)
 // + 4h + (j&3)][c]) through LDS: returns the fragments of X^T in the same form.  tw = tile + 80 * tl + 8 * h (write
@@ -1452,11 +1455,15 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
         acc[4 * g] = b.x; acc[4 * g + 1] = b.y; acc[4 * g + 2] = b.z; acc[4 * g + 3] = b.w;
       }
       EF_CHAIN(acc, wa, 0, xf)
+      // K [key (rows), d], Q [q (rows), d]: operands of the products that contract over tokens.  EA_TR_RECOMPUTE = 0 (round
+      // 4): the 32 x 32 TRANSPOSES of the packed K^T / Q^T / V^T / dO^T tiles through the wave's LDS tile (4 ds_write_b64 +
+      // 4 ds_read_b64_tr_b16 each, no VALU) instead of a second projection chain per operand in the other MFMA orientation
+      // (8 MFMAs + 8 weight fragments + bias splat + pack each: 128 MFMAs and 128 ds_read_b128 per tile less)
+#if EA_TR_RECOMPUTE
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] *= qscale;
       const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
       EF_FENCE();
-      // K [key (rows), d], Q [q (rows), d]: operands of the products that contract over tokens
       EA_SPLAT(acc, plane[EF_P_BIN + 128])
       EA_CHAIN_TR(acc, wa, EF_PART_BYTES, xf)
       const ef_v8bf kt0 = ef_pack<0>(acc), kt1 = ef_pack<1>(acc);
@@ -1464,6 +1471,14 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
       EA_SPLAT(acc, plane[EF_P_BIN])
       EA_CHAIN_TR(acc, wa, 0, xf)
       const ef_v8bf qt0 = ef_pack<0>(acc), qt1 = ef_pack<1>(acc);
+#else
+      ef_v8bf kt0, kt1, qt0, qt1;
+      ef_transpose32(ef_pack<0>(acc), ef_pack<1>(acc), tw, ttr, qt0, qt1);        // the UNSCALED Q (dK = Q-contracted dS)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] *= qscale;
+      const ef_v8bf qf0 = ef_pack<0>(acc), qf1 = ef_pack<1>(acc);
+      ef_transpose32(kf0, kf1, tw, ttr, kt0, kt1);
+#endif
       // boundary: wait for unit 2 blk + 1; since its DMA was issued: the 8 block stores of the previous head block
       if (blk == 0) { EF_UNIT_NEXT_K(0, true, 2 * blk + 2, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
       else if (blk < 3) { EF_UNIT_NEXT_K(0, true, 2 * blk + 2, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
@@ -1471,10 +1486,12 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
 
       // ---- unit 2 blk + 1: Wv rows | Wo^T rows
       const char* wb = EF_UBUF(1);
+#if EA_TR_RECOMPUTE
       EA_SPLAT(acc, plane[EF_P_BIN + 256])
       EA_CHAIN_TR(acc, wb, 0, xf)                                        // V [key (rows), d]
       const ef_v8bf vt0 = ef_pack<0>(acc), vt1 = ef_pack<1>(acc);
       EF_FENCE();
+#endif
       acc = ef_zero16();
       EF_CHAIN(acc, wb, EF_PART_BYTES, dyf)                              // dO^T [d, q] = Wo^T rows . d_y
       const ef_v8bf dof0 = ef_pack<0>(acc), dof1 = ef_pack<1>(acc);
@@ -1486,10 +1503,16 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
       }
       EF_CHAIN(acc, wb, 0, xf)                                           // V^T [d, key]
       const ef_v8bf vf0 = ef_pack<0>(acc), vf1 = ef_pack<1>(acc);
+#if EA_TR_RECOMPUTE
       EF_FENCE();
       acc = ef_zero16();
       EA_CHAIN_TR(acc, wb, EF_PART_BYTES, dyf)                           // dO [q (rows), d]
       const ef_v8bf dotf0 = ef_pack<0>(acc), dotf1 = ef_pack<1>(acc);
+#else
+      ef_v8bf vt0, vt1, dotf0, dotf1;
+      ef_transpose32(vf0, vf1, tw, ttr, vt0, vt1);                       // V [key (rows), d]
+      ef_transpose32(dof0, dof1, tw, ttr, dotf0, dotf1);                 // dO [q (rows), d]
+#endif
       if (blk < 3) { EF_UNIT_NEXT(1, true, 2 * blk + 3, EF_UNIT_BYTES) }
       else { EF_UNIT_NEXT(1, has_next, 1, EF_UNIT_BYTES) }
 
