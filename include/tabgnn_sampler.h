@@ -22,6 +22,16 @@ int tg_sampler_sample(void* handle, const int64_t* seed_src, const int64_t* seed
                       const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
                       int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, int64_t* n_edges,
                       int64_t* n_nodes);
+/* The same sample in two phases, so that the caller allocates the outputs exactly: tg_sampler_draw runs the k-hop draw
+ * into the handle's staging and returns the output sizes (cap = upper bound on output edges, an error beyond it);
+ * tg_sampler_emit relabels and writes out_eid [n_edges], out_edge_index [2, ld] (ld >= n_edges; ld = n_edges: the
+ * compact [2, E] edge_index of main.py:48) and out_nodes [n_nodes], and returns the handle to idle.  One draw may be
+ * pending per handle; a new draw discards it. */
+int tg_sampler_draw(void* handle, const int64_t* seed_src, const int64_t* seed_dst, const int64_t* seed_eid, int64_t B,
+                    const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
+                    int64_t* n_edges, int64_t* n_nodes);
+int tg_sampler_emit(void* handle, int32_t num_threads, int64_t ld, int64_t* out_eid, int64_t* out_edge_index,
+                    int64_t* out_nodes);
 /* Stable counting sort of M keys in [0, N) on the host: rowptr int32 [N+1], perm int32 [M] = input positions, ascending
  * inside a segment — identical to the device's tg_csr_build (tabgnn_hip.h).  With it the sampler hands the batch's
  * CSR-by-destination / by-source to the aggregation kernels directly (get_graph_inputs + the scatter indices of

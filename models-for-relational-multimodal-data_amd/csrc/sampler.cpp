@@ -34,6 +34,8 @@ struct Graph {
   std::vector<int32_t> local;    // [num_nodes]  -1 = not in the current subgraph, else its local id (0 until relabelled)
   // reused output staging (capacity grows to the largest batch seen)
   std::vector<int32_t> e_src, e_dst, e_id, touched, frontier, next;
+  std::vector<int64_t> drawn_seeds;     // seed edge ids of the draw that awaits its tg_sampler_emit (their bits are set)
+  bool pending = false;                 // a draw has been made and not yet emitted
 };
 
 inline uint64_t splitmix64(uint64_t& s) {
@@ -119,16 +121,27 @@ int64_t tg_sampler_max_edges(int64_t B, const int32_t* fanout, int32_t hops) {
 //   out_edge_index [2, cap]     LOCAL node ids (row 0 = src at [0..n_edges), row 1 = dst at [cap..cap+n_edges))
 //   out_nodes [n_nodes]         sorted global node ids (local id = position)
 // Returns 0, or non-zero with tg_sampler_last_error().
-int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst, const int64_t* seed_eid, int64_t B,
-                      const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
-                      int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, int64_t* n_edges,
-                      int64_t* n_nodes) {
+static void sampler_reset(Graph& g) {      // the per-call scratch back to its idle state
+  for (int32_t v : g.touched) g.local[(size_t)v] = -1;
+  for (int64_t e : g.drawn_seeds)
+    if (e >= 0 && e < g.num_edges) g.seedbit[(size_t)e >> 6] = 0ull;
+  g.drawn_seeds.clear();
+  g.pending = false;
+}
+
+// Phase 1 of a sample: the k-hop draw into the handle's staging (global ids).  n_edges / n_nodes = the sizes of the
+// outputs tg_sampler_emit will write: the caller allocates them EXACTLY (round 3 sized every call for the worst case —
+// 81 MB of fresh pages for a 5 M-edge graph — and copied the used part out three times).
+int tg_sampler_draw(void* h, const int64_t* seed_src, const int64_t* seed_dst, const int64_t* seed_eid, int64_t B,
+                    const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
+                    int64_t* n_edges, int64_t* n_nodes) {
   Graph& g = *(Graph*)h;
   if (B <= 0 || hops < 0 || cap < B) {
     snprintf(g_err, sizeof(g_err), "tg_sampler_sample: bad arguments B=%lld hops=%d cap=%lld", (long long)B, hops,
              (long long)cap);
     return 1;
   }
+  if (g.pending) sampler_reset(g);      // a draw that was never emitted
   std::vector<int32_t>&e_src = g.e_src, &e_dst = g.e_dst, &e_id = g.e_id, &touched = g.touched, &frontier = g.frontier,
                       &next = g.next;
   e_src.clear(); e_dst.clear(); e_id.clear(); touched.clear(); frontier.clear();
@@ -143,6 +156,8 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
     e_src.push_back((int32_t)seed_src[i]); e_dst.push_back((int32_t)seed_dst[i]); e_id.push_back((int32_t)seed_eid[i]);
     if (seed_eid[i] >= 0 && seed_eid[i] < g.num_edges) g.seedbit[(size_t)seed_eid[i] >> 6] |= 1ull << (seed_eid[i] & 63);
   }
+  g.drawn_seeds.assign(seed_eid, seed_eid + B);
+  g.pending = true;
   // frontier 0 = sorted unique seed endpoints (torch.cat([src, dst]).unique())
   frontier.assign(e_src.begin(), e_src.end());
   frontier.insert(frontier.end(), e_dst.begin(), e_dst.end());
@@ -209,12 +224,27 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
         const int32_t v = frontier[(size_t)i];
         const int64_t base = g.colptr[(size_t)v], deg = g.colptr[(size_t)v + 1] - base;
         if (i + 4 < nf) __builtin_prefetch(&in[g.colptr[(size_t)frontier[(size_t)i + 4]]]);
+        // the two random touches of an edge (its source's slot of `local`, its bit of the seed bitmap) are requested 8
+        // edges ahead: the loop was bound by those misses (local is 2 MB for HI-Small, the in-edge lists 40 MB)
         if (k < 0 || deg <= k) {
-          for (int64_t p = 0; p < deg; ++p) take(in[base + p].src, v, in[base + p].eid);
+          for (int64_t p = 0; p < deg; ++p) {
+            if (p + 8 < deg) {
+              __builtin_prefetch(&local[(size_t)in[base + p + 8].src]);
+              __builtin_prefetch(&seedbit[(size_t)in[base + p + 8].eid >> 6]);
+            }
+            take(in[base + p].src, v, in[base + p].eid);
+          }
         } else {
           uint64_t rng = rng_seed ^ (0xD1B54A32D192ED03ULL * (uint64_t)(hop + 1)) ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(v + 1));
           sample_positions(deg, k, rng, pos);
-          for (int64_t p : pos) take(in[base + p].src, v, in[base + p].eid);
+          const int64_t np = (int64_t)pos.size();
+          for (int64_t q = 0; q < np; ++q) {
+            if (q + 8 < np) {
+              __builtin_prefetch(&local[(size_t)in[base + pos[(size_t)q + 8]].src]);
+              __builtin_prefetch(&seedbit[(size_t)in[base + pos[(size_t)q + 8]].eid >> 6]);
+            }
+            take(in[base + pos[(size_t)q]].src, v, in[base + pos[(size_t)q]].eid);
+          }
         }
       }
     }
@@ -225,34 +255,67 @@ int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst,
     frontier.swap(next);
   }
 
-  // relabel: every endpoint is a touched node (seed endpoints, expanded destinations, sampled sources);
-  // sorted unique endpoints (torch.unique) = sorted touched list, local id = rank
+  if (rc) { sampler_reset(g); return rc; }
+  *n_edges = (int64_t)e_id.size();
+  *n_nodes = (int64_t)touched.size();
+  return 0;
+}
+
+// Phase 2: relabel (sorted unique endpoints = sorted touched list, local id = rank: torch.unique) and write the outputs of
+// the pending draw — out_eid [n_edges], out_edge_index [2, ld] LOCAL ids (ld >= n_edges: ld = n_edges gives the compact
+// [2, E] array the wrappers take), out_nodes [n_nodes] sorted global ids — then return the handle's scratch to idle.
+int tg_sampler_emit(void* h, int32_t num_threads, int64_t ld, int64_t* out_eid, int64_t* out_edge_index,
+                    int64_t* out_nodes) {
+  Graph& g = *(Graph*)h;
+  if (!g.pending) {
+    snprintf(g_err, sizeof(g_err), "tg_sampler_emit: %s", "no pending draw");
+    return 1;
+  }
+  std::vector<int32_t>&e_src = g.e_src, &e_dst = g.e_dst, &e_id = g.e_id, &touched = g.touched;
+  int32_t* local = g.local.data();
   const int64_t ne = (int64_t)e_id.size();
   const int64_t nn = (int64_t)touched.size();
-  if (rc == 0) {
-    if (nn * 16 > g.num_nodes) {     // dense subgraph: one pass over the local-id array beats sorting
-      int64_t w = 0;
-      for (int64_t v = 0; v < g.num_nodes; ++v)
-        if (local[(size_t)v] >= 0) touched[(size_t)w++] = (int32_t)v;
-    } else {
-      std::sort(touched.begin(), touched.end());
-    }
-    for (int64_t i = 0; i < nn; ++i) { local[(size_t)touched[(size_t)i]] = (int32_t)i; out_nodes[i] = touched[(size_t)i]; }
-#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1 && ne >= 65536)
-    for (int64_t j = 0; j < ne; ++j) {
-      out_eid[j] = e_id[(size_t)j];
-      out_edge_index[j] = local[(size_t)e_src[(size_t)j]];
-      out_edge_index[cap + j] = local[(size_t)e_dst[(size_t)j]];
-    }
+  if (ld < ne || !out_eid || !out_edge_index || !out_nodes) {
+    snprintf(g_err, sizeof(g_err), "tg_sampler_emit: bad arguments ld=%lld n_edges=%lld", (long long)ld, (long long)ne);
+    sampler_reset(g);
+    return 1;
   }
-  // reset the per-call scratch
-  for (int64_t i = 0; i < nn; ++i) local[(size_t)touched[(size_t)i]] = -1;
-  for (int64_t i = 0; i < B; ++i)
-    if (seed_eid[i] >= 0 && seed_eid[i] < g.num_edges) g.seedbit[(size_t)seed_eid[i] >> 6] = 0ull;
-  if (rc) return rc;
-  *n_edges = ne;
-  *n_nodes = nn;
+#ifdef _OPENMP
+  const int nthreads = num_threads > 0 ? num_threads : omp_get_max_threads();
+#else
+  const int nthreads = 1;
+#endif
+  (void)nthreads;
+  if (nn * 16 > g.num_nodes) {     // dense subgraph: one pass over the local-id array beats sorting
+    int64_t w = 0;
+    for (int64_t v = 0; v < g.num_nodes; ++v)
+      if (local[(size_t)v] >= 0) touched[(size_t)w++] = (int32_t)v;
+  } else {
+    std::sort(touched.begin(), touched.end());
+  }
+  for (int64_t i = 0; i < nn; ++i) { local[(size_t)touched[(size_t)i]] = (int32_t)i; out_nodes[i] = touched[(size_t)i]; }
+#pragma omp parallel for num_threads(nthreads) schedule(static) if (nthreads > 1 && ne >= 65536)
+  for (int64_t j = 0; j < ne; ++j) {
+    if (j + 16 < ne) {
+      __builtin_prefetch(&local[(size_t)e_src[(size_t)j + 16]]);
+      __builtin_prefetch(&local[(size_t)e_dst[(size_t)j + 16]]);
+    }
+    out_eid[j] = e_id[(size_t)j];
+    out_edge_index[j] = local[(size_t)e_src[(size_t)j]];
+    out_edge_index[ld + j] = local[(size_t)e_dst[(size_t)j]];
+  }
+  sampler_reset(g);
   return 0;
+}
+
+// draw + emit in one call with worst-case-sized outputs (out_edge_index row stride = cap): the round-1 entry point
+int tg_sampler_sample(void* h, const int64_t* seed_src, const int64_t* seed_dst, const int64_t* seed_eid, int64_t B,
+                      const int32_t* fanout, int32_t hops, uint64_t rng_seed, int32_t num_threads, int64_t cap,
+                      int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, int64_t* n_edges,
+                      int64_t* n_nodes) {
+  int rc = tg_sampler_draw(h, seed_src, seed_dst, seed_eid, B, fanout, hops, rng_seed, num_threads, cap, n_edges, n_nodes);
+  if (rc) return rc;
+  return tg_sampler_emit(h, num_threads, cap, out_eid, out_edge_index, out_nodes);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -429,10 +492,11 @@ extern "C" int tg_host_csr(const int64_t* key, int64_t M, int64_t N, int32_t* ro
 //   5 perm by src [max(En,1)] | 6 seed endpoints [2B] (sources then destinations) | 7 rowptr of 6 [N+1] |
 //   8 perm of 6 [max(2B,1)] | 9 dst32[perm by dst] [En] | 10 src32[perm by dst] [En] | 11 inverse of perm by dst [En] |
 //   12 position in the dst-sorted layout of the edges in by-src order [En]
-// (stable counting sorts: the structures tg_csr_build makes on the device).  out == NULL: only the offsets.
+// (stable counting sorts: the structures tg_csr_build makes on the device).  out == NULL: only the offsets (edge_index may
+// be NULL then: they are a function of E, n_seed and N).
 extern "C" int tg_host_batch_index(const int64_t* edge_index, int64_t ld, int64_t E, int64_t n_seed, int64_t N,
                                    int32_t* out, int64_t* offsets) {
-  if (!edge_index || !offsets || E < 0 || n_seed < 0 || n_seed > E || ld < E || N <= 0 || E > 2147483647LL ||
+  if ((!edge_index && out) || !offsets || E < 0 || n_seed < 0 || n_seed > E || ld < E || N <= 0 || E > 2147483647LL ||
       N > 2147483646LL) {
     snprintf(g_err, sizeof(g_err), "tg_host_batch_index: bad arguments E=%lld n_seed=%lld N=%lld", (long long)E,
              (long long)n_seed, (long long)N);
@@ -450,31 +514,66 @@ extern "C" int tg_host_batch_index(const int64_t* edge_index, int64_t ld, int64_
   const int64_t *src = edge_index, *dst = edge_index + ld;
   std::fill(rp_d, rp_d + N + 1, 0); std::fill(rp_s, rp_s + N + 1, 0); std::fill(rp_t, rp_t + N + 1, 0);
   pm_d[0] = pm_s[0] = pm_t[0] = 0;
-  for (int64_t j = 0; j < E; ++j)
-    if (src[j] < 0 || src[j] >= N || dst[j] < 0 || dst[j] >= N) {
-      snprintf(g_err, sizeof(g_err), "tg_host_batch_index: edge %lld has a node id outside [0, %lld)", (long long)j, (long long)N);
-      return 1;
-    }
+  // one pass: range check (OR of the ids against N: a single compare per edge), int32 endpoints, both histograms, and
+  // whether the neighbour edges arrive GROUPED by destination (every destination's edges contiguous) — the k-hop sampler
+  // emits them so (a node is expanded once, its in-edges together), and then the by-destination structures are block
+  // copies instead of a random scatter per edge
+  const uint64_t un = (uint64_t)N;
+  bool bad = false, grouped = true;
+  for (int64_t i = 0; i < n_seed; ++i) bad |= ((uint64_t)src[i] >= un) | ((uint64_t)dst[i] >= un);
+  int32_t prev = -1;
   for (int64_t j = 0; j < En; ++j) {
-    const int32_t sj = (int32_t)src[n_seed + j], dj = (int32_t)dst[n_seed + j];
+    const int64_t s64 = src[n_seed + j], d64 = dst[n_seed + j];
+    if (((uint64_t)s64 >= un) | ((uint64_t)d64 >= un)) { bad = true; break; }
+    const int32_t sj = (int32_t)s64, dj = (int32_t)d64;
     src32[j] = sj; dst32[j] = dj;
+    if (dj != prev) { grouped &= rp_d[dj + 1] == 0; prev = dj; }
     ++rp_d[dj + 1]; ++rp_s[sj + 1];
+  }
+  if (bad) {
+    for (int64_t j = 0; j < E; ++j)
+      if (src[j] < 0 || src[j] >= N || dst[j] < 0 || dst[j] >= N) {
+        snprintf(g_err, sizeof(g_err), "tg_host_batch_index: edge %lld has a node id outside [0, %lld)", (long long)j, (long long)N);
+        return 1;
+      }
   }
   for (int64_t i = 0; i < n_seed; ++i) {
     tei[i] = (int32_t)src[i]; tei[n_seed + i] = (int32_t)dst[i];
     ++rp_t[tei[i] + 1]; ++rp_t[tei[n_seed + i] + 1];
   }
   for (int64_t n = 0; n < N; ++n) { rp_d[n + 1] += rp_d[n]; rp_s[n + 1] += rp_s[n]; rp_t[n + 1] += rp_t[n]; }
-  std::vector<int32_t> pd(rp_d, rp_d + N), ps(rp_s, rp_s + N), pt(rp_t, rp_t + N);
+  // scatter with the row pointers themselves as cursors (rp[n] ends at rp[n + 1]'s old value), shifted back afterwards
+  if (grouped) {
+    for (int64_t j = 0; j < En;) {                       // one block per destination
+      const int32_t d = dst32[j];
+      const int32_t k0 = rp_d[d], c = rp_d[d + 1] - k0;
+      for (int32_t q = 0; q < c; ++q) {
+        pm_d[k0 + q] = (int32_t)(j + q); inv[j + q] = k0 + q;
+        dst_sorted[k0 + q] = d; src_sorted[k0 + q] = src32[j + q];
+      }
+      j += c;
+    }
+  } else {
+    for (int64_t j = 0; j < En; ++j) pm_d[rp_d[dst32[j]]++] = (int32_t)j;
+    for (int64_t n = N; n > 0; --n) rp_d[n] = rp_d[n - 1];
+    rp_d[0] = 0;
+    for (int64_t k = 0; k < En; ++k) {
+      const int32_t j = pm_d[k];
+      dst_sorted[k] = dst32[j]; src_sorted[k] = src32[j]; inv[j] = (int32_t)k;
+    }
+  }
   for (int64_t j = 0; j < En; ++j) {
-    pm_d[pd[(size_t)dst32[j]]++] = (int32_t)j;
-    pm_s[ps[(size_t)src32[j]]++] = (int32_t)j;
+    if (j + 16 < En) __builtin_prefetch(&rp_s[src32[j + 16]], 1);
+    pm_s[rp_s[src32[j]]++] = (int32_t)j;
   }
-  for (int64_t i = 0; i < B2; ++i) pm_t[pt[(size_t)tei[i]]++] = (int32_t)i;
+  for (int64_t n = N; n > 0; --n) rp_s[n] = rp_s[n - 1];
+  rp_s[0] = 0;
+  for (int64_t i = 0; i < B2; ++i) pm_t[rp_t[tei[i]]++] = (int32_t)i;
+  for (int64_t n = N; n > 0; --n) rp_t[n] = rp_t[n - 1];
+  rp_t[0] = 0;
   for (int64_t k = 0; k < En; ++k) {
-    const int32_t j = pm_d[k];
-    dst_sorted[k] = dst32[j]; src_sorted[k] = src32[j]; inv[j] = (int32_t)k;
+    if (k + 16 < En) __builtin_prefetch(&inv[pm_s[k + 16]]);
+    s2s[k] = inv[pm_s[k]];
   }
-  for (int64_t k = 0; k < En; ++k) s2s[k] = inv[pm_s[k]];
   return 0;
 }

@@ -41,6 +41,11 @@ def _load():
         lib.tg_sampler_sample.argtypes = [C.c_void_p, i64p, i64p, i64p, C.c_int64, i32p, C.c_int32, C.c_uint64,
                                           C.c_int32, C.c_int64, i64p, i64p, i64p, i64p, i64p]
         lib.tg_sampler_sample.restype = C.c_int
+        lib.tg_sampler_draw.argtypes = [C.c_void_p, i64p, i64p, i64p, C.c_int64, i32p, C.c_int32, C.c_uint64,
+                                        C.c_int32, C.c_int64, i64p, i64p]
+        lib.tg_sampler_draw.restype = C.c_int
+        lib.tg_sampler_emit.argtypes = [C.c_void_p, C.c_int32, C.c_int64, i64p, i64p, i64p]
+        lib.tg_sampler_emit.restype = C.c_int
         lib.tg_host_csr.argtypes = [i64p, C.c_int64, C.c_int64, i32p, i32p]
         lib.tg_host_csr.restype = C.c_int
         lib.tg_host_batch_index.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i32p, i64p]
@@ -89,19 +94,21 @@ class NeighborSampler:
         bound = lib.tg_sampler_max_edges(B, fan.ctypes.data_as(C.POINTER(C.c_int32)), len(fan)) if (fan >= 0).all() \
             else self.num_edges + B
         cap = int(min(bound, self.num_edges + B))
-        out_eid = np.empty(cap, dtype=np.int64)
-        out_ei = np.empty((2, cap), dtype=np.int64)
-        out_nodes = np.empty(2 * cap, dtype=np.int64)
+        # two phases: the draw stays in the handle's staging and reports its sizes, the outputs are then allocated EXACTLY
+        # and written once (edge_index compact, row stride = n_edges) — no worst-case buffers, no copies of the used part
         ne, nn = C.c_int64(0), C.c_int64(0)
-        rc = lib.tg_sampler_sample(self._h, _p64(s_src), _p64(s_dst), _p64(seeds), B,
-                                   fan.ctypes.data_as(C.POINTER(C.c_int32)), len(fan), int(rng_seed) & (2 ** 64 - 1),
-                                   self.num_threads, cap, _p64(out_eid), _p64(out_ei), _p64(out_nodes), C.byref(ne),
-                                   C.byref(nn))
+        rc = lib.tg_sampler_draw(self._h, _p64(s_src), _p64(s_dst), _p64(seeds), B,
+                                 fan.ctypes.data_as(C.POINTER(C.c_int32)), len(fan), int(rng_seed) & (2 ** 64 - 1),
+                                 self.num_threads, cap, C.byref(ne), C.byref(nn))
         if rc != 0:
             raise RuntimeError(lib.tg_sampler_last_error().decode())
         ne, nn = ne.value, nn.value
-        return (torch.from_numpy(out_eid[:ne].copy()), torch.from_numpy(np.ascontiguousarray(out_ei[:, :ne])),
-                torch.from_numpy(out_nodes[:nn].copy()))
+        out_eid = np.empty(ne, dtype=np.int64)
+        out_ei = np.empty((2, ne), dtype=np.int64)
+        out_nodes = np.empty(nn, dtype=np.int64)
+        if lib.tg_sampler_emit(self._h, self.num_threads, ne, _p64(out_eid), _p64(out_ei), _p64(out_nodes)) != 0:
+            raise RuntimeError(lib.tg_sampler_last_error().decode())
+        return torch.from_numpy(out_eid), torch.from_numpy(out_ei), torch.from_numpy(out_nodes)
 
 
 def host_csr(keys, num_nodes):
@@ -134,6 +141,31 @@ def host_batch_index(edge_index, num_nodes, n_seed):
     if lib.tg_host_batch_index(*args, flat.ctypes.data_as(C.POINTER(C.c_int32)), _p64(off)) != 0:
         raise ValueError(lib.tg_sampler_last_error().decode())
     return flat, off, ei
+
+
+def host_index_offsets(E, num_nodes, n_seed):
+    """Part offsets (int64 [14], in int32 elements; [13] = total) of ``host_batch_index``'s array: a function of
+    (E, N, n_seed) alone."""
+    lib = _load()
+    off = np.zeros(14, dtype=np.int64)
+    if lib.tg_host_batch_index(None, int(E), int(E), int(n_seed), int(num_nodes), None, _p64(off)) != 0:
+        raise ValueError(lib.tg_sampler_last_error().decode())
+    return off
+
+
+def fill_host_batch_index(ei, num_nodes, n_seed, flat_out):
+    """``host_batch_index`` written into a caller-owned int32 buffer (``graph_step.prepare_sample``: a slot of the batch's
+    pinned arena).  ``ei``: C-contiguous int64 [2, E]."""
+    lib = _load()
+    E = ei.shape[1]
+    if not (ei.flags.c_contiguous and ei.dtype == np.int64 and flat_out.flags.c_contiguous and flat_out.dtype == np.int32):
+        raise ValueError("fill_host_batch_index: contiguous int64 edge_index and int32 output expected")
+    off = np.zeros(14, dtype=np.int64)
+    if lib.tg_host_batch_index(_p64(ei), E, E, int(n_seed), int(num_nodes), flat_out.ctypes.data_as(C.POINTER(C.c_int32)),
+                               _p64(off)) != 0:
+        raise ValueError(lib.tg_sampler_last_error().decode())
+    if int(off[13]) != flat_out.shape[0]:
+        raise ValueError("fill_host_batch_index: output buffer of the wrong size")
 
 
 def batch_index(edge_index, num_nodes, n_seed, device, prebuilt=None):
