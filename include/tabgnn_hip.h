@@ -335,14 +335,16 @@ int tg_encoder_bwd_ffn_dw_bf16(const void* g, const void* z1, const void* z2, vo
 int tg_encoder_dw_reduce(const float* dwp, const float* dbp, int64_t nblk, int32_t nw, float* const* out_w /*host [nw]*/,
                          float* const* out_b /*host [nw]*/, int32_t accumulate, void* stream);
 /* backward of the fused layer, attention half (4 or 8 heads): d_x1 -> LayerNorm-1 backward -> output projection
- * backward -> attention backward with q / k / v / probabilities recomputed from x.  Writes dx (partial:
- * tg_gemm_nt_bf16 then adds d_qkv W_in), the operands of the weight-gradient GEMMs: dy, o [R,S,128] and dqkv [R,S,384],
- * and (lnp, as above) the partial sums of d gamma1, d beta1 (rows 2, 3 zero). */
+ * backward -> attention backward with q / k / v / probabilities recomputed from x.  Writes dx, the operands of the
+ * weight-gradient GEMMs: dy, o [R,S,128] and dqkv [R,S,384], and (lnp, as above) the partial sums of d gamma1, d beta1
+ * (rows 2, 3 zero).  w_in_t = W_in^T [128, ld_it >= 384] (bf16): the input gradient of the QKV projection,
+ * d_x += d_qkv W_in, is then formed INSIDE the kernel (dx is final; wpack needs 7 stages); NULL: dx is the partial
+ * gradient and the caller adds d_qkv W_in with tg_gemm_nt_bf16 (wpack: 4 stages). */
 int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const void* x, const void* g /*d out; NULL if alpha == 0*/,
                              void* dx, void* dy, void* o, void* dqkv, const void* w_in /*[384,128]*/,
-                             const void* w_o_t /*Wo^T [128, ld_ot]*/, int32_t ld_ot,
-                             void* wpack /*4 x tg_encoder_stage_bytes()*/, const float* prm, int64_t R, int32_t S, int32_t H,
-                             float alpha, float eps, float p_drop, uint64_t seed, const uint32_t* rs, float* lnp,
+                             const void* w_o_t /*Wo^T [128, ld_ot]*/, int32_t ld_ot, const void* w_in_t, int32_t ld_it,
+                             void* wpack /*4 or 7 x tg_encoder_stage_bytes()*/, const float* prm, int64_t R, int32_t S,
+                             int32_t H, float alpha, float eps, float p_drop, uint64_t seed, const uint32_t* rs, float* lnp,
                              void* stream);
 int64_t tg_encoder_ln_partial_blocks(int64_t R, int32_t S);
 int tg_encoder_ln_reduce(const float* lnp, int64_t nblk, float* const* out /*host [4]: fp32 [128] or NULL*/,

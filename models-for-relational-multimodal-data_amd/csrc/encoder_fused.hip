@@ -1268,8 +1268,12 @@ struct EaArgs {
   unsigned rs0, rs1;
   int small_idx;
   float* lnp;                    // [grid][4][128] partial sums: d gamma1, d beta1, 0, 0
+  int dx_fold;                   // 1: d_x += d_qkv W_in inside the kernel (wpack stages 4..6 = the three [128,128] parts of W_in^T)
 };
 
+#ifndef EA_DX_LAST3
+#define EA_DX_LAST3 1            // d_x epilogue: 1 = the last head block's d_qkv slices parked in LDS (no wait for its stores, no re-read)
+#endif
 #ifndef EA_TR_RECOMPUTE
 #define EA_TR_RECOMPUTE 0        // 1: round 3's second-orientation recompute of K / Q / V / dO (A/B builds)
 #endif
@@ -1482,6 +1486,7 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
       // boundary: wait for unit 2 blk + 1; since its DMA was issued: the 8 block stores of the previous head block
       if (blk == 0) { EF_UNIT_NEXT_K(0, true, 2 * blk + 2, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
       else if (blk < 3) { EF_UNIT_NEXT_K(0, true, 2 * blk + 2, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
+      else if (a.dx_fold) { EF_UNIT_NEXT_K(0, true, 8, EF_UNIT_BYTES, EF_WAIT_VM(8)) }       // -> the d_x units
       else { EF_UNIT_NEXT_K(0, has_next, 0, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
 
       // ---- unit 2 blk + 1: Wv rows | Wo^T rows
@@ -1514,6 +1519,7 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
       ef_transpose32(dof0, dof1, tw, ttr, dotf0, dotf1);                 // dO [q (rows), d]
 #endif
       if (blk < 3) { EF_UNIT_NEXT(1, true, 2 * blk + 3, EF_UNIT_BYTES) }
+      else if (a.dx_fold) { EF_UNIT_NEXT(1, true, 9, EF_UNIT_BYTES) }
       else { EF_UNIT_NEXT(1, has_next, 1, EF_UNIT_BYTES) }
 
       // ---- per head
@@ -1643,9 +1649,78 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
         }
       }
       ef_store_block32(ef_pack<0>(o_all), ef_pack<1>(o_all), tw, tbr, ro, go_o, EF_C * 2, 64 * blk);
-      ef_store_block32(ef_pack<0>(dq_all), ef_pack<1>(dq_all), tw, tbr, rq, go_q, 3 * EF_C * 2, 64 * blk);
-      ef_store_block32(ef_pack<0>(dk_all), ef_pack<1>(dk_all), tw, tbr, rq, go_q, 3 * EF_C * 2, 256 + 64 * blk);
-      ef_store_block32(ef_pack<0>(dv_all), ef_pack<1>(dv_all), tw, tbr, rq, go_q, 3 * EF_C * 2, 512 + 64 * blk);
+      const ef_v8bf dqf0 = ef_pack<0>(dq_all), dqf1 = ef_pack<1>(dq_all), dkf0 = ef_pack<0>(dk_all), dkf1 = ef_pack<1>(dk_all),
+                    dvf0 = ef_pack<0>(dv_all), dvf1 = ef_pack<1>(dv_all);
+      ef_store_block32(dqf0, dqf1, tw, tbr, rq, go_q, 3 * EF_C * 2, 64 * blk);
+      ef_store_block32(dkf0, dkf1, tw, tbr, rq, go_q, 3 * EF_C * 2, 256 + 64 * blk);
+      ef_store_block32(dvf0, dvf1, tw, tbr, rq, go_q, 3 * EF_C * 2, 512 + 64 * blk);
+#if EA_DX_LAST3
+      if (blk == 3 && a.dx_fold) {      // parked lane-linear in the wave's idle staging bytes (region A and the tail of region B)
+        *reinterpret_cast<uint4*>(stg + lane16) = __builtin_bit_cast(uint4, dqf0);
+        *reinterpret_cast<uint4*>(stg + lane16 + 1024) = __builtin_bit_cast(uint4, dqf1);
+        *reinterpret_cast<uint4*>(stg + lane16 + 2048) = __builtin_bit_cast(uint4, dkf0);
+        *reinterpret_cast<uint4*>(stg + lane16 + 3072) = __builtin_bit_cast(uint4, dkf1);
+        *reinterpret_cast<uint4*>(stg + lane16 + 7168) = __builtin_bit_cast(uint4, dvf0);
+        *reinterpret_cast<uint4*>(stg + lane16 + 8192) = __builtin_bit_cast(uint4, dvf1);
+      }
+#endif
+    }
+    // ---- d_x += d_qkv W_in (round 4; was a separate 0.8 ms GEMM per big launch that re-read d_qkv and d_x from HBM):
+    //      d_x^T[c, token] = partial + sum over the 384 gradient channels of W_in^T[c, k] d_qkv[token, k], as three
+    //      128-deep parts (q | k | v) against units 8..13 = the [128,128] tiles of W_in^T, two 64-row units each.  The
+    //      wave reads back what it has just stored (the partial d_x and its d_qkv rows, L2-resident) in B-fragment order;
+    //      96 MFMAs per tile, no VALU beyond the unpack of the partial and the final pack.
+    if (a.dx_fold) {
+      // the stores of head blocks 0..2 and of the partial d_x (and the DMA of unit 9) have landed once at most the 8 block
+      // stores of head block 3 are outstanding; that block's d_qkv slices are still in registers (last3)
+      EF_WAIT_VM(EA_DX_LAST3 ? 8 : 0);
+      ef_v8bf bq[8], bn[8];
+      ef_f32x16 dxa[4];
+      {
+        const __amdgpu_buffer_rsrc_t rdx = ef_tile_rsrc(a.dx, tok0, nvalid);
+        EF_LOAD_X(bn, rdx)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dxa[m][i] = ef_bf(bn[2 * m + (i >> 3)], i & 7);
+      }
+      const unsigned qoff = (unsigned)(3 * EF_C * 2 * tl + 8 * h);
+#define EA_LOAD_PART(DST, P)                                                                          \
+      if (EA_DX_LAST3) {      /* k-steps 6, 7 = head block 3: parked in LDS by the loop above, never re-read from memory */ \
+        DST[6] = ef_frag(stg + ((P) == 2 ? 7168 : 2048 * (P)), lane16);                               \
+        DST[7] = ef_frag(stg + ((P) == 2 ? 8192 : 2048 * (P) + 1024), lane16);                        \
+      }                                                                                               \
+      _Pragma("unroll") for (int ks = 0; ks < (EA_DX_LAST3 ? 6 : 8); ++ks) {                          \
+        const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rq, qoff, 256 * (P) + 32 * ks, 0));      \
+        const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rq, qoff, 256 * (P) + 32 * ks + 16, 0)); \
+        DST[ks] = __builtin_bit_cast(ef_v8bf, make_uint4(lo.x, lo.y, hi.x, hi.y));                   \
+      }
+      EA_LOAD_PART(bq, 0)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {            // unit 8 + e in buffer e & 1: rows 64 (e & 1) .. of part e >> 1
+        const char* wu = EF_UBUF(e);
+        EF_CHAIN(dxa[2 * (e & 1)], wu, 0, bq)
+        EF_FENCE();
+        EF_CHAIN(dxa[2 * (e & 1) + 1], wu, EF_PART_BYTES, bq)
+        if (e == 0 || e == 2) {
+          // nothing newer than the DMA of unit 9 + e is in flight
+          EF_UNIT_NEXT_K(e, true, 10 + e, EF_UNIT_BYTES, EF_WAIT_VM(0))
+          if (e == 0) { EA_LOAD_PART(bn, 1) } else { EA_LOAD_PART(bn, 2) }       // the next part: 12 loads the next boundary lets fly
+        } else if (e == 1 || e == 3) {
+          EF_UNIT_NEXT_K(e, true, 10 + e, EF_UNIT_BYTES, EF_WAIT_VM(EA_DX_LAST3 ? 12 : 16))
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) bq[ks] = bn[ks];
+        } else if (e == 4) {
+          EF_UNIT_NEXT_K(4, has_next, 0, EF_UNIT_BYTES, EF_WAIT_VM(0))
+        } else {
+          EF_UNIT_NEXT_K(5, has_next, 1, EF_UNIT_BYTES, EF_WAIT_VM(0))
+        }
+      }
+#undef EA_LOAD_PART
+      ef_v8bf zo[8];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { zo[2 * m] = ef_pack<0>(dxa[m]); zo[2 * m + 1] = ef_pack<1>(dxa[m]); }
+      ef_store_rows(zo, la, ef_tile_rsrc(a.dx, tok0, nvalid));
     }
   }
   {
@@ -1657,9 +1732,17 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
 // wpack stage blk (0..3) = Wq rows | Wk rows | Wv rows | Wo^T rows (32 rows each, rows 32 blk ..), k-permuted images
 __global__ void __launch_bounds__(256) k_encoder_pack_attn_bwd(const unsigned short* __restrict__ w_in,
                                                                 const unsigned short* __restrict__ w_o_t, int ld_ot,
+                                                                const unsigned short* __restrict__ w_in_t, int ld_it,
                                                                 char* __restrict__ wpack) {
   const int stage = blockIdx.x;
   char* dst = wpack + (size_t)stage * EF_STAGE_BYTES;
+  if (stage >= 4) {        // stages 4..6: W_in^T[:, 128 (stage - 4) ..]: rows = input channel c, k = gradient channel of q | k | v
+    for (int p = threadIdx.x; p < 128 * 17; p += blockDim.x) {
+      const int row = p / 17, c = p - 17 * row;
+      ef_pack_row(dst + EF_ROWB * row, w_in_t + (size_t)row * ld_it + 128 * (stage - 4), c);
+    }
+    return;
+  }
   for (int p = threadIdx.x; p < 128 * 17; p += blockDim.x) {
     const int row = p / 17, c = p - 17 * row, part = row >> 5, r = row & 31;
     const unsigned short* wrow = part < 3 ? w_in + (size_t)(128 * part + 32 * stage + r) * EF_C
@@ -1996,16 +2079,18 @@ extern "C" int tg_encoder_ln_reduce(const float* lnp, int64_t nblk, float* const
 // Writes dx (partial: add d_qkv W_in to it), dy, o ([R,S,128]) and dqkv ([R,S,384]).
 extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const void* x, const void* g, void* dx, void* dy,
                                         void* o, void* dqkv, const void* w_in, const void* w_o_t, int32_t ld_ot,
-                                        void* wpack, const float* prm, int64_t R, int32_t S, int32_t H, float alpha,
-                                        float eps, float p_drop, uint64_t seed, const uint32_t* rs, float* lnp,
-                                        void* stream) {
+                                        const void* w_in_t, int32_t ld_it, void* wpack, const float* prm, int64_t R,
+                                        int32_t S, int32_t H, float alpha, float eps, float p_drop, uint64_t seed,
+                                        const uint32_t* rs, float* lnp, void* stream) {
   TG_CHECK(S >= 2 && S <= 32 && (H == 4 || H == 8), "tg_encoder_bwd_attn_bf16: unsupported geometry S=%d H=%d", S, H);
   TG_CHECK(dx1 && z1 && x && dx && dy && o && dqkv && w_in && w_o_t && wpack && prm && rs && lnp && (g || alpha == 0.f),
            "tg_encoder_bwd_attn_bf16: null operand");
   if (R <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_encoder_pack_attn_bwd, dim3(4), dim3(256), 0, st, (const unsigned short*)w_in,
-                     (const unsigned short*)w_o_t, ld_ot, (char*)wpack);
+  TG_CHECK(!w_in_t || (ld_it >= 384 && ld_it % 4 == 0 && (reinterpret_cast<uintptr_t>(w_in_t) & 7) == 0),
+           "tg_encoder_bwd_attn_bf16: W_in^T must be an 8-byte aligned [128, >=384] matrix (ld_it=%d)", ld_it);
+  hipLaunchKernelGGL(k_encoder_pack_attn_bwd, dim3(w_in_t ? 7 : 4), dim3(256), 0, st, (const unsigned short*)w_in,
+                     (const unsigned short*)w_o_t, ld_ot, (const unsigned short*)w_in_t, ld_it, (char*)wpack);
   EaArgs a;
   a.dx1 = (const unsigned short*)dx1; a.z1 = (const unsigned short*)z1; a.x = (const unsigned short*)x;
   a.g = (const unsigned short*)g; a.dx = (unsigned short*)dx; a.dy = (unsigned short*)dy; a.o = (unsigned short*)o;
@@ -2015,6 +2100,7 @@ extern "C" int tg_encoder_bwd_attn_bf16(const void* dx1, const void* z1, const v
   a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1];
   a.small_idx = ((double)(R + 32) * S * 128.0 < 4294967296.0 && (double)(R + 32) * H * S * S < 4294967296.0) ? 1 : 0;
   a.lnp = lnp;
+  a.dx_fold = w_in_t ? 1 : 0;
   const size_t lds = ef_lds_bytes();
   const unsigned grid = ef_grid(R, S);
   const int drop = drop_mode(a.thresh);      // DROP template value (common.hpp)

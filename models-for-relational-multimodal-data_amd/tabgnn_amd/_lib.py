@@ -85,8 +85,8 @@ SIGNATURES = {
     "tg_encoder_pack_tiles": [_vp, _vp, _i32, _vp, _vp],
     "tg_encoder_bwd_ffn_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _u64,
                                 _vp, _vp, _vp],
-    "tg_encoder_bwd_attn_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _f32,
-                                 _f32, _f32, _u64, _vp, _vp, _vp],
+    "tg_encoder_bwd_attn_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32,
+                                 _f32, _f32, _f32, _u64, _vp, _vp, _vp],
     "tg_encoder_ln_partial_blocks": [_i64, _i32],
     "tg_encoder_dw_blocks": [_i64, _i32],
     "tg_encoder_bwd_ffn_dw_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _u64, _vp, _vp, _vp, _vp,

@@ -25,6 +25,7 @@ _FUSED_TAIL = os.environ.get("TABGNN_NO_FUSED_TAIL") != "1"      # same-box A/B 
 _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B switch: the one-kernel layer (encoder_fused.hip)
 _FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
 _DW_FFN = os.environ.get("TABGNN_NO_DW_FFN") != "1"      # A/B: feed-forward weight gradients inside the chained backward kernel
+_DX_FOLD = os.environ.get("TABGNN_NO_DX_FOLD") != "1"    # A/B: d_x += d_qkv W_in inside the attention-half backward kernel
 
 
 STATS = {"fused_fwd": 0, "fused_bwd": 0, "fused_bwd_attn": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
@@ -374,13 +375,18 @@ def _fused_backward(ctx, g):
     wo_t = ops.wt(lw_o, p_o)
     if not wo_t.is_contiguous():
         wo_t = wo_t.contiguous()
-    wpack_a = torch.empty(4 * stage, dtype=torch.uint8, device=dev)
+    # d_x += d_qkv W_in inside the kernel (W_in^T as three more weight stages); _DX_FOLD off: the separate accumulating GEMM
+    win_t = ops.wt(lw_in, p_in) if _DX_FOLD else None
+    if win_t is not None and win_t.stride(1) != 1:
+        win_t = win_t.contiguous()
+    wpack_a = torch.empty((7 if _DX_FOLD else 4) * stage, dtype=torch.uint8, device=dev)
     d_x, d_y, o = (torch.empty(T, C, dtype=g.dtype, device=dev) for _ in range(3))
     d_qkv = torch.empty(T, 3 * C, dtype=g.dtype, device=dev)
     with_g = tail and alpha != 0.0
     lnp1 = torch.empty(nblk * 512, dtype=torch.float32, device=dev)
     ops._launch("tg_encoder_bwd_attn_bf16", L.ptr(d_x1), L.ptr(z1), L.ptr(x2d), L.ptr(g) if with_g else None, L.ptr(d_x),
                 L.ptr(d_y), L.ptr(o), L.ptr(d_qkv), L.ptr(lw_in.contiguous()), L.ptr(wo_t), wo_t.stride(0),
+                win_t.data_ptr() if win_t is not None else None, win_t.stride(0) if win_t is not None else 0,
                 L.ptr(wpack_a), L.ptr(prm), R, S, H, float(alpha) if with_g else 0.0, 1e-5, float(p), int(seed),
                 ctypes.addressof(rs_arr), L.ptr(lnp1), L.stream(), nbytes=2 * T * C * (9 + int(with_g)))
     STATS["fused_bwd_attn"] += 1
@@ -393,7 +399,8 @@ def _fused_backward(ctx, g):
     dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
     if dbin is None and dwin is not None:
         dbin = d_qkv.sum(0, dtype=torch.float32)
-    ops.gemm_nt(d_qkv, ops.wt(lw_in, p_in), None, ops.NT_ACCUM, out=d_x)
+    if not _DX_FOLD:
+        ops.gemm_nt(d_qkv, ops.wt(lw_in, p_in), None, ops.NT_ACCUM, out=d_x)
     return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dbo, dw1, db1, dw2, db2,
             dg1, dbe1, dg2, dbe2, dgt, dbt, None)
 
