@@ -209,6 +209,8 @@ int tg_gemm_nt_scaled_bf16(const void* X, const void* W, const float* scales, vo
  * three accumulator sets (one per scaler) combined in the epilogue; operands HBM/L2 -> LDS by LDS-DMA, 3-stage ring.
  * wcat [128, 3K] bf16 in tg_pna_fold_fwd's virtual-chunk order, wx [128,128] bf16, scales fp32 [>=R][2], K % 128 == 0.
  * (PNAConv.forward: post_nns + lin over [x | scalers x aggregators], torch_geometric 2.5.3, reached from fused.py:204-214) */
+int tg_pna_post_dagg_bf16(const void* g, const void* wt_cat /*[K,384] = [W_0^T | W_1^T | W_2^T]*/, const float* scales,
+                          void* dagg /*[R,K]*/, int64_t R, int32_t K, int64_t ld_g, int64_t ld_dagg, void* stream);
 int tg_pna_post_fwd_bf16(const void* agg, const void* x, const void* wcat, const void* wx, const float* bias,
                          const float* scales, void* out, int64_t R, int32_t K, int64_t ld_agg, int64_t ld_x,
                          int64_t ld_out, void* stream);

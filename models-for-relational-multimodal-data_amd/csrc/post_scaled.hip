@@ -57,6 +57,8 @@ struct PsArgs {
   unsigned short* out;
   long long R, ld_agg, ld_x, ld_out;            // row strides in elements
   int K;
+  int nct;                                      // column tiles of a wider output walked by ONE workgroup (1 = the forward)
+  long long w_ct_bytes, out_ct_cols;            // column tile ct: wcat += ct * w_ct_bytes, out += ct * out_ct_cols
 };
 
 __device__ __forceinline__ void ps_dma(unsigned voff, const char* sbase, unsigned lds_addr) {
@@ -76,6 +78,7 @@ __device__ __forceinline__ int ps_out_off(int row, int ch) {       // restaged o
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
+template <bool MULTI /* several column tiles per workgroup, no x / bias terms: the input-gradient use */>
 __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -90,10 +93,17 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
   // 16 different 16-byte slots of the 256-byte bank row.  row = 8*j + (l >> 3): (row >> 1) & 7 = (l >> 4) ^ 4*(j & 1).
   const int drow = lane >> 3;
   const unsigned dpos = (unsigned)((lane & 7) ^ (lane >> 4));
-  const int KT = a.K / PS_BK, T = KT + PS_F / PS_BK;
+  // T stages per column tile (x == NULL: no x Wx^T stages — the input-gradient use); with nct > 1 the stages of all the
+  // column tiles form ONE pipeline (global stage index tt, buffer tt & 1): the row tile's operand pieces are re-fetched
+  // per column tile (L2), the weights change, and a column tile's epilogue restages through the buffer its last stage
+  // just freed while the next tile's first stage is already landing in the other one
+  const int nct = MULTI ? a.nct : 1;        // (a full unroll over 4 column tiles: 43 spilled registers instead of 20)
+  const int KT = a.K / PS_BK, T = KT + (MULTI ? 0 : PS_F / PS_BK), TT = T * nct;
 
-  auto issue = [&](int t) {
-    const unsigned sb = lds0 + (unsigned)((t % PS_NSTAGE) * PS_STAGE);
+  auto issue = [&](int tt) {
+    const unsigned sb = lds0 + (unsigned)((tt % PS_NSTAGE) * PS_STAGE);
+    const int ct = MULTI ? (T == 2 ? tt >> 1 : tt / T) : 0, t = tt - ct * T;
+    const char* wcat = a.wcat + (MULTI ? (long long)ct * a.w_ct_bytes : 0ll);
     const bool tail = t >= KT;                                   // x Wx^T stages
     const int u = tail ? t - KT : t;
     const char* xb = tail ? a.x + (r0 * a.ld_x + (long long)PS_BK * u) * 2 : a.agg + (r0 * a.ld_agg + (long long)PS_BK * u) * 2;
@@ -115,21 +125,13 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
       // W_s[n, k] of the agg stages sits at wcat[n, ((k >> 7) * 3 + s) * 128 + (k & 127)] (virtual-chunk order of
       // tg_pna_fold_fwd); the tail stages read Wx for every set (only set 0 is multiplied)
       const char* wb = tail ? a.wx + 2ll * PS_BK * u
-                            : a.wcat + (((long long)(u >> 1) * 3 + s) * 128 + (long long)PS_BK * (u & 1)) * 2;
+                            : wcat + (((long long)(u >> 1) * 3 + s) * 128 + (long long)PS_BK * (u & 1)) * 2;
       ps_dma((unsigned)(8 * j + drow_o) * ldw + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), wb,
              sb + (unsigned)PS_XB + 1024u * (unsigned)i);
     }
   };
 
   ps_f32x16 acc[3][2][2];
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[s][p][b][i] = 0.f;
 
   // fragment lane offsets inside a piece: row r = lane & 31, 16-byte chunk 2*ks + (lane >> 5), swizzled
   const int fr = lane & 31, fh = lane >> 5;
@@ -144,9 +146,9 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
     if (!(PS_ABL & 4)) __builtin_amdgcn_s_barrier();                                                  \
     asm volatile("" ::: "memory");                                                                    \
-    if (!(PS_ABL & 2) && t + 1 < T) issue(t + 1);                                                     \
-    const char* xs = smem + (t % PS_NSTAGE) * PS_STAGE + (wr * 64) * PS_ROWB;                         \
-    const char* ws = smem + (t % PS_NSTAGE) * PS_STAGE + PS_XB + (wn * 64) * PS_ROWB;                 \
+    if (!(PS_ABL & 2) && tt + 1 < TT) issue(tt + 1);                                                  \
+    const char* xs = smem + (tt % PS_NSTAGE) * PS_STAGE + (wr * 64) * PS_ROWB;                        \
+    const char* ws = smem + (tt % PS_NSTAGE) * PS_STAGE + PS_XB + (wn * 64) * PS_ROWB;                \
     /* rolling fragment prefetch, one (k-step, set) group ahead: the reads of group g+1 are issued before the four   \
        MFMAs of group g (32 fragment registers: two A pairs, two B pairs) */                                          \
     ps_v8bf bA[2][2], aA[2][2];                                                                       \
@@ -170,45 +172,59 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
     }                                                                                                 \
   }
   issue(0);
-  int t = 0;
-  for (; t < KT; ++t) PS_STAGE_BODY(3)
-  for (; t < T; ++t) PS_STAGE_BODY(1)
-#undef PS_STAGE_BODY
-  __syncthreads();                                               // every wave is done reading the ring
+  int tt = 0;
+#pragma unroll 1
+  for (int ct = 0; ct < nct; ++ct) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[s][p][b][i] = 0.f;
+    for (int t = 0; t < KT; ++t, ++tt) PS_STAGE_BODY(3)
+    if constexpr (!MULTI) { for (int t = KT; t < T; ++t, ++tt) PS_STAGE_BODY(1) }
+    __syncthreads();                                             // every wave is done reading the buffer of stage tt - 1
+    char* og = smem + ((tt - 1) % PS_NSTAGE) * PS_STAGE;         // ... which takes the restaged output tile (64 of its 80 KiB)
+    unsigned short* outp = a.out + (MULTI ? (long long)ct * a.out_ct_cols : 0ll);
 
-  // ---- epilogue.  C/D map of a 32x32 tile: column (-> row r) = lane & 31, row (-> feature n) = (reg & 3) +
-  // 8*(reg >> 2) + 4*(lane >> 5): 4 consecutive n per register group.  amp / att are per-lane scalars.
+    // ---- epilogue.  C/D map of a 32x32 tile: column (-> row r) = lane & 31, row (-> feature n) = (reg & 3) +
+    // 8*(reg >> 2) + 4*(lane >> 5): 4 consecutive n per register group.  amp / att are per-lane scalars.
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int rl = wr * 64 + b * 32 + fr;
-    const long long rg = r0 + (rl < rows_here ? rl : rows_here - 1);
-    const float2 sc = *reinterpret_cast<const float2*>(a.scales + 2 * rg);
+    for (int b = 0; b < 2; ++b) {
+      const int rl = wr * 64 + b * 32 + fr;
+      const long long rg = r0 + (rl < rows_here ? rl : rows_here - 1);
+      const float2 sc = *reinterpret_cast<const float2*>(a.scales + 2 * rg);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < 2; ++p) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = wn * 64 + p * 32 + 8 * g + 4 * fh;
-        const float4 bv = *reinterpret_cast<const float4*>(a.bias + nl);
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        float v[4];
+        for (int g = 0; g < 4; ++g) {
+          const int nl = wn * 64 + p * 32 + 8 * g + 4 * fh;
+          const float4 bv = MULTI ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.bias + nl);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+          float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          v[j] = acc[0][p][b][4 * g + j] + bb[j] + sc.x * acc[1][p][b][4 * g + j] + sc.y * acc[2][p][b][4 * g + j];
-        uint2 pk;
-        pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *reinterpret_cast<uint2*>(smem + ps_out_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;
+          for (int j = 0; j < 4; ++j)
+            v[j] = acc[0][p][b][4 * g + j] + bb[j] + sc.x * acc[1][p][b][4 * g + j] + sc.y * acc[2][p][b][4 * g + j];
+          uint2 pk;
+          pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(og + ps_out_off(rl, nl >> 3) + 2 * (nl & 7)) = pk;
+        }
       }
     }
-  }
-  __syncthreads();
+    __syncthreads();
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {                                  // whole-row stores: piece -> (row, 16-byte chunk)
-    const int piece = tid + PS_THREADS * p, row = piece >> 4, ch = piece & 15;
-    if (row < rows_here)
-      *reinterpret_cast<uint4*>(a.out + (r0 + row) * a.ld_out + ch * 8) =
-          *reinterpret_cast<const uint4*>(smem + ps_out_off(row, ch));
+    for (int p = 0; p < 8; ++p) {                                // whole-row stores: piece -> (row, 16-byte chunk)
+      const int piece = tid + PS_THREADS * p, row = piece >> 4, ch = piece & 15;
+      if (row < rows_here)
+        *reinterpret_cast<uint4*>(outp + (r0 + row) * a.ld_out + ch * 8) =
+            *reinterpret_cast<const uint4*>(og + ps_out_off(row, ch));
+    }
+    // (the next stage's barrier comes before the DMA that refills this buffer: every wave has read its pieces by then)
   }
+#undef PS_STAGE_BODY
 }
 
 }  // namespace tg
@@ -234,7 +250,7 @@ extern "C" int tg_pna_post_fwd_bf16(const void* agg, const void* x, const void* 
            "tg_pna_post_fwd_bf16: %s", "row stride too large");
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pna_post_fwd), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pna_post_fwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
     attr = true;
   }
   const long long tiles = (R + PS_ROWS - 1) / PS_ROWS;
@@ -243,7 +259,41 @@ extern "C" int tg_pna_post_fwd_bf16(const void* agg, const void* x, const void* 
   a.agg = (const char*)agg; a.x = (const char*)x; a.wcat = (const char*)wcat; a.wx = (const char*)wx;
   a.bias = bias; a.scales = scales; a.out = (unsigned short*)out;
   a.R = R; a.ld_agg = ld_agg; a.ld_x = ld_x; a.ld_out = ld_out; a.K = K;
-  hipLaunchKernelGGL(k_pna_post_fwd, dim3((unsigned)tiles), dim3(PS_THREADS), PS_LDS, (hipStream_t)stream, a);
+  a.nct = 1; a.w_ct_bytes = 0; a.out_ct_cols = 0;
+  hipLaunchKernelGGL(k_pna_post_fwd<false>, dim3((unsigned)tiles), dim3(PS_THREADS), PS_LDS, (hipStream_t)stream, a);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// The input gradient of the same projection w.r.t. the aggregates, on the same kernel:
+//     dagg[r, :] = g[r] W_0 + amp(r) * (g[r] W_1) + att(r) * (g[r] W_2)          (dagg [R, K], g [R, 128])
+// Column tile j of dagg is a post projection with agg := g (K' = 128), W_s' := W_s[:, 128 j ..]^T and no x / bias terms;
+// wt_cat [K, 384] = [W_0^T | W_1^T | W_2^T] (what tg_pna_fold_fwd already writes for tg_gemm_nt_scaled_bf16) read as
+// K / 128 blocks of [128, 384] IS the kernel's virtual-chunk weight layout for K' = 128.  One workgroup walks the K / 128
+// column tiles of its row tile as ONE stage pipeline (separate launches per column tile have two stages each and ran
+// prologue-bound: no faster than the GEMM they replace).  Replaces tg_gemm_nt_scaled_bf16's VALU-rescaled operand copies (MFMA busy 0.24).
+extern "C" int tg_pna_post_dagg_bf16(const void* g, const void* wt_cat, const float* scales, void* dagg, int64_t R,
+                                     int32_t K, int64_t ld_g, int64_t ld_dagg, void* stream) {
+  TG_CHECK(R > 0 && K > 0 && K % 128 == 0, "tg_pna_post_dagg_bf16: need K %% 128 == 0 (R=%lld K=%d)", (long long)R, K);
+  TG_CHECK(g && wt_cat && scales && dagg, "tg_pna_post_dagg_bf16: %s", "null operand");
+  TG_CHECK(ld_g % 8 == 0 && ld_dagg % 8 == 0 && ld_g >= PS_F && ld_dagg >= K, "tg_pna_post_dagg_bf16: %s", "bad row strides");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(wt_cat) | reinterpret_cast<uintptr_t>(dagg)) & 15) == 0 &&
+               (reinterpret_cast<uintptr_t>(scales) & 7) == 0,
+           "tg_pna_post_dagg_bf16: %s", "operands must be 16-byte aligned");
+  TG_CHECK((long long)PS_ROWS * ld_g * 2 < (1ll << 31), "tg_pna_post_dagg_bf16: %s", "row stride too large");
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pna_post_fwd<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS);
+    attr = true;
+  }
+  const long long tiles = (R + PS_ROWS - 1) / PS_ROWS;
+  TG_CHECK(tiles <= 2147483647LL, "tg_pna_post_dagg_bf16: %s", "too many tiles");
+  PsArgs a;
+  a.agg = (const char*)g; a.x = nullptr; a.wcat = (const char*)wt_cat; a.wx = nullptr;
+  a.bias = nullptr; a.scales = scales; a.out = (unsigned short*)dagg;
+  a.R = R; a.ld_agg = ld_g; a.ld_x = 0; a.ld_out = ld_dagg; a.K = PS_F;
+  a.nct = K / 128; a.w_ct_bytes = 128ll * 384 * 2; a.out_ct_cols = 128;
+  hipLaunchKernelGGL(k_pna_post_fwd<true>, dim3((unsigned)tiles), dim3(PS_THREADS), PS_LDS, (hipStream_t)stream, a);
   TG_LAUNCH_CHECK();
   return 0;
 }

@@ -99,6 +99,7 @@ SIGNATURES = {
     "tg_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],
     "tg_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "tg_pna_post_fwd_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _i64, _vp],
+    "tg_pna_post_dagg_bf16": [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "tg_advance_step": [_vp, _f32, _f32, _f32, _vp],
     "tg_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp, _f32, _i32, _vp],
     "tg_zero": [_vp, _i64, _vp],

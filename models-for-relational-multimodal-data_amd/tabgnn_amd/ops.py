@@ -1270,6 +1270,7 @@ def degree_scalers(graph, avg_log):
 
 _FUSED_POST = os.environ.get("TABGNN_NO_FUSED_POST") != "1"
 _POST_FWD_KERNEL = os.environ.get("TABGNN_NO_POST_FWD_KERNEL") != "1"     # same-box A/B switch: the two-GEMM forward
+_POST_DAGG_KERNEL = os.environ.get("TABGNN_NO_POST_DAGG_KERNEL") != "1"   # same-box A/B switch: d agg on the scaled NT GEMM
 
 
 def post_scaled_ok(x, agg, agg_width=None):
@@ -1333,8 +1334,13 @@ class _PNAPostScaled(torch.autograd.Function):
         if dbx is None:
             dbx = g.sum(0, dtype=torch.float32)
         dagg = torch.empty_like(agg)
-        L.call("tg_gemm_nt_scaled_bf16", L.ptr(g), L.ptr(wt_cat), L.ptr(scales), L.ptr(dagg), N, K, F, g.stride(0),
-               dagg.stride(0), 0, L.stream())
+        if _POST_DAGG_KERNEL and F == 128 and wt_cat.is_contiguous():
+            # the forward's three-accumulator kernel, one launch over the K / 128 column tiles of dagg (post_scaled.hip)
+            _launch("tg_pna_post_dagg_bf16", L.ptr(g), L.ptr(wt_cat), L.ptr(scales), L.ptr(dagg), N, K, g.stride(0),
+                    dagg.stride(0), L.stream(), nbytes=2 * N * (K + F))
+        else:
+            L.call("tg_gemm_nt_scaled_bf16", L.ptr(g), L.ptr(wt_cat), L.ptr(scales), L.ptr(dagg), N, K, F, g.stride(0),
+                   dagg.stride(0), 0, L.stream())
         dw = torch.empty(3 * F, K, dtype=torch.float32, device=g.device)
         ws = _workspace(L.load().tg_gemm_tn_workspace_floats(N, 3 * F, K), g.device)
         L.call("tg_gemm_tn_scaled_bf16", L.ptr(g), L.ptr(agg), L.ptr(scales), L.ptr(dw), L.ptr(ws), N, F, K, g.stride(0),
