@@ -52,8 +52,20 @@ constexpr int EF_STAGE_BYTES = 4 * EF_PART_BYTES;     // 128 rows (34 KiB)
 #ifndef EF_WAVES_N
 #define EF_WAVES_N 4
 #endif
-#ifndef EF_DBUF
-#define EF_DBUF 0
+// Wait states behind every LDS-DMA instruction (see ef_dma), in units of `s_nop 7` (8 cycles).
+#ifndef EF_DMA_GAP
+#define EF_DMA_GAP 4
+#endif
+#if EF_DMA_GAP == 0
+#define EF_DMA_GAP_ASM
+#elif EF_DMA_GAP == 1
+#define EF_DMA_GAP_ASM "\n\ts_nop 7"
+#elif EF_DMA_GAP == 2
+#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7"
+#elif EF_DMA_GAP == 3
+#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+#else
+#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
 #endif
 #ifndef EF_WG_PER_CU
 #define EF_WG_PER_CU 2       // resident workgroups per CU the kernels are built for (waves per SIMD with EF_WAVES_N = 4)
@@ -63,7 +75,6 @@ constexpr int EF_STAGE_BYTES = 4 * EF_PART_BYTES;     // 128 rows (34 KiB)
 // workgroup per CU, whose waves all stall together).  EF_DBUF = 1: double-buffered stages (needs EF_WAVES_N = 8 to pay).
 constexpr int EF_WAVES = EF_WAVES_N;         // waves per workgroup
 constexpr int EF_THREADS = 64 * EF_WAVES;
-constexpr int EF_NBUF = EF_DBUF ? 2 : 1;
 constexpr int EF_NSTAGE = 7;              // 4 head blocks (Wq|Wk|Wv rows), Wo, W1, W2
 constexpr int EF_STG_ROWB = 144;          // output restage: 128-byte half rows padded to 144 B (one base + immediates)
 // fp32 parameter block (floats): b_in[384] | b_o | g1 | be1 | b1 | b2 | g2 | be2 | gt | bt  (128 each)
@@ -184,14 +195,24 @@ __device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 
 #endif
 
 // LDS-DMA of BYTES (rounded up to 1 KiB pieces: the images are padded accordingly) by the workgroup: one 1 KiB piece per
-// wave-instruction, pieces dealt round-robin to the waves.  The LDS destination and the piece's global base are formed
-// from the wave id in SGPRs, the lane adds 16 * lane (saddr form).
+// wave-instruction; wave w takes the contiguous run of pieces [w P, (w + 1) P), P = ceil(pieces / waves).
 // INLINE ASM on purpose: for the builtin (__builtin_amdgcn_global_load_lds) hipcc assumes that every later LDS access
 // may alias the DMA's destination and puts `s_waitcnt vmcnt(0)` in front of the next ds_read / ds_write — i.e. the wave
 // stalled for the full DMA latency right after issuing it, at every one of the 14 unit boundaries of a tile (the
 // "prefetch" never ran ahead).  Through asm the compiler sees no LDS write; the landing is awaited by the counted
 // `s_waitcnt vmcnt(K)` + barrier of the unit boundary (EF_UNIT_NEXT_K), and the "memory" clobber keeps the compiler from
-// moving or merging LDS reads across the statement.  M0 (the LDS base of the DMA) is saved and restored inside it.
+// moving or merging LDS reads across the statement.
+// M0 (the LDS base of a DMA) is saved, set per piece and restored inside the asm statement (the compiler does not honour
+// an M0 clobber; tests/test_cabi_and_host.py checks that these moves are the only M0 references in the compiled file).
+// `s_nop 4` in front of the DMA: hipcc may reload a spilled address pair with v_readlane right in front of the statement,
+// and a VALU-written SGPR needs 5 wait states before a vector-memory instruction reads it — the hazard recogniser does
+// not look inside inline asm (round 4: the dropout forward with its 138 spilled SGPRs faulted without it).
+// EF_DMA_GAP: round 4 found the p = 0 kernels NOT run-to-run deterministic with two workgroups per CU — one wave tile of
+// a CU's second workgroup, first iteration, 4-13 % of the launches at R = 13000, |error| 0.01-0.2 (tools/enc_det_probe.py).
+// One workgroup per CU never showed it; `s_waitcnt vmcnt(0)` at the boundaries, sleeps, LDS padding, an M0 written once
+// per call with immediate piece offsets (which the hardware adds to BOTH addresses: tools/hwtests/lds_dma_offset.hip) did
+// not remove it; 32 wait states behind every DMA instruction did (0 of 9000 launches, + 0.1 ms per step).  The mechanism
+// is not pinned down — back-to-back LDS-DMA issue from co-resident workgroups is what the data points at.
 template <int BYTES>
 __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_dst, int wave, int lane16) {
   constexpr int NP = (BYTES + 1023) / 1024;
@@ -203,35 +224,15 @@ __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_d
     const int q = p * EF_WAVES + wave;                         // wave-uniform piece
     if ((p + 1) * EF_WAVES <= NP || q < NP) {
       unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" EF_DMA_GAP_ASM "\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
                    : "memory");
     }
   }
 }
-// Stage pipeline of the backward kernels.  Double-buffered: stage g sits in buffer g & 1, the next stage's DMA is issued
-// on entry, one barrier on leaving.  Single-buffered: barrier (buffer free) -> DMA -> barrier (landed).
 // (the DMA is inline asm: the compiler does not wait for it at a __syncthreads(), EF_DMA_LANDED() does)
 #define EF_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#if EF_DBUF
-#define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
-  char* wb = (gstage & 1) ? wbuf1 : wbuf0;                                                            \
-  if (NEXT_VALID) ef_dma<EF_STAGE_BYTES>(a.wpack + (size_t)(NEXT) * EF_STAGE_BYTES, (gstage & 1) ? wbuf0 : wbuf1, wave, lane16);
-#define EF_STAGE_LEAVE() EF_DMA_LANDED(); __syncthreads(); gstage += 1;
-#define EF_PIPE_PROLOGUE() if (blockIdx.x < n_it) ef_dma<EF_STAGE_BYTES>(a.wpack, wbuf0, wave, lane16); EF_DMA_LANDED(); __syncthreads();
-#else
-#define EF_STAGE_ENTER(CUR, NEXT_VALID, NEXT)                                                         \
-  if (!(EF_ABL & 32)) {                                                                               \
-    __syncthreads();                                                                                  \
-    ef_dma<EF_STAGE_BYTES>(a.wpack + (size_t)(CUR) * EF_STAGE_BYTES, wbuf0, wave, lane16);            \
-    EF_DMA_LANDED();                                                                                  \
-    __syncthreads();                                                                                  \
-  }                                                                                                   \
-  char* wb = wbuf0;
-#define EF_STAGE_LEAVE()
-#define EF_PIPE_PROLOGUE() __syncthreads();
-#endif
 
 // mean / rstd of a token's 128 channels held as 8 packed fragments (this lane's 64 + the xor-32 partner's 64): ONE pass
 // over the bf16-rounded values (sum and sum of squares, packed fp32 math: one v_pk_add + one v_pk_fma per dword)
@@ -303,11 +304,13 @@ __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], const EfLa
       *reinterpret_cast<uint2*>(la.sw + 32 * ff) = make_uint2(v.x, v.y);
       *reinterpret_cast<uint2*>(la.sw + 32 * ff + 16) = make_uint2(v.z, v.w);
     }
+    uint4 rv[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rv[p] = *reinterpret_cast<const uint4*>(la.sr + 8 * p * EF_STG_ROWB);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const uint4 v = *reinterpret_cast<const uint4*>(la.sr + 8 * p * EF_STG_ROWB);
       if (!(EF_ABL & 2))
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, v), dst, la.go + (unsigned)(2048 * p), 128 * half, 0);   // (row in voffset: range-checked)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, rv[p]), dst, la.go + (unsigned)(2048 * p), 128 * half, 0);   // (row in voffset: range-checked)
     }
   }
 }

@@ -61,12 +61,18 @@ struct PsArgs {
   long long w_ct_bytes, out_ct_cols;            // column tile ct: wcat += ct * w_ct_bytes, out += ct * out_ct_cols
 };
 
-__device__ __forceinline__ void ps_dma(unsigned voff, const char* sbase, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(sbase), "s"(lds_addr)
-               : "memory");
+// LDS-DMA pieces of a stage.  M0 (the LDS base) is written once per GROUP of pieces whose LDS destinations are 1 KiB
+// apart; piece i of a group goes to M0 + 1024 (i - MID) through the instruction's immediate offset, which the hardware
+// adds to the global address too — the piece's scalar base is moved back by the same amount.  A `global_load_lds` may read
+// M0 some cycles after it has been issued (encoder_fused.hip:ef_dma, round 4: rounds 2-3 wrote and restored M0 around
+// every piece and now and then a piece landed at the wrong LDS address), so PS_M0_SETTLE() stands between the last DMA of
+// one group and the M0 write of the next.  hipcc does not use M0 in this file (checked by tests/test_cabi_and_host.py).
+#define PS_M0_SET(ADDR) asm volatile("s_mov_b32 m0, %0\n\ts_nop 4" ::"s"(ADDR) : "memory")
+#define PS_M0_SETTLE() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory")
+template <int OFF>
+__device__ __forceinline__ void ps_dma(unsigned voff, const char* sbase) {
+  // (s_nop 4: a v_readlane reload of the address pair right in front needs 5 wait states before a VMEM read; see ef_dma)
+  asm volatile("s_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff), "s"(sbase - OFF), "n"(OFF) : "memory");
 }
 
 __device__ __forceinline__ ps_v8bf ps_frag(const char* p) {
@@ -111,24 +117,30 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
     int drow_o = drow;
     unsigned dpos_o = dpos;
     asm volatile("" : "+v"(drow_o), "+v"(dpos_o));     // opaque: per-lane byte offsets are recomputed, not hoisted as live registers
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                      // X: 32 instructions, wave w takes j = 4w .. 4w+3
-      const int j = 4 * wave + i;
-      int rr = 8 * j + drow_o;
-      rr = rr < rows_here ? rr : rows_here - 1;        // clamped: rows past R are never stored
-      ps_dma((unsigned)rr * ldx + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), xb, sb + 1024u * (unsigned)j);
+    PS_M0_SET(sb + 1024u * (unsigned)(4 * wave + 2));
+#define PS_X_PIECE(I)                                                                                 \
+    {                                                  /* X: 32 instructions, wave w takes j = 4w .. 4w+3 */ \
+      const int j = 4 * wave + (I);                                                                   \
+      int rr = 8 * j + drow_o;                                                                        \
+      rr = rr < rows_here ? rr : rows_here - 1;        /* clamped: rows past R are never stored */     \
+      ps_dma<1024 * ((I) - 2)>((unsigned)rr * ldx + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), xb);   \
     }
+    PS_X_PIECE(0) PS_X_PIECE(1) PS_X_PIECE(2) PS_X_PIECE(3)
+#undef PS_X_PIECE
     const unsigned ldw = tail ? 2u * PS_F : 6u * (unsigned)a.K;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {                      // W: 3 sets x 16 instructions, wave w takes i = 6w .. 6w+5
-      const int i = 6 * wave + q, s = i >> 4, j = i & 15;
-      // W_s[n, k] of the agg stages sits at wcat[n, ((k >> 7) * 3 + s) * 128 + (k & 127)] (virtual-chunk order of
-      // tg_pna_fold_fwd); the tail stages read Wx for every set (only set 0 is multiplied)
-      const char* wb = tail ? a.wx + 2ll * PS_BK * u
-                            : wcat + (((long long)(u >> 1) * 3 + s) * 128 + (long long)PS_BK * (u & 1)) * 2;
-      ps_dma((unsigned)(8 * j + drow_o) * ldw + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), wb,
-             sb + (unsigned)PS_XB + 1024u * (unsigned)i);
+    PS_M0_SETTLE();
+    PS_M0_SET(sb + (unsigned)PS_XB + 1024u * (unsigned)(6 * wave + 3));
+#define PS_W_PIECE(Q)                                                                                 \
+    {                                                  /* W: 3 sets x 16 instructions, wave w takes i = 6w .. 6w+5 */ \
+      const int i = 6 * wave + (Q), s = i >> 4, j = i & 15;                                           \
+      /* W_s[n, k] of the agg stages sits at wcat[n, ((k >> 7) * 3 + s) * 128 + (k & 127)] (virtual-chunk order of    \
+         tg_pna_fold_fwd); the tail stages read Wx for every set (only set 0 is multiplied) */                          \
+      const char* wb = tail ? a.wx + 2ll * PS_BK * u                                                  \
+                            : wcat + (((long long)(u >> 1) * 3 + s) * 128 + (long long)PS_BK * (u & 1)) * 2;           \
+      ps_dma<1024 * ((Q) - 3)>((unsigned)(8 * j + drow_o) * ldw + 16u * (dpos_o ^ (unsigned)(4 * (j & 1))), wb);      \
     }
+    PS_W_PIECE(0) PS_W_PIECE(1) PS_W_PIECE(2) PS_W_PIECE(3) PS_W_PIECE(4) PS_W_PIECE(5)
+#undef PS_W_PIECE
   };
 
   ps_f32x16 acc[3][2][2];

@@ -110,3 +110,23 @@ def test_synthetic_batch_contract():
     assert edge_tf.num_rows == ei.shape[1] and edge_tf.num_cols == 5
     sub = edge_tf[:200, :]
     assert sub.num_rows == 200
+
+
+def test_only_the_dma_helpers_touch_m0():
+    """The LDS-DMA helpers (encoder_fused.hip:ef_dma, post_scaled.hip:PS_M0_SET) write M0 from inline assembly, and the
+    compiler does not honour an M0 clobber (M0 is a reserved register).  That is only sound while hipcc itself never
+    uses M0 in those translation units: compile them to gfx950 assembly and check that every M0 reference is one of the
+    helpers' own moves between M0 and an SGPR."""
+    import re
+    import subprocess
+    import tempfile
+    csrc = os.path.join(ROOT, "models-for-relational-multimodal-data_amd", "csrc")
+    for name in ("post_scaled.hip", "encoder_fused.hip"):
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "k.s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fno-strict-aliasing", "--offload-arch=gfx950",
+                                   "--cuda-device-only", "-S", os.path.join(csrc, name), "-o", out], stderr=subprocess.DEVNULL)
+            lines = [ln.strip() for ln in open(out) if re.search(r"\bm0\b", ln) and not ln.lstrip().startswith(";")]
+        assert lines, name                                                    # the helpers are there
+        other = [ln for ln in lines if not re.fullmatch(r"s_mov_b32 (m0, (s\d+|vcc_lo|vcc_hi)|(s\d+|vcc_lo|vcc_hi), m0)", ln)]
+        assert not other, (name, other[:5])
