@@ -153,6 +153,16 @@ int tg_act_dropout_fwd(const void* x, void* y, int64_t n, int32_t act, float p_d
 int tg_act_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t act, float p_drop, uint64_t seed,
                        uint32_t rstream, int32_t dt, void* stream);
 int tg_axpby(const void* a, const void* b, void* y, int64_t n, float alpha, float beta, int32_t dt, void* stream);
+/* y1 = alpha*a + beta*b (a NULL: beta*b) and y2 = gamma*b in one pass over b: the backward of the residual mixes
+ * (fused.py:254) when a's gradient goes to a shared gradient buffer. */
+int tg_axpby2(const void* a, const void* b, void* y1, void* y2, int64_t n, float alpha, float beta, float gamma, int32_t dt,
+              void* stream);
+/* out[C] fp32 (+)= column sums of x [R, C] with row stride ld (elements): the gradient of the shared CLS vector
+ * (column 0 of the [R, S, C] row gradient, fused.py:158-159).  workspace: tg_col_sum_workspace_floats(R, C) floats.
+ * Fixed summation order (no atomics). */
+int64_t tg_col_sum_workspace_floats(int64_t R, int32_t C);
+int tg_col_sum(const void* x, int64_t R, int32_t C, int64_t ld, float* out, float* workspace, int32_t accumulate, int32_t dt,
+               void* stream);
 /* CLS merge of the fused layer, fused.py:259-260 */
 int tg_cls_merge_fwd(const void* xtab /*[B,S,C]*/, const void* xf /*[B,D]*/, void* out, int64_t B, int32_t S,
                      int32_t C, int32_t D, int32_t dt, void* stream);

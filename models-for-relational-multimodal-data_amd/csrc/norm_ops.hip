@@ -576,6 +576,89 @@ __global__ void k_axpby(const T* __restrict__ a, const T* __restrict__ b, T* __r
   }
 }
 
+// y1 = alpha*a + beta*b and y2 = gamma*b in ONE pass over b (a == nullptr: y1 = beta*b): the backward of an axpby whose
+// first input's gradient goes to a shared gradient buffer (ops.GradSink) while the second input takes its own scaled copy
+template <typename T, int VEC>
+__global__ void k_axpby2(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y1, T* __restrict__ y2,
+                         long long n, float alpha, float beta, float gamma) {
+  long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * VEC;
+  long long stride = (long long)gridDim.x * blockDim.x * VEC;
+  for (; i < n; i += stride) {
+    float u[VEC], v[VEC], w[VEC];
+    loadv<T, VEC>(b + i, v);
+    if (a) {
+      loadv<T, VEC>(a + i, u);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) u[j] = alpha * u[j] + beta * v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) u[j] = beta * v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) w[j] = gamma * v[j];
+    storev<T, VEC>(y1 + i, u);
+    storev<T, VEC>(y2 + i, w);
+  }
+}
+
+// Column sums of a strided [R, C] matrix (the CLS-vector gradient: column 0 of a [R, S, C] gradient, fused.py:158-159):
+// block b sums rows [b chunk, (b+1) chunk) — C / VEC lanes across a row, 256 / (C / VEC) rows per pass — and writes
+// part[b][C]; k_col_sum_reduce adds the partials in block order (deterministic, no atomics).
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) k_col_sum_part(const T* __restrict__ x, long long R, int C, long long ld,
+                                                      long long chunk, float* __restrict__ part) {
+  __shared__ float red[256 * 8];
+  const int lpr = C / VEC, rpp = 256 / lpr;                  // lanes per row, rows per pass
+  const int lane = threadIdx.x % lpr, rg = threadIdx.x / lpr;
+  const long long r0 = blockIdx.x * chunk, r1 = r0 + chunk < R ? r0 + chunk : R;
+  float acc[VEC], acc2[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = acc2[j] = 0.f;
+  if (rg < rpp) {
+    long long r = r0 + rg;
+    for (; r + rpp < r1; r += 2 * rpp) {
+      float u[VEC], v[VEC];
+      loadv<T, VEC>(x + r * ld + lane * VEC, u);
+      loadv<T, VEC>(x + (r + rpp) * ld + lane * VEC, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { acc[j] += u[j]; acc2[j] += v[j]; }
+    }
+    if (r < r1) {
+      float u[VEC];
+      loadv<T, VEC>(x + r * ld + lane * VEC, u);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += u[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[threadIdx.x * VEC + j] = acc[j] + acc2[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+    for (int g = 0; g < rpp; ++g) t += red[(g * lpr + c / VEC) * VEC + c % VEC];
+    part[(long long)blockIdx.x * C + c] = t;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_col_sum_reduce(const float* __restrict__ part, int nblk, int C,
+                                                        float* __restrict__ out, int accumulate) {
+  __shared__ float red[256];
+  const int cpb = 32, strips = 256 / cpb;                    // 32 columns per block, 8 strips of partials each
+  const int c = blockIdx.x * cpb + threadIdx.x % cpb, strip = threadIdx.x / cpb;
+  float t = 0.f;
+  if (c < C) {
+    const int per = (nblk + strips - 1) / strips, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    for (int b = b0; b < b1; ++b) t += part[(long long)b * C + c];
+  }
+  red[threadIdx.x] = t;
+  __syncthreads();
+  if (strip == 0 && c < C) {
+    float u = 0.f;
+    for (int g = 0; g < strips; ++g) u += red[g * cpb + threadIdx.x];
+    out[c] = accumulate ? out[c] + u : u;
+  }
+}
+
 // CLS-token merge of the fused layer (fused.py:259-260): out = x_tab with token 0 <- (x_tab[:,0] + xf[:, :C]) / 2
 template <typename T, int VEC>
 __global__ void k_cls_merge_fwd(const T* __restrict__ xtab, const T* __restrict__ xf, T* __restrict__ out, long long B,
@@ -1017,6 +1100,50 @@ extern "C" int tg_axpby(const void* a, const void* b, void* y, int64_t n, float 
     hipLaunchKernelGGL((k_axpby<T, VEC>), dim3(grid_full(ceil_div(n / VEC, 256))), dim3(256), 0, (hipStream_t)stream,
                        (const T*)a, (const T*)b, (T*)y, (long long)n, alpha, beta);
   })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_axpby2(const void* a, const void* b, void* y1, void* y2, int64_t n, float alpha, float beta, float gamma,
+                         int32_t dt, void* stream) {
+  TG_CHECK(n % 8 == 0, "tg_axpby2: n must be a multiple of 8 (n=%lld)", (long long)n);
+  TG_CHECK(b && y1 && y2, "tg_axpby2: null operand");
+  if (n == 0) return 0;
+  DISPATCH_T(dt, {
+    hipLaunchKernelGGL((k_axpby2<T, VEC>), dim3(grid_full(ceil_div(n / VEC, 256))), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)a, (const T*)b, (T*)y1, (T*)y2, (long long)n, alpha, beta, gamma);
+  })
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int col_sum_blocks(int64_t R, int rows_per_pass) {
+  const int64_t want = ceil_div(R, (int64_t)rows_per_pass * 8);      // >= 8 passes per block
+  return (int)(want < 1 ? 1 : want > 1024 ? 1024 : want);
+}
+extern "C" int64_t tg_col_sum_workspace_floats(int64_t R, int32_t C) { return (int64_t)1024 * C; }
+
+// out[C] (fp32) (+)= sum over r of x[r*ld + 0..C)  — column sums of a strided matrix, in a fixed order
+extern "C" int tg_col_sum(const void* x, int64_t R, int32_t C, int64_t ld, float* out, float* workspace,
+                          int32_t accumulate, int32_t dt, void* stream) {
+  TG_CHECK(x && out && workspace, "tg_col_sum: null operand");
+  TG_CHECK(C > 0 && C % 8 == 0 && C <= 2048 && ld >= C && ld % 8 == 0 && R >= 0, "tg_col_sum: bad shape (R=%lld C=%d ld=%lld)",
+           (long long)R, C, (long long)ld);
+  TG_CHECK((reinterpret_cast<uintptr_t>(x) & 15) == 0, "tg_col_sum: x must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int nblk = 0;
+  if (R > 0) {
+    DISPATCH_T(dt, {
+      TG_CHECK(C / VEC <= 256, "tg_col_sum: C too wide");
+      const int rpp = 256 / (C / VEC);
+      nblk = col_sum_blocks(R, rpp);
+      const long long chunk = ceil_div(R, (int64_t)nblk);
+      hipLaunchKernelGGL((k_col_sum_part<T, VEC>), dim3(nblk), dim3(256), 0, st, (const T*)x, (long long)R, C, (long long)ld,
+                         chunk, workspace);
+      TG_LAUNCH_CHECK();
+    })
+  }
+  hipLaunchKernelGGL(k_col_sum_reduce, dim3(ceil_div(C, 32)), dim3(256), 0, st, workspace, nblk, C, out, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }

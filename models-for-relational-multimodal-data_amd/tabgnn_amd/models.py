@@ -57,7 +57,14 @@ class _PrependCLS(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        dcls = g[:, 0, :].sum(0, dtype=torch.float32)
+        R, S, C = g.shape
+        if g.is_cuda and g.stride(2) == 1 and g.stride(1) == C and C % 8 == 0 and g.dtype in (torch.bfloat16, torch.float32):
+            from . import _lib as L
+            dcls = torch.empty(C, dtype=torch.float32, device=g.device)
+            ws = ops._workspace(L.load().tg_col_sum_workspace_floats(R, C), g.device)
+            L.call("tg_col_sum", L.ptr(g), R, C, g.stride(0), L.ptr(dcls), L.ptr(ws), 0, L.dt(g), L.stream())
+        else:
+            dcls = g[:, 0, :].sum(0, dtype=torch.float32)
         return dcls, g[:, 1:, :]           # a view: the encoder's backward reads it in place (no copy of [R,ncols,C])
 
 

@@ -751,9 +751,14 @@ class _Axpby(torch.autograd.Function):
             g = g.contiguous()
             buf, acc, ret = ctx.sink_a.target(g.shape, g.dtype, g.device)
             # buf (+)= alpha * g   (first user: alpha*g + 0*g, so the uninitialised buffer is never read)
-            L.call("tg_axpby", L.ptr(buf if acc else g), L.ptr(g), L.ptr(buf), g.numel(), 1.0 if acc else 0.0, alpha,
-                   L.dt(g), L.stream())
-            gb = g if beta == 1.0 else g * beta
+            if beta == 1.0 or not ctx.needs_input_grad[1]:
+                L.call("tg_axpby", L.ptr(buf if acc else g), L.ptr(g), L.ptr(buf), g.numel(), 1.0 if acc else 0.0, alpha,
+                       L.dt(g), L.stream())
+                gb = g
+            else:                                            # buf (+)= alpha * g and gb = beta * g in one pass over g
+                gb = torch.empty_like(g)
+                L.call("tg_axpby2", L.ptr(buf) if acc else None, L.ptr(g), L.ptr(buf), L.ptr(gb), g.numel(), 1.0, alpha, beta,
+                       L.dt(g), L.stream())
             return (buf if ret else None), gb, None, None, None
         ga = g if alpha == 1.0 else g * alpha                 # one scaled copy serves both inputs when alpha == beta
         gb = ga if beta == alpha else (g if beta == 1.0 else g * beta)

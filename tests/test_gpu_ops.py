@@ -430,3 +430,55 @@ def test_tail_and_norm2_backward_in_one_kernel(dtype, alpha, p):
     for i in (0, 1, 2, 4):
         torch.testing.assert_close(acc_t[i], dp[i] + 2.0, rtol=1e-5, atol=1e-4)
     assert torch.all(acc_t[3] == 2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,S,C", [(1, 6, 128), (37, 6, 128), (50000, 6, 128), (4097, 3, 384), (0, 6, 128)])
+def test_col_sum_of_the_cls_column_matches_torch_and_repeats(T, dtype, R, S, C):
+    """`tg_col_sum`: the shared CLS vector's gradient = column 0 of the [R, S, C] row gradient summed over rows
+    (src/nn/models/fused.py:158-159 via autograd).  fp32 accumulation in a fixed order: equal to a float64 sum of the
+    same (rounded) inputs within fp32 summation error, and bit-identical run to run."""
+    from tabgnn_amd import _lib as L
+    from tabgnn_amd.models import _PrependCLS
+    torch.manual_seed(R + C)
+    g = torch.randn(R, S, C, device="cuda").to(dtype)
+    ref = g[:, 0, :].double().sum(0)
+    outs = []
+    for _ in range(2):
+        out = torch.full((C,), 7.0, device="cuda")
+        ws = torch.empty(L.load().tg_col_sum_workspace_floats(R, C), dtype=torch.float32, device="cuda")
+        L.call("tg_col_sum", L.ptr(g) if R else L.ptr(torch.empty(8, device="cuda", dtype=dtype)), R, C, S * C, L.ptr(out),
+               L.ptr(ws), 0, L.dt(g), L.stream())
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert (outs[0].double() - ref).abs().max().item() <= 1e-5 * max(1.0, (R ** 0.5) * 4)
+    acc = outs[0].clone()
+    L.call("tg_col_sum", L.ptr(g) if R else L.ptr(torch.empty(8, device="cuda", dtype=dtype)), R, C, S * C, L.ptr(acc),
+           L.ptr(ws), 1, L.dt(g), L.stream())
+    assert torch.allclose(acc, 2 * outs[0], rtol=1e-6, atol=1e-6)
+    if R:
+        class Ctx:
+            pass
+        dcls, rest = _PrependCLS.backward(Ctx(), g)
+        assert torch.equal(dcls, outs[0]) and rest.data_ptr() == g[:, 1:, :].data_ptr()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_axpby2_is_the_two_axpby_passes_in_one(T, dtype):
+    from tabgnn_amd import _lib as L
+    torch.manual_seed(0)
+    n = 8 * 12345
+    a = torch.randn(n, device="cuda").to(dtype)
+    b = torch.randn(n, device="cuda").to(dtype)
+    for with_a in (True, False):
+        y1, y2 = torch.empty_like(b), torch.empty_like(b)
+        L.call("tg_axpby2", L.ptr(a) if with_a else None, L.ptr(b), L.ptr(y1), L.ptr(y2), n, 1.0, 0.5, 0.25, L.dt(b), L.stream())
+        r1 = torch.empty_like(b)
+        L.call("tg_axpby", L.ptr(a if with_a else b), L.ptr(b), L.ptr(r1), n, 1.0 if with_a else 0.0, 0.5, L.dt(b), L.stream())
+        assert torch.equal(y1, r1)
+        assert torch.equal(y2, (b.float() * 0.25).to(dtype))
+    # in place on the first operand, as the gradient-buffer accumulation uses it
+    buf = a.clone()
+    gb = torch.empty_like(b)
+    L.call("tg_axpby2", L.ptr(buf), L.ptr(b), L.ptr(buf), L.ptr(gb), n, 1.0, 0.5, 0.5, L.dt(b), L.stream())
+    assert torch.equal(buf, (a.float() + 0.5 * b.float()).to(dtype))
