@@ -153,6 +153,22 @@ int tg_act_dropout_fwd(const void* x, void* y, int64_t n, int32_t act, float p_d
 int tg_act_dropout_bwd(const void* x, const void* dy, void* dx, int64_t n, int32_t act, float p_drop, uint64_t seed,
                        uint32_t rstream, int32_t dt, void* stream);
 int tg_axpby(const void* a, const void* b, void* y, int64_t n, float alpha, float beta, int32_t dt, void* stream);
+/* ClassifierHead / NodeClassificationHead readout MLP (src/nn/gnn/decoder.py:5-32: Linear(D0,50) ReLU Dropout
+ * Linear(50,25) ReLU Dropout Linear(25,NC)) as one forward and one backward kernel.  h0 [B,D0], w1 [50,D0], w2 [25,50]
+ * in the activation dtype dt; biases, w3 [NC,25] and logits [B,NC] fp32; z1 [B,50], z2 [B,25] (dt) are the saved
+ * pre-activations.  rs1 / rs2: dropout stream ids of the two Dropout sites (masks = those of tg_act_dropout_fwd on
+ * the same (seed, stream, element index)).  Supported: D0 % 8 == 0, D0 <= 512, H1 == 50, H2 == 25, NC <= 10
+ * (tg_head_mlp_supported).  Backward: dh0 [B,D0] (dt); parameter gradients fp32, written (accumulate 0) or added
+ * (accumulate 1: .grad += semantics) in a fixed order; workspace tg_head_mlp_partial_floats() floats. */
+int32_t tg_head_mlp_supported(int32_t D0, int32_t H1, int32_t H2, int32_t NC);
+int64_t tg_head_mlp_partial_floats(int32_t D0, int32_t H1, int32_t H2, int32_t NC);
+int tg_head_mlp_fwd(const void* h0, const void* w1, const float* b1, const void* w2, const float* b2, const float* w3,
+                    const float* b3, void* z1, void* z2, float* logits, int64_t B, int32_t D0, int32_t H1, int32_t H2,
+                    int32_t NC, float p_drop, uint64_t seed, uint32_t rs1, uint32_t rs2, int32_t dt, void* stream);
+int tg_head_mlp_bwd(const float* g, const void* h0, const void* z1, const void* z2, const void* w1, const void* w2,
+                    const float* w3, void* dh0, float* workspace, float* dw1, float* db1, float* dw2, float* db2, float* dw3,
+                    float* db3, int32_t accumulate, int64_t B, int32_t D0, int32_t H1, int32_t H2, int32_t NC, float p_drop,
+                    uint64_t seed, uint32_t rs1, uint32_t rs2, int32_t dt, void* stream);
 /* y1 = alpha*a + beta*b (a NULL: beta*b) and y2 = gamma*b in one pass over b: the backward of the residual mixes
  * (fused.py:254) when a's gradient goes to a shared gradient buffer. */
 int tg_axpby2(const void* a, const void* b, void* y1, void* y2, int64_t n, float alpha, float beta, float gamma, int32_t dt,

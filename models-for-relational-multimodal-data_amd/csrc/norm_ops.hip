@@ -643,14 +643,19 @@ __global__ void __launch_bounds__(256) k_col_sum_part(const T* __restrict__ x, l
 __global__ void __launch_bounds__(256) k_col_sum_reduce(const float* __restrict__ part, int nblk, int C,
                                                         float* __restrict__ out, int accumulate) {
   __shared__ float red[256];
-  const int cpb = 32, strips = 256 / cpb;                    // 32 columns per block, 8 strips of partials each
+  constexpr int cpb = 8, strips = 256 / cpb;                 // 8 columns per block, 32 strips of partials each
   const int c = blockIdx.x * cpb + threadIdx.x % cpb, strip = threadIdx.x / cpb;
-  float t = 0.f;
+  float t0 = 0.f, t1 = 0.f;
   if (c < C) {
     const int per = (nblk + strips - 1) / strips, b0 = strip * per, b1 = b0 + per < nblk ? b0 + per : nblk;
-    for (int b = b0; b < b1; ++b) t += part[(long long)b * C + c];
+    int b = b0;
+    for (; b + 1 < b1; b += 2) {
+      t0 += part[(long long)b * C + c];
+      t1 += part[(long long)(b + 1) * C + c];
+    }
+    if (b < b1) t0 += part[(long long)b * C + c];
   }
-  red[threadIdx.x] = t;
+  red[threadIdx.x] = t0 + t1;
   __syncthreads();
   if (strip == 0 && c < C) {
     float u = 0.f;
@@ -1119,7 +1124,7 @@ extern "C" int tg_axpby2(const void* a, const void* b, void* y1, void* y2, int64
 
 static int col_sum_blocks(int64_t R, int rows_per_pass) {
   const int64_t want = ceil_div(R, (int64_t)rows_per_pass * 8);      // >= 8 passes per block
-  return (int)(want < 1 ? 1 : want > 1024 ? 1024 : want);
+  return (int)(want < 1 ? 1 : want > 512 ? 512 : want);
 }
 extern "C" int64_t tg_col_sum_workspace_floats(int64_t R, int32_t C) { return (int64_t)1024 * C; }
 
@@ -1143,7 +1148,7 @@ extern "C" int tg_col_sum(const void* x, int64_t R, int32_t C, int64_t ld, float
       TG_LAUNCH_CHECK();
     })
   }
-  hipLaunchKernelGGL(k_col_sum_reduce, dim3(ceil_div(C, 32)), dim3(256), 0, st, workspace, nblk, C, out, accumulate);
+  hipLaunchKernelGGL(k_col_sum_reduce, dim3(ceil_div(C, 8)), dim3(256), 0, st, workspace, nblk, C, out, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }

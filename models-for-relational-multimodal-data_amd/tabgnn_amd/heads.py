@@ -13,6 +13,8 @@ def _mlp(n_in, n_classes, dropout):
 
 
 def _run_mlp(mlp, h, p):
+    if ops.head_mlp_ok(mlp, h):                        # one forward / one backward kernel (csrc/head.hip)
+        return ops.head_mlp(h, mlp, p)
     h = ops.act_dropout(ops.linear(h, mlp[0].weight, mlp[0].bias), "relu", p)
     h = ops.act_dropout(ops.linear(h, mlp[3].weight, mlp[3].bias), "relu", p)
     return ops.linear(h.float(), mlp[6].weight, mlp[6].bias)       # logits in fp32

@@ -474,6 +474,71 @@ def mlp_relu(x, lin0, lin2):
     return linear(act_dropout(linear(x, lin0.weight, lin0.bias), "relu", 0.0), lin2.weight, lin2.bias)
 
 
+FUSED_HEAD = os.environ.get("TABGNN_NO_FUSED_HEAD", "0") != "1"
+
+
+class _HeadMLP(torch.autograd.Function):
+    """The readout MLP of ``ClassifierHead`` / ``NodeClassificationHead`` (``src/nn/gnn/decoder.py:5-32``):
+    Linear(D0, 50) -> ReLU -> Dropout -> Linear(50, 25) -> ReLU -> Dropout -> Linear(25, n_classes) as one forward and one
+    backward kernel (``csrc/head.hip``); same arithmetic, masks and dropout-stream order as the op-by-op composition
+    ``linear / act_dropout / linear / act_dropout / linear(h.float())``.  Parameter gradients are added in place when
+    every parameter owns a gradient buffer (FlatParams views), returned otherwise."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2, w3, b3, lw1, lw2, p):
+        B, D0 = h.shape
+        H1, H2, NC = lw1.shape[0], lw2.shape[0], w3.shape[0]
+        z1 = torch.empty(B, H1, dtype=h.dtype, device=h.device)
+        z2 = torch.empty(B, H2, dtype=h.dtype, device=h.device)
+        logits = torch.empty(B, NC, dtype=torch.float32, device=h.device)
+        ctx.seed, ctx.rs = DropoutRNG.seed, (DropoutRNG.next_stream(), DropoutRNG.next_stream())
+        ctx.p = p
+        L.call("tg_head_mlp_fwd", L.ptr(h), L.ptr(lw1), L.ptr(b1), L.ptr(lw2), L.ptr(b2), L.ptr(w3), L.ptr(b3), L.ptr(z1),
+               L.ptr(z2), L.ptr(logits), B, D0, H1, H2, NC, p, ctx.seed, ctx.rs[0], ctx.rs[1], L.dt(h), L.stream())
+        ctx.save_for_backward(h, z1, z2, lw1, lw2, w3)
+        ctx.params = (w1, b1, w2, b2, w3, b3)
+        return logits
+
+    @staticmethod
+    def backward(ctx, g):
+        h, z1, z2, lw1, lw2, w3 = ctx.saved_tensors
+        B, D0 = h.shape
+        H1, H2, NC = lw1.shape[0], lw2.shape[0], w3.shape[0]
+        g = g.contiguous().float()
+        params = ctx.params
+        targets = [_grad_target(q) if isinstance(q, torch.nn.Parameter) else None for q in params]
+        inplace = all(t is not None and t.shape == q.shape for t, q in zip(targets, params))
+        outs = targets if inplace else [torch.empty(q.shape, dtype=torch.float32, device=h.device) for q in params]
+        dh = torch.empty_like(h)
+        ws = _workspace(L.load().tg_head_mlp_partial_floats(D0, H1, H2, NC), h.device)
+        L.call("tg_head_mlp_bwd", L.ptr(g), L.ptr(h), L.ptr(z1), L.ptr(z2), L.ptr(lw1), L.ptr(lw2), L.ptr(w3), L.ptr(dh),
+               L.ptr(ws), *[L.ptr(t) for t in outs], 1 if inplace else 0, B, D0, H1, H2, NC, ctx.p, ctx.seed, ctx.rs[0],
+               ctx.rs[1], L.dt(h), L.stream())
+        grads = [None] * 6 if inplace else outs
+        return (dh if ctx.needs_input_grad[0] else None, *grads, None, None, None)
+
+
+def head_mlp_ok(mlp, h):
+    """Does the fused readout kernel take this MLP (``nn.Sequential`` with Linear modules at 0, 3, 6) on this input?"""
+    if not (FUSED_HEAD and h.is_cuda and h.dim() == 2 and h.is_contiguous() and h.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    l0, l3, l6 = mlp[0], mlp[3], mlp[6]
+    if l0.bias is None or l3.bias is None or l6.bias is None or h.data_ptr() % 16:
+        return False
+    return bool(L.load().tg_head_mlp_supported(h.shape[1], l0.out_features, l3.out_features, l6.out_features))
+
+
+def head_mlp(h, mlp, p):
+    l0, l3, l6 = mlp[0], mlp[3], mlp[6]
+    lw1 = shadow(l0.weight, h.dtype)
+    lw2 = shadow(l3.weight, h.dtype)
+    lw1 = l0.weight.detach() if lw1 is None else lw1
+    lw2 = l3.weight.detach() if lw2 is None else lw2
+    if lw1.data_ptr() % 16 or not lw1.is_contiguous() or not lw2.is_contiguous():
+        lw1, lw2 = lw1.contiguous().clone(), lw2.contiguous()
+    return _HeadMLP.apply(h, l0.weight, l0.bias, l3.weight, l3.bias, l6.weight, l6.bias, lw1, lw2, float(p))
+
+
 class _MLPChain(torch.autograd.Function):
     """Linear -> act -> dropout -> ... -> Linear as ONE node on the MFMA GEMMs (the fuse MLP of the fused layer,
     fused.py:199-202: 3D -> 4*3D -> 4*3D -> 3D with LeakyReLU + Dropout; any chain whose widths are multiples of 128).
