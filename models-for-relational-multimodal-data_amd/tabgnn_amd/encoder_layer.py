@@ -28,6 +28,12 @@ _DW_FFN = os.environ.get("TABGNN_NO_DW_FFN") != "1"      # A/B: feed-forward wei
 _DX_FOLD = os.environ.get("TABGNN_NO_DX_FOLD") != "1"    # A/B: d_x += d_qkv W_in inside the attention-half backward kernel
 
 
+
+def wave_tiles(R, S):
+    """32-token wave tiles of a [R, S, C] launch of the fused kernels (a tile holds floor(32 / S) whole table rows)."""
+    per = max(32 // S, 1)
+    return (R + per - 1) // per
+
 STATS = {"fused_fwd": 0, "fused_bwd": 0, "fused_bwd_attn": 0}       # launches of the one-kernel layer (tests assert the path under test ran)
 
 
@@ -70,7 +76,7 @@ def fused_forward(x, nhead, p, tail, alpha, beta_c, wpack, prm, seed, rs, want_z
     rs_arr = (ctypes.c_uint32 * 4)(*rs)
     ops._launch("tg_encoder_fwd_bf16", L.ptr(x), L.ptr(out), L.ptr(z1), L.ptr(z2), L.ptr(wpack), L.ptr(prm), R, S, nhead,
                 int(tail), float(alpha), float(beta_c), 1e-5, float(p), int(seed), ctypes.addressof(rs_arr), L.stream(),
-                nbytes=2 * x.numel() * (2 + 2 * int(want_z)))
+                nbytes=2 * x.numel() * (2 + 2 * int(want_z)), units=wave_tiles(R, S))
     return out, z1, z2
 
 
@@ -347,7 +353,7 @@ def _fused_backward(ctx, g):
         dbp = torch.empty(nblk * 2 * 128, dtype=torch.float32, device=dev)
         ops._launch("tg_encoder_bwd_ffn_dw_bf16", L.ptr(g), L.ptr(z1), L.ptr(z2), L.ptr(d_x1), L.ptr(wpack_b), L.ptr(prm), R, S,
                     int(tail), float(beta_c), 1e-5, float(p), int(seed), ctypes.addressof(rs_arr), L.ptr(lnp), L.ptr(dwp),
-                    L.ptr(dbp), L.stream(), nbytes=2 * T * C * 4)
+                    L.ptr(dbp), L.stream(), nbytes=2 * T * C * 4, units=wave_tiles(R, S))
         STATS["fused_bwd"] += 1
         STATS["fused_bwd_dw"] = STATS.get("fused_bwd_dw", 0) + 1
         dg2, dbe2, dgt, dbt = _ln_reduce(lnp, nblk, (gg2, gb2, ggt if tail else None, gbt if tail else None))
@@ -388,7 +394,7 @@ def _fused_backward(ctx, g):
                 L.ptr(d_y), L.ptr(o), L.ptr(d_qkv), L.ptr(lw_in.contiguous()), L.ptr(wo_t), wo_t.stride(0),
                 win_t.data_ptr() if win_t is not None else None, win_t.stride(0) if win_t is not None else 0,
                 L.ptr(wpack_a), L.ptr(prm), R, S, H, float(alpha) if with_g else 0.0, 1e-5, float(p), int(seed),
-                ctypes.addressof(rs_arr), L.ptr(lnp1), L.stream(), nbytes=2 * T * C * (9 + int(with_g)))
+                ctypes.addressof(rs_arr), L.ptr(lnp1), L.stream(), nbytes=2 * T * C * (9 + int(with_g)), units=wave_tiles(R, S))
     STATS["fused_bwd_attn"] += 1
     dg1, dbe1 = _ln_reduce(lnp1, nblk, (ctx.ln_params[0][0], ctx.ln_params[0][1]))[:2]
     del d_x1

@@ -75,14 +75,16 @@ class KernelTimer:
         self.spans = {}
         self.nbytes = {}
         self.only = None if only is None else set(only)      # time just these entry points (None = every _launch)
+        self.units = {}                                      # work units of the timed launches (wave tiles of the encoder kernels)
 
-    def timed(self, name, fn, nbytes=0):
+    def timed(self, name, fn, nbytes=0, units=0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
         self.spans.setdefault(name, []).append((e0, e1))
         self.nbytes[name] = self.nbytes.get(name, 0) + int(nbytes)
+        self.units[name] = self.units.get(name, 0) + int(units)
 
     def total_ms(self, name):
         return sum(a.elapsed_time(b) for a, b in self.spans.get(name, []))
@@ -100,12 +102,12 @@ class KernelTimer:
         return len(self.spans.get(name, []))
 
 
-def _launch(name, *args, nbytes=0):
+def _launch(name, *args, nbytes=0, units=0):
     t = KernelTimer.active
     if t is None or (t.only is not None and name not in t.only):
         L.call(name, *args)
     else:
-        t.timed(name, lambda: L.call(name, *args), nbytes)
+        t.timed(name, lambda: L.call(name, *args), nbytes, units)
 
 
 def _workspace(n_floats, device):
