@@ -179,6 +179,11 @@ int tg_axpby2(const void* a, const void* b, void* y1, void* y2, int64_t n, float
 int64_t tg_col_sum_workspace_floats(int64_t R, int32_t C);
 int tg_col_sum(const void* x, int64_t R, int32_t C, int64_t ld, float* out, float* workspace, int32_t accumulate, int32_t dt,
                void* stream);
+/* dst[r, 0:W] = (c < C ? s_head : s_tail) * src[r, c] for c < w_src, zero beyond (src row pitch ld_src elements): the
+ * row-wise pieces of the backward of the CLS merge (fused.py:259-260) and of the seed gathers (fused.py:257,
+ * decoder.py:18-19) — one pass each instead of clone / slice-multiply / zeros / slice-copy. */
+int tg_row_head_scale(const void* src, int64_t ld_src, int32_t w_src, void* dst, int64_t B, int32_t W, int32_t C, float s_head,
+                      float s_tail, int32_t dt, void* stream);
 /* CLS merge of the fused layer, fused.py:259-260 */
 int tg_cls_merge_fwd(const void* xtab /*[B,S,C]*/, const void* xf /*[B,D]*/, void* out, int64_t B, int32_t S,
                      int32_t C, int32_t D, int32_t dt, void* stream);

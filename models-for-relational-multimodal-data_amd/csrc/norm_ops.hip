@@ -664,6 +664,32 @@ __global__ void __launch_bounds__(256) k_col_sum_reduce(const float* __restrict_
   }
 }
 
+// dst[r, 0:W] = scale(c) * src[r, c], scale = s_head for c < C else s_tail, columns at or past w_src read as zero
+// (src row pitch ld_src): the row-wise pieces of the CLS merge / seed gather backward — "token 0 of the row times 1/2",
+// "the CLS slice of a [B, D] gradient padded to a [B, S*C] row", "a column block made contiguous" — in one pass each
+template <typename T, int VEC>
+__global__ void k_row_head_scale(const T* __restrict__ src, long long ld_src, int w_src, T* __restrict__ dst, long long B,
+                                 int W, int C, float s_head, float s_tail) {
+  const int vpr = W / VEC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long total = B * vpr, stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const long long r = i / vpr;
+    const int c = (int)(i - r * vpr) * VEC;
+    float v[VEC];
+    if (c < w_src) {
+      loadv<T, VEC>(src + r * ld_src + c, v);
+      const float sc = c < C ? s_head : s_tail;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] *= sc;
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+    }
+    storev<T, VEC>(dst + r * (long long)W + c, v);
+  }
+}
+
 // CLS-token merge of the fused layer (fused.py:259-260): out = x_tab with token 0 <- (x_tab[:,0] + xf[:, :C]) / 2
 template <typename T, int VEC>
 __global__ void k_cls_merge_fwd(const T* __restrict__ xtab, const T* __restrict__ xf, T* __restrict__ out, long long B,
@@ -1149,6 +1175,23 @@ extern "C" int tg_col_sum(const void* x, int64_t R, int32_t C, int64_t ld, float
     })
   }
   hipLaunchKernelGGL(k_col_sum_reduce, dim3(ceil_div(C, 8)), dim3(256), 0, st, workspace, nblk, C, out, accumulate);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int tg_row_head_scale(const void* src, int64_t ld_src, int32_t w_src, void* dst, int64_t B, int32_t W, int32_t C,
+                                 float s_head, float s_tail, int32_t dt, void* stream) {
+  TG_CHECK(src && dst, "tg_row_head_scale: null operand");
+  TG_CHECK(W > 0 && W % 8 == 0 && C % 8 == 0 && w_src % 8 == 0 && ld_src % 8 == 0 && w_src >= 0 && w_src <= ld_src && C >= 0,
+           "tg_row_head_scale: widths must be multiples of 8 (W=%d C=%d w_src=%d ld=%lld)", W, C, w_src, (long long)ld_src);
+  TG_CHECK(((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+           "tg_row_head_scale: operands must be 16-byte aligned");
+  if (B == 0) return 0;
+  DISPATCH_T(dt, {
+    const long long total = (long long)B * (W / VEC);
+    hipLaunchKernelGGL((k_row_head_scale<T, VEC>), dim3(grid_cap(ceil_div(total, 256))), dim3(256), 0, (hipStream_t)stream,
+                       (const T*)src, (long long)ld_src, w_src, (T*)dst, (long long)B, W, C, s_head, s_tail);
+  })
   TG_LAUNCH_CHECK();
   return 0;
 }

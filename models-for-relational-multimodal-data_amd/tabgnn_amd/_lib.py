@@ -52,6 +52,7 @@ SIGNATURES = {
                         _i32, _vp],
     "tg_head_mlp_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32,
                         _i32, _f32, _u64, _u32, _u32, _i32, _vp],
+    "tg_row_head_scale": [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _f32, _f32, _i32, _vp],
     "tg_axpby2": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "tg_col_sum_workspace_floats": [_i64, _i32],
     "tg_col_sum": [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp],

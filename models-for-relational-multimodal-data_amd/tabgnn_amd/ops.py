@@ -1100,12 +1100,14 @@ class _SeedGather(torch.autograd.Function):
         L.call("tg_segment_sum2", L.ptr(g), g.shape[1], ctx.offs[0], L.ptr(seeds.rowptr), L.ptr(seeds.perm),
                ctx.offs[1], None, None, seeds.B, L.ptr(relu_src), L.ptr(dx), seeds.N, F, L.ptr(hub), acc_x, L.dt(g),
                L.stream())
-        if ctx.mode == "fuse":
+        if ctx.mode == "fuse":                                        # [g[:, :C] | 0] as the [B, S, C] gradient of x_tab
             C = ctx.oshape[-1]
-            dother = torch.zeros(ctx.oshape, dtype=g.dtype, device=g.device)
-            dother[:, 0, :] = g[:, :C]
-        else:
-            dother = g[:, 2 * F:].contiguous()
+            dother = torch.empty(ctx.oshape, dtype=g.dtype, device=g.device)
+            _row_head_scale(g, g.shape[1], C, dother, seeds.B, dother[0].numel(), C, 1.0, 0.0)
+        else:                                                         # the tail block made contiguous
+            Fe = g.shape[1] - 2 * F
+            dother = torch.empty(g.shape[0], Fe, dtype=g.dtype, device=g.device)
+            _row_head_scale(g, g.shape[1], Fe, dother, g.shape[0], Fe, Fe, 1.0, 1.0, offset=2 * F)
         return (dx if ret_x else None), dother, None, None, None
 
 
@@ -1467,6 +1469,12 @@ def gine_aggregate(x, le, graph, self_scale=1.0):
 # --------------------------------------------------------------------------- fused-layer tail: CLS merge + pooling
 
 
+def _row_head_scale(src, ld_src, w_src, dst, B, W, C, s_head, s_tail, offset=0):
+    """dst[r, :W] = (c < C ? s_head : s_tail) * src[r, offset + c] for c < w_src, zero beyond (tg_row_head_scale)."""
+    L.call("tg_row_head_scale", src.data_ptr() + offset * src.element_size(), ld_src, w_src, L.ptr(dst), B, W, C, s_head,
+           s_tail, L.dt(src), L.stream())
+
+
 class _ClsMerge(torch.autograd.Function):
     """x_tab with its CLS token replaced by (cls + xf[:, :C]) / 2  (fused.py:259-260)."""
 
@@ -1482,10 +1490,12 @@ class _ClsMerge(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         C, D = ctx.cfg
-        dxtab = g.clone()
-        dxtab[:, 0, :] *= 0.5
-        dxf = torch.zeros(g.shape[0], D, dtype=g.dtype, device=g.device)
-        dxf[:, :C] = g[:, 0, :] * 0.5
+        g = g.contiguous()
+        B, S, _ = g.shape
+        dxtab = torch.empty_like(g)                                       # g with token 0 halved
+        _row_head_scale(g, S * C, S * C, dxtab, B, S * C, C, 0.5, 1.0)
+        dxf = torch.empty(B, D, dtype=g.dtype, device=g.device)           # [g[:, 0] / 2 | 0]
+        _row_head_scale(g, S * C, C, dxf, B, D, C, 0.5, 0.0)
         return dxtab, dxf
 
 
