@@ -40,6 +40,7 @@ class _PrependCLS(torch.autograd.Function):
     def forward(ctx, cls, rows):
         R, ncols, C = rows.shape
         ctx.C = C
+        ctx.cls = cls if isinstance(cls, nn.Parameter) else None
         base = getattr(rows, "_cls_base", None)
         if (base is not None and base.shape == (R, ncols + 1, C) and base.is_contiguous() and base.dtype == rows.dtype
                 and rows.data_ptr() == base.data_ptr() + C * rows.element_size()):
@@ -60,9 +61,15 @@ class _PrependCLS(torch.autograd.Function):
         R, S, C = g.shape
         if g.is_cuda and g.stride(2) == 1 and g.stride(1) == C and C % 8 == 0 and g.dtype in (torch.bfloat16, torch.float32):
             from . import _lib as L
-            dcls = torch.empty(C, dtype=torch.float32, device=g.device)
+            tgt = ops._grad_target(ctx.cls)          # the parameter's own fp32 gradient buffer: added in place
+            if tgt is not None and tgt.shape != (C,):
+                tgt = None
+            dcls = tgt if tgt is not None else torch.empty(C, dtype=torch.float32, device=g.device)
             ws = ops._workspace(L.load().tg_col_sum_workspace_floats(R, C), g.device)
-            L.call("tg_col_sum", L.ptr(g), R, C, g.stride(0), L.ptr(dcls), L.ptr(ws), 0, L.dt(g), L.stream())
+            L.call("tg_col_sum", L.ptr(g), R, C, g.stride(0), L.ptr(dcls), L.ptr(ws), 1 if tgt is not None else 0, L.dt(g),
+                   L.stream())
+            if tgt is not None:
+                dcls = None
         else:
             dcls = g[:, 0, :].sum(0, dtype=torch.float32)
         return dcls, g[:, 1:, :]           # a view: the encoder's backward reads it in place (no copy of [R,ncols,C])

@@ -458,9 +458,15 @@ def test_col_sum_of_the_cls_column_matches_torch_and_repeats(T, dtype, R, S, C):
     assert torch.allclose(acc, 2 * outs[0], rtol=1e-6, atol=1e-6)
     if R:
         class Ctx:
-            pass
+            cls = None
         dcls, rest = _PrependCLS.backward(Ctx(), g)
         assert torch.equal(dcls, outs[0]) and rest.data_ptr() == g[:, 1:, :].data_ptr()
+        par = torch.nn.Parameter(torch.zeros(C, device="cuda"))          # a parameter that owns a gradient buffer: added in place
+        par.grad = torch.full((C,), 7.0, device="cuda")
+        ctx = Ctx()
+        ctx.cls = par
+        dcls2, _ = _PrependCLS.backward(ctx, g)
+        assert dcls2 is None and torch.allclose(par.grad, outs[0] + 7.0, rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
