@@ -1471,6 +1471,8 @@ def gine_aggregate(x, le, graph, self_scale=1.0):
 
 def _row_head_scale(src, ld_src, w_src, dst, B, W, C, s_head, s_tail, offset=0):
     """dst[r, :W] = (c < C ? s_head : s_tail) * src[r, offset + c] for c < w_src, zero beyond (tg_row_head_scale)."""
+    if B == 0:
+        return
     L.call("tg_row_head_scale", src.data_ptr() + offset * src.element_size(), ld_src, w_src, L.ptr(dst), B, W, C, s_head,
            s_tail, L.dt(src), L.stream())
 

@@ -488,3 +488,35 @@ def test_axpby2_is_the_two_axpby_passes_in_one(T, dtype):
     gb = torch.empty_like(b)
     L.call("tg_axpby2", L.ptr(buf), L.ptr(b), L.ptr(buf), L.ptr(gb), n, 1.0, 0.5, 0.5, L.dt(b), L.stream())
     assert torch.equal(buf, (a.float() + 0.5 * b.float()).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_head_scale_matches_the_torch_slicing_it_replaces(T, dtype):
+    """`tg_row_head_scale`: the row-wise pieces of the CLS-merge backward (fused.py:259-260) and of the seed gathers'
+    backward (fused.py:257, decoder.py:18-19) against the clone / slice-multiply / zeros / slice-copy they replace."""
+    from tabgnn_amd import ops
+    torch.manual_seed(0)
+    B, S, C, F = 37, 6, 128, 128
+    D = C + 2 * F
+    g = torch.randn(B, S, C, device="cuda").to(dtype)
+    # g with token 0 halved
+    want = g.clone(); want[:, 0, :] *= 0.5
+    got = torch.empty_like(g)
+    ops._row_head_scale(g, S * C, S * C, got, B, S * C, C, 0.5, 1.0)
+    assert torch.equal(got, want)
+    # [g[:, 0] / 2 | 0] as a [B, D] row
+    want = torch.zeros(B, D, dtype=dtype, device="cuda"); want[:, :C] = g[:, 0, :] * 0.5
+    got = torch.full((B, D), 7.0, dtype=dtype, device="cuda")
+    ops._row_head_scale(g, S * C, C, got, B, D, C, 0.5, 0.0)
+    assert torch.equal(got, want)
+    # the CLS slice of a [B, D] gradient padded to a [B, S, C] row; a tail block made contiguous
+    gd = torch.randn(B, D, device="cuda").to(dtype)
+    want = torch.zeros(B, S, C, dtype=dtype, device="cuda"); want[:, 0, :] = gd[:, :C]
+    got = torch.full((B, S, C), 7.0, dtype=dtype, device="cuda")
+    ops._row_head_scale(gd, D, C, got, B, S * C, C, 1.0, 0.0)
+    assert torch.equal(got, want)
+    got = torch.empty(B, C, dtype=dtype, device="cuda")
+    ops._row_head_scale(gd, D, C, got, B, C, C, 1.0, 1.0, offset=2 * F)
+    assert torch.equal(got, gd[:, 2 * F:].contiguous())
+    # B = 0 is a no-op
+    ops._row_head_scale(gd[:0], D, C, got[:0], 0, C, C, 1.0, 1.0)
