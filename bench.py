@@ -181,6 +181,28 @@ def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     T.ops.KernelTimer.active = None
+    # The same loop with the DEVICE sampler (csrc/sampler_gpu.hip): seeds -> k-hop draw + relabel on the GPU over the
+    # HBM-resident CSC -> train step with the batch's CSRs built on the device; no host thread, no upload.
+    from tabgnn_amd.device_sampler import DeviceNeighborSampler
+    dsmp = DeviceNeighborSampler(ei, N, (100, 100), dev)
+    d_edges, d_ev = 0, []
+    for i in range(total):
+        if i == warm:
+            torch.cuda.synchronize(); t1 = time.perf_counter(); d_edges = 0
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        d_eid, d_lei, d_nodes = dsmp.sample(torch.from_numpy(seeds[i]), i)
+        ev[1].record()
+        T.train_step(model, flat, opt, store.batch(d_eid, d_lei, d_nodes, batch_size), loss_w)
+        if i >= warm:
+            d_ev.append(ev)
+        d_edges += d_eid.numel()
+    torch.cuda.synchronize()
+    d_dt = time.perf_counter() - t1
+    device_sampler = dict(value=d_edges / d_dt, unit="edges/s", ms_per_step=1e3 * d_dt / steps, steps=steps,
+                          edges_per_step=d_edges / steps, sampler_ms_per_batch=sum(a.elapsed_time(b) for a, b in d_ev) / len(d_ev),
+                          what="DeviceNeighborSampler (k-hop draw + relabel on the GPU, one size read-back per batch) -> train "
+                               "step with the CSRs built on the device; no sampler threads")
     F, b_act = model.config["n_hidden"], 2
     agg_bytes = (edges / steps - batch_size) * (F * b_act + 4) + (n_nodes / steps) * 4 * F * b_act
     agg_ms = timer.mean_ms("tg_pna_aggregate_fwd")
@@ -192,6 +214,7 @@ def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
     return dict(value=edges / dt, unit="edges/s", ms_per_step=1e3 * dt / steps, steps=steps, roofline_sampled=sampled,
                 model_only_ms_per_step=sum(a.elapsed_time(b) for a, b in t_model) / len(t_model),
                 edges_per_step=edges / steps, nodes_per_step=n_nodes / steps, sampler_ms_per_batch=1e3 * float(np.mean(t_sample[warm:])),
+                device_sampler=device_sampler,
                 sampler=f"libtabgnn_sampler.so k-hop [100,100], {n_workers} host threads (one handle each), prefetch <= "
                         f"{2 * n_workers} batches; batch = ids + CSRs built in the sampler thread (tg_host_batch_index; no row gather, no "
                         f"device CSR build); sampler_ms_per_batch includes them",

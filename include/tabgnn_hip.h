@@ -43,6 +43,27 @@ int64_t tg_csr_workspace_ints(int64_t M, int32_t N);
 int tg_csr_build(const int32_t* key, int64_t M, int32_t N, int32_t* rowptr, int32_t* perm, int32_t* work,
                  void* stream);
 
+/* ---- k-hop neighbour sampler + relabel over the HBM-resident graph (the device form of
+ *      tg_sampler_draw / tg_sampler_emit of tabgnn_sampler.h, i.e. of sample_neighbors + get_graph_inputs,
+ *      src/datasets/ibm_transactions_for_aml.py:61-112,159-180).  The graph: esrc / edst int64 [E] = the rows of the
+ *      full edge_index; its CSC colptr int32 [N+1], in_src / in_eid int32 [E] (tg_csr_build of the destination column:
+ *      in-edges of v at colptr[v] .. colptr[v+1], ascending edge id).  seeds int64 [B] edge ids (device); fanout host
+ *      int32 [hops], < 0 = every in-edge, else <= 128.  cap = staging capacity in edges, an upper bound on seed + drawn
+ *      edges (min(tg_sampler_max_edges(B, fanout, hops), E + B), at most 8 Mi).  seedbit: tg_gsampler_seedbit_bytes(E)
+ *      bytes, zero before the first draw (emit clears what the draw set); workspace: tg_gsampler_workspace_bytes(N, cap).
+ *      draw: counts_out (device int64 [4]) = {output edges, output nodes, staged edges, error (0 = ok; 1/2 = seed id /
+ *      endpoint out of range, 3 = cap too small)} once the stream reaches the end.  emit (after the caller has read the
+ *      counts and allocated): out_eid int64 [n_edges] (seed edges first, in order), out_edge_index int64 [2, ld] LOCAL
+ *      ids, out_nodes int64 [n_nodes] sorted global ids.  A sample is a pure function of (graph, seeds, fanout, rng_seed). */
+int64_t tg_gsampler_seedbit_bytes(int64_t E);
+int64_t tg_gsampler_workspace_bytes(int32_t N, int64_t cap);
+int tg_gsampler_draw(const int64_t* seeds, int64_t B, const int64_t* esrc, const int64_t* edst, int64_t E,
+                     const int32_t* colptr, const int32_t* in_src, const int32_t* in_eid, int32_t N, const int32_t* fanout,
+                     int32_t hops, uint64_t rng_seed, int64_t cap, void* seedbit, void* workspace, int64_t* counts_out,
+                     void* stream);
+int tg_gsampler_emit(const int64_t* seeds, int64_t B, int32_t N, int64_t E, int64_t cap, int64_t ld, void* seedbit,
+                     void* workspace, int64_t* out_eid, int64_t* out_edge_index, int64_t* out_nodes, void* stream);
+
 /* ---- stype encoders (torch_frame fork EmbeddingEncoder/LinearEncoder/TimestampEncoder/ProjectionEncoder;
  *      src/datasets/ibm_transactions_for_aml.py:283-294,313-319; utils.py:357-359) -------------------- */
 typedef struct {

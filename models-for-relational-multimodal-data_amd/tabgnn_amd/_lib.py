@@ -53,6 +53,10 @@ SIGNATURES = {
     "tg_head_mlp_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32,
                         _i32, _f32, _u64, _u32, _u32, _i32, _vp],
     "tg_row_head_scale": [_vp, _i64, _i32, _vp, _i64, _i32, _i32, _f32, _f32, _i32, _vp],
+    "tg_gsampler_seedbit_bytes": [_i64],
+    "tg_gsampler_workspace_bytes": [_i32, _i64],
+    "tg_gsampler_draw": [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _i32, _u64, _i64, _vp, _vp, _vp, _vp],
+    "tg_gsampler_emit": [_vp, _i64, _i32, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     "tg_axpby2": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _i32, _vp],
     "tg_col_sum_workspace_floats": [_i64, _i32],
     "tg_col_sum": [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp],
@@ -116,7 +120,7 @@ SIGNATURES = {
     "tg_transpose_batched_bf16": [_vp, _vp, _vp, _i32, _vp],
 }
 _RESTYPES = {"tg_last_error": C.c_char_p, "tg_csr_workspace_ints": _i64, "tg_segment_hub_ints": _i64,
-             "tg_gemm_tn_workspace_floats": _i64, "tg_col_sum_workspace_floats": _i64, "tg_head_mlp_partial_floats": _i64, "tg_encoder_pack_bytes": _i64, "tg_encoder_stage_bytes": _i64, "tg_encoder_ln_partial_blocks": _i64, "tg_encoder_dw_blocks": _i64, "tg_encoder_prm_floats": _i64,
+             "tg_gemm_tn_workspace_floats": _i64, "tg_col_sum_workspace_floats": _i64, "tg_head_mlp_partial_floats": _i64, "tg_gsampler_seedbit_bytes": _i64, "tg_gsampler_workspace_bytes": _i64, "tg_encoder_pack_bytes": _i64, "tg_encoder_stage_bytes": _i64, "tg_encoder_ln_partial_blocks": _i64, "tg_encoder_dw_blocks": _i64, "tg_encoder_prm_floats": _i64,
              "tg_pna_fold_ws_floats": _i64,
              "tg_gemm_tn_gather3_workspace_floats": _i64}
 
