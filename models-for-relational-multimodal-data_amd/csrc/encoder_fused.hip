@@ -64,8 +64,12 @@ constexpr int EF_STAGE_BYTES = 4 * EF_PART_BYTES;     // 128 rows (34 KiB)
 #define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7"
 #elif EF_DMA_GAP == 3
 #define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-#else
+#elif EF_DMA_GAP == 4
 #define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+#elif EF_DMA_GAP == 8
+#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
+#elif EF_DMA_GAP == 16
+#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
 #endif
 #ifndef EF_WG_PER_CU
 #define EF_WG_PER_CU 2       // resident workgroups per CU the kernels are built for (waves per SIMD with EF_WAVES_N = 4)
@@ -195,7 +199,7 @@ __device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 
 #endif
 
 // LDS-DMA of BYTES (rounded up to 1 KiB pieces: the images are padded accordingly) by the workgroup: one 1 KiB piece per
-// wave-instruction; wave w takes the contiguous run of pieces [w P, (w + 1) P), P = ceil(pieces / waves).
+// wave-instruction; wave w takes pieces w, w + waves, w + 2 waves, ...
 // INLINE ASM on purpose: for the builtin (__builtin_amdgcn_global_load_lds) hipcc assumes that every later LDS access
 // may alias the DMA's destination and puts `s_waitcnt vmcnt(0)` in front of the next ds_read / ds_write — i.e. the wave
 // stalled for the full DMA latency right after issuing it, at every one of the 14 unit boundaries of a tile (the
@@ -207,12 +211,24 @@ __device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 
 // `s_nop 4` in front of the DMA: hipcc may reload a spilled address pair with v_readlane right in front of the statement,
 // and a VALU-written SGPR needs 5 wait states before a vector-memory instruction reads it — the hazard recogniser does
 // not look inside inline asm (round 4: the dropout forward with its 138 spilled SGPRs faulted without it).
-// EF_DMA_GAP: round 4 found the p = 0 kernels NOT run-to-run deterministic with two workgroups per CU — one wave tile of
-// a CU's second workgroup, first iteration, 4-13 % of the launches at R = 13000, |error| 0.01-0.2 (tools/enc_det_probe.py).
-// One workgroup per CU never showed it; `s_waitcnt vmcnt(0)` at the boundaries, sleeps, LDS padding, an M0 written once
-// per call with immediate piece offsets (which the hardware adds to BOTH addresses: tools/hwtests/lds_dma_offset.hip) did
-// not remove it; 32 wait states behind every DMA instruction did (0 of 9000 launches, + 0.1 ms per step).  The mechanism
-// is not pinned down — back-to-back LDS-DMA issue from co-resident workgroups is what the data points at.
+// EF_DMA_SERIAL / EF_STAGGER: round 4 found the kernels NOT run-to-run deterministic with two workgroups per CU — one
+// 32-token wave tile of the output off by 0.01-0.2, never with one workgroup per CU (tools/enc_det_probe4.py: the layer
+// forward + backward repeated thousands of times).  What the rates say (launches that differ / launches, R = rows):
+//   pieces back to back, no wait states                    R = 13 000: 4-13 %          (p = 0 kernels; p = 0.5: 0-3 %)
+//   32 wait states behind every piece (EF_DMA_GAP 4)        R = 13 000: 0.03-0.2 %;    R = 430 000: 0.1-0.3 %
+//   64 / 128 wait states                                   R = 13 000: 0 of 12 000;    R = 430 000: 0.08 % / 1.7 % (not monotonic)
+//   + second half of the grid started 15 us late            R = 13 000: 0 of 36 000;    R = 430 000: 0.1-0.3 % (start-up only)
+//   M0 written once per call + immediate offsets, per-lane 64-bit addresses (no scalar operand changes)    1.6-100 %
+//   s_waitcnt vmcnt(2) behind every piece                  6 %
+//   s_waitcnt vmcnt(0) between a wave's pieces (this)      0 of 22 500 at both sizes; + 0.28 ms per step
+// So it is neither a late read of M0 / the scalar base nor the number of pieces in flight per CU: what removes it is that
+// a wave never has two LDS-DMA instructions in flight at once.  The mechanism is not pinned down.
+#ifndef EF_DMA_SERIAL
+#define EF_DMA_SERIAL 1      // 1: a wave's pieces never overlap (vmcnt(0) between them); 0: back to back with EF_DMA_GAP wait states
+#endif
+#ifndef EF_STAGGER
+#define EF_STAGGER 4         // start delay of the second half of the grid, in units of s_sleep 127 (8 128 cycles); 0 = off
+#endif
 template <int BYTES>
 __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_dst, int wave, int lane16) {
   constexpr int NP = (BYTES + 1023) / 1024;
@@ -224,6 +240,16 @@ __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_d
     const int q = p * EF_WAVES + wave;                         // wave-uniform piece
     if ((p + 1) * EF_WAVES <= NP || q < NP) {
       unsigned keep;
+#if EF_DMA_SERIAL
+      // pieces of one wave never overlap: the previous one has landed before the next is issued (the last one is awaited
+      // by the unit boundary as before)
+      if (p > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_nop 7\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
+                   : "memory");
+      continue;
+#endif
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" EF_DMA_GAP_ASM "\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
@@ -417,6 +443,9 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
 
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
+#if EF_STAGGER
+  if (blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
+#endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
   __syncthreads();
@@ -1037,6 +1066,9 @@ __global__ void __launch_bounds__(EF_THREADS, DW ? 1 : EF_WG_PER_CU) k_encoder_b
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
+#if EF_STAGGER
+  if (blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
+#endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
   __syncthreads();
@@ -1337,6 +1369,9 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
+#if EF_STAGGER
+  if (blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
+#endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
   __syncthreads();

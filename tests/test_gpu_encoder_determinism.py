@@ -1,11 +1,11 @@
 """Run-to-run determinism of the column-transformer kernels at a size that fills every CU with two workgroups.
 
-Round 4 found two defects that only showed as run-to-run differences (DESIGN.md §4d): type-punned LDS accesses of the row
+Round 4 found two defects that only showed as run-to-run differences (DESIGN.md 4d): type-punned LDS accesses of the row
 restage reordered under strict aliasing (z1 / z2 rows with dwords of later temporaries), and one wave tile of the output
-wrong at 4-13 % of the p = 0 launches when LDS-DMA instructions of co-resident workgroups were issued back to back.  Both
-needed >= 2 workgroups per CU and >= 512 workgroups, which no parity test reaches (the oracle sizes are far smaller), so
-the guard is this repeat test: with the round-3 build 40 launches fail with probability > 0.8 per mode.
-"""
+wrong at up to 13 % of the launches whenever a wave had two LDS-DMA instructions in flight beside a co-resident
+workgroup.  Both needed >= 2 workgroups per CU and >= 512 workgroups, which no parity test reaches (the oracle sizes are
+far smaller), so the guard is this repeat test; tools/enc_det_probe4.py measures the RATE over thousands of launches
+(0 of 22 500 with the shipped DMA helper)."""
 import os
 import sys
 
