@@ -444,7 +444,8 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
 
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
 #if EF_STAGGER
-  if (blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
+  // (only grids that put two workgroups on a CU: 256 CUs on this part; a B = 200 launch has a few workgroups and would just wait)
+  if (gridDim.x > 256 && blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
 #endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
@@ -1067,7 +1068,8 @@ __global__ void __launch_bounds__(EF_THREADS, DW ? 1 : EF_WG_PER_CU) k_encoder_b
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
 #if EF_STAGGER
-  if (blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
+  // (only grids that put two workgroups on a CU: 256 CUs on this part; a B = 200 launch has a few workgroups and would just wait)
+  if (gridDim.x > 256 && blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
 #endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
@@ -1370,7 +1372,8 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
 #if EF_STAGGER
-  if (blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
+  // (only grids that put two workgroups on a CU: 256 CUs on this part; a B = 200 launch has a few workgroups and would just wait)
+  if (gridDim.x > 256 && blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
 #endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
