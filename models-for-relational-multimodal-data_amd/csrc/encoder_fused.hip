@@ -226,10 +226,13 @@ __device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 
 #ifndef EF_DMA_SERIAL
 #define EF_DMA_SERIAL 1      // 1: a wave's pieces never overlap (vmcnt(0) between them); 0: back to back with EF_DMA_GAP wait states
 #endif
+#ifndef EF_DW_UNSERIAL
+#define EF_DW_UNSERIAL 0     // 1: the one-workgroup-per-CU feed-forward backward (DW) issues its pieces back to back
+#endif
 #ifndef EF_STAGGER
 #define EF_STAGGER 4         // start delay of the second half of the grid, in units of s_sleep 127 (8 128 cycles); 0 = off
 #endif
-template <int BYTES>
+template <int BYTES, bool SERIAL = true>
 __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_dst, int wave, int lane16) {
   constexpr int NP = (BYTES + 1023) / 1024;
   unsigned l16 = (unsigned)lane16;
@@ -242,8 +245,8 @@ __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_d
       unsigned keep;
 #if EF_DMA_SERIAL
       // pieces of one wave never overlap: the previous one has landed before the next is issued (the last one is awaited
-      // by the unit boundary as before)
-      if (p > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // by the unit boundary as before).  SERIAL = false: kernels that run ONE workgroup per CU, where the hazard never showed.
+      if (SERIAL && p > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_nop 7\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
@@ -419,12 +422,13 @@ struct EfArgs {
     EF_STAMP(EF_SEC)                                                                                  \
     if (!(EF_ABL & 128)) { WAIT; EF_STAMP(12) __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }       \
     EF_STAMP(13)                                                                                      \
-    if (!(EF_ABL & 32) && (VALID)) ef_dma<BYTES>(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, EF_UBUF(U), wave, lane16); \
+    if (!(EF_ABL & 32) && (VALID)) ef_dma<BYTES, EF_SERIAL_HERE>(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, EF_UBUF(U), wave, lane16); \
     EF_STAMP(14)                                                                                      \
   }
 #define EF_UNIT_NEXT(U, VALID, U2, BYTES) EF_UNIT_NEXT_K(U, VALID, U2, BYTES, EF_WAIT_VM(0))
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const EfArgs a_) {
+  constexpr bool EF_SERIAL_HERE = true;
   EfArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1042,6 +1046,7 @@ __device__ __forceinline__ void ef_db_write(const float (&bsum)[2], float* dst /
 
 template <int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */, bool DW /* weight gradients inside */>
 __global__ void __launch_bounds__(EF_THREADS, DW ? 1 : EF_WG_PER_CU) k_encoder_bwd_ffn(const EbArgs a_) {
+  constexpr bool EF_SERIAL_HERE = !(DW && EF_DW_UNSERIAL);          // the DW variant runs one workgroup per CU
   EbArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1355,6 +1360,7 @@ __device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* b
 
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(const EaArgs a_) {
+  constexpr bool EF_SERIAL_HERE = true;
   EaArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
