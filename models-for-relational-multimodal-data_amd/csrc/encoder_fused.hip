@@ -221,13 +221,14 @@ __device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 
 //   M0 written once per call + immediate offsets, per-lane 64-bit addresses (no scalar operand changes)    1.6-100 %
 //   s_waitcnt vmcnt(2) behind every piece                  6 %
 //   s_waitcnt vmcnt(0) between a wave's pieces (this)      0 of 22 500 at both sizes; + 0.28 ms per step
+//   ... except in the one-workgroup-per-CU feed-forward backward (DW)   0 of 22 500; + 0.03 ms per step
 // So it is neither a late read of M0 / the scalar base nor the number of pieces in flight per CU: what removes it is that
 // a wave never has two LDS-DMA instructions in flight at once.  The mechanism is not pinned down.
 #ifndef EF_DMA_SERIAL
 #define EF_DMA_SERIAL 1      // 1: a wave's pieces never overlap (vmcnt(0) between them); 0: back to back with EF_DMA_GAP wait states
 #endif
 #ifndef EF_DW_UNSERIAL
-#define EF_DW_UNSERIAL 0     // 1: the one-workgroup-per-CU feed-forward backward (DW) issues its pieces back to back
+#define EF_DW_UNSERIAL 1     // 1: the one-workgroup-per-CU feed-forward backward (DW) issues its pieces back to back
 #endif
 #ifndef EF_STAGGER
 #define EF_STAGGER 4         // start delay of the second half of the grid, in units of s_sleep 127 (8 128 cycles); 0 = off
