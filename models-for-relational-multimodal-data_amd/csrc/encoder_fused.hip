@@ -247,7 +247,8 @@ __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_d
 #if EF_DMA_SERIAL
       // pieces of one wave never overlap: the previous one has landed before the next is issued (the last one is awaited
       // by the unit boundary as before).  SERIAL = false: kernels that run ONE workgroup per CU, where the hazard never showed.
-      if (SERIAL && p > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (and only in grids that can put two workgroups on a CU: more than the part's 256 CUs — a B = 200 launch has ~10)
+      if (SERIAL && p > 0 && gridDim.x > 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_nop 7\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
