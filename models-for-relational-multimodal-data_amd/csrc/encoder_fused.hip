@@ -52,25 +52,6 @@ constexpr int EF_STAGE_BYTES = 4 * EF_PART_BYTES;     // 128 rows (34 KiB)
 #ifndef EF_WAVES_N
 #define EF_WAVES_N 4
 #endif
-// Wait states behind every LDS-DMA instruction (see ef_dma), in units of `s_nop 7` (8 cycles).
-#ifndef EF_DMA_GAP
-#define EF_DMA_GAP 4
-#endif
-#if EF_DMA_GAP == 0
-#define EF_DMA_GAP_ASM
-#elif EF_DMA_GAP == 1
-#define EF_DMA_GAP_ASM "\n\ts_nop 7"
-#elif EF_DMA_GAP == 2
-#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7"
-#elif EF_DMA_GAP == 3
-#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-#elif EF_DMA_GAP == 4
-#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-#elif EF_DMA_GAP == 8
-#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-#elif EF_DMA_GAP == 16
-#define EF_DMA_GAP_ASM "\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"
-#endif
 #ifndef EF_WG_PER_CU
 #define EF_WG_PER_CU 2       // resident workgroups per CU the kernels are built for (waves per SIMD with EF_WAVES_N = 4)
 #endif
@@ -199,68 +180,65 @@ __device__ __forceinline__ ef_f32x16 ef_no_mfma(ef_v8bf a, ef_v8bf b, ef_f32x16 
 #endif
 
 // LDS-DMA of BYTES (rounded up to 1 KiB pieces: the images are padded accordingly) by the workgroup: one 1 KiB piece per
-// wave-instruction; wave w takes pieces w, w + waves, w + 2 waves, ...
+// wave-instruction; a wave takes a CONTIGUOUS run of pieces (17 pieces over 4 waves: 5 | 4 | 4 | 4).
 // INLINE ASM on purpose: for the builtin (__builtin_amdgcn_global_load_lds) hipcc assumes that every later LDS access
 // may alias the DMA's destination and puts `s_waitcnt vmcnt(0)` in front of the next ds_read / ds_write — i.e. the wave
 // stalled for the full DMA latency right after issuing it, at every one of the 14 unit boundaries of a tile (the
 // "prefetch" never ran ahead).  Through asm the compiler sees no LDS write; the landing is awaited by the counted
 // `s_waitcnt vmcnt(K)` + barrier of the unit boundary (EF_UNIT_NEXT_K), and the "memory" clobber keeps the compiler from
 // moving or merging LDS reads across the statement.
-// M0 (the LDS base of a DMA) is saved, set per piece and restored inside the asm statement (the compiler does not honour
-// an M0 clobber; tests/test_cabi_and_host.py checks that these moves are the only M0 references in the compiled file).
-// `s_nop 4` in front of the DMA: hipcc may reload a spilled address pair with v_readlane right in front of the statement,
-// and a VALU-written SGPR needs 5 wait states before a vector-memory instruction reads it — the hazard recogniser does
-// not look inside inline asm (round 4: the dropout forward with its 138 spilled SGPRs faulted without it).
-// EF_DMA_SERIAL / EF_STAGGER: round 4 found the kernels NOT run-to-run deterministic with two workgroups per CU — one
-// 32-token wave tile of the output off by 0.01-0.2, never with one workgroup per CU (tools/enc_det_probe4.py: the layer
-// forward + backward repeated thousands of times).  What the rates say (launches that differ / launches, R = rows):
-//   pieces back to back, no wait states                    R = 13 000: 4-13 %          (p = 0 kernels; p = 0.5: 0-3 %)
-//   32 wait states behind every piece (EF_DMA_GAP 4)        R = 13 000: 0.03-0.2 %;    R = 430 000: 0.1-0.3 %
-//   64 / 128 wait states                                   R = 13 000: 0 of 12 000;    R = 430 000: 0.08 % / 1.7 % (not monotonic)
-//   + second half of the grid started 15 us late            R = 13 000: 0 of 36 000;    R = 430 000: 0.1-0.3 % (start-up only)
-//   M0 written once per call + immediate offsets, per-lane 64-bit addresses (no scalar operand changes)    1.6-100 %
-//   s_waitcnt vmcnt(2) behind every piece                  6 %
-//   s_waitcnt vmcnt(0) between a wave's pieces (this)      0 of 22 500 at both sizes; + 0.28 ms per step
-//   ... except in the one-workgroup-per-CU feed-forward backward (DW)   0 of 22 500; + 0.03 ms per step
-// So it is neither a late read of M0 / the scalar base nor the number of pieces in flight per CU: what removes it is that
-// a wave never has two LDS-DMA instructions in flight at once.  The mechanism is not pinned down.
-#ifndef EF_DMA_SERIAL
-#define EF_DMA_SERIAL 1      // 1: a wave's pieces never overlap (vmcnt(0) between them); 0: back to back with EF_DMA_GAP wait states
+// M0 (the LDS base of a DMA) is written ONCE per call, to the middle of the wave's run; the pieces are addressed by the
+// instruction's immediate offset (-2048 .. +2048), which the hardware adds to the LDS address AND to the global address
+// (tools/hwtests/lds_dma_offset.hip) — so the scalar base points at the same middle.  M0 is read when the instruction
+// issues: tools/hwtests/lds_dma_race.hip part B rewrites M0 0 / 8 / 32 wait states behind a DMA under full load, 5.2e8
+// pieces, none lands at the new value — no wait states are needed behind a DMA, and nothing has to be restored (hipcc
+// does not use M0 in this file: tests/test_cabi_and_host.py checks the compiled assembly).
+// `s_nop 4` in front of the first DMA: hipcc may reload a spilled address pair with v_readlane right in front of the
+// statement, and a VALU-written SGPR needs 5 wait states before a vector-memory instruction reads it — the hazard
+// recogniser does not look inside inline asm (round 4: the dropout forward with its spilled SGPRs faulted without it).
+// Round 4 shipped this helper with `s_waitcnt vmcnt(0)` between a wave's pieces and a late start of half the grid
+// against "one wave tile wrong at percent rates"; the cause was not the DMA at all but LDS reads in flight across the
+// unit barrier (EF_WAIT_VM below) — with that closed the pieces issue back to back again, in every grid.
+#ifndef EF_DMA_FORM
+#define EF_DMA_FORM 1        // 0: the round-3/4 form (M0 per piece, pieces strided over the waves) for the A/B probe only
 #endif
-#ifndef EF_DW_UNSERIAL
-#define EF_DW_UNSERIAL 1     // 1: the one-workgroup-per-CU feed-forward backward (DW) issues its pieces back to back
-#endif
-#ifndef EF_STAGGER
-#define EF_STAGGER 4         // start delay of the second half of the grid, in units of s_sleep 127 (8 128 cycles); 0 = off
-#endif
-template <int BYTES, bool SERIAL = true>
+#define EF_GLDS(OFF) "global_load_lds_dwordx4 %0, %1 offset:" #OFF "\n\t"
+template <int BYTES>
 __device__ __forceinline__ void ef_dma(const char* __restrict__ src, char* lds_dst, int wave, int lane16) {
   constexpr int NP = (BYTES + 1023) / 1024;
   unsigned l16 = (unsigned)lane16;
   asm volatile("" : "+v"(l16));      // opaque: not hoisted out of the persistent loop as 64-bit address pairs
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst;
+#if EF_DMA_FORM == 1
+  constexpr int BASE = NP / EF_WAVES, REM = NP % EF_WAVES;     // waves below REM issue BASE + 1 pieces
+  static_assert(BASE == 1 || BASE == 2 || BASE == 4, "piece runs of 1, 2 or 4 (+1)");
+  const int first = wave * BASE + (wave < REM ? wave : REM);   // wave-uniform
+  const char* g = src + first * 1024 + 2048;
+  const unsigned m0v = lds0 + (unsigned)(first * 1024 + 2048);
+  if constexpr (BASE == 4)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\t" EF_GLDS(-2048) EF_GLDS(-1024) EF_GLDS(0) EF_GLDS(1024) :: "v"(l16), "s"(g), "s"(m0v) : "memory");
+  else if constexpr (BASE == 2)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\t" EF_GLDS(-2048) EF_GLDS(-1024) :: "v"(l16), "s"(g), "s"(m0v) : "memory");
+  else
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\t" EF_GLDS(-2048) :: "v"(l16), "s"(g), "s"(m0v) : "memory");
+  if (REM != 0 && wave < REM) {      // (M0 written again: this is a statement of its own)
+    if constexpr (BASE == 4) asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\t" EF_GLDS(2048) :: "v"(l16), "s"(g), "s"(m0v) : "memory");
+    else if constexpr (BASE == 2) asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\t" EF_GLDS(0) :: "v"(l16), "s"(g), "s"(m0v) : "memory");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\t" EF_GLDS(-1024) :: "v"(l16), "s"(g), "s"(m0v) : "memory");
+  }
+#else
 #pragma unroll
   for (int p = 0; p < (NP + EF_WAVES - 1) / EF_WAVES; ++p) {
     const int q = p * EF_WAVES + wave;                         // wave-uniform piece
     if ((p + 1) * EF_WAVES <= NP || q < NP) {
       unsigned keep;
-#if EF_DMA_SERIAL
-      // pieces of one wave never overlap: the previous one has landed before the next is issued (the last one is awaited
-      // by the unit boundary as before).  SERIAL = false: kernels that run ONE workgroup per CU, where the hazard never showed.
-      // (and only in grids that can put two workgroups on a CU: more than the part's 256 CUs — a B = 200 launch has ~10)
-      if (SERIAL && p > 0 && gridDim.x > 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_nop 7\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep)
-                   : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
-                   : "memory");
-      continue;
-#endif
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2" EF_DMA_GAP_ASM "\n\ts_mov_b32 m0, %0"
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
                    : "v"(l16), "s"(src + q * 1024), "s"(lds0 + (unsigned)(q * 1024))
                    : "memory");
     }
   }
+#endif
 }
 // (the DMA is inline asm: the compiler does not wait for it at a __syncthreads(), EF_DMA_LANDED() does)
 #define EF_DMA_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -418,19 +396,31 @@ struct EfArgs {
 // the DMA is done while the stores stay in flight.  (__syncthreads() would wait vmcnt(0): every output store of the tile
 // then stalled the next barrier — stripping the stores saved 0.26 ms of a 1.34 ms launch.)  K must never exceed the real
 // count: each call site states what was issued.
+// ... and lgkmcnt(0): the wave's own LDS reads of the buffer that the barrier hands over to the next DMA must have
+// RETURNED, not just been issued.  hipcc sinks the MFMAs of a unit's last k-steps below the boundary (an asm statement
+// orders memory operations, not register-only instructions), so their `ds_read_b128` were still in the LDS queue when
+// the wave crossed the raw s_barrier, and the DMA of unit U+2 — issued by ANY wave right behind the barrier — could land
+// in U's buffer before those reads executed (round 4's "one wave tile wrong at percent rates with two workgroups per
+// CU": DESIGN.md, LDS-DMA hazard; tools/hwtests/lds_dma_race.hip part C reproduces it without the arithmetic).
+#ifndef EF_LGKM_FENCE
+#define EF_LGKM_FENCE 1      // 0: the round-3/4 boundary (for the A/B of tools/enc_det_probe4.py only)
+#endif
+#if EF_LGKM_FENCE
+#define EF_WAIT_VM(K) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(K) : "memory")
+#else
 #define EF_WAIT_VM(K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory")
+#endif
 #define EF_UNIT_NEXT_K(U, VALID, U2, BYTES, WAIT)                                                     \
   {                                                                                                   \
     EF_STAMP(EF_SEC)                                                                                  \
     if (!(EF_ABL & 128)) { WAIT; EF_STAMP(12) __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }       \
     EF_STAMP(13)                                                                                      \
-    if (!(EF_ABL & 32) && (VALID)) ef_dma<BYTES, EF_SERIAL_HERE>(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, EF_UBUF(U), wave, lane16); \
+    if (!(EF_ABL & 32) && (VALID)) ef_dma<BYTES>(a.wpack + (size_t)(U2) * EF_UNIT_BYTES, EF_UBUF(U), wave, lane16); \
     EF_STAMP(14)                                                                                      \
   }
 #define EF_UNIT_NEXT(U, VALID, U2, BYTES) EF_UNIT_NEXT_K(U, VALID, U2, BYTES, EF_WAIT_VM(0))
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const EfArgs a_) {
-  constexpr bool EF_SERIAL_HERE = true;
   EfArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -449,10 +439,6 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
 
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
-#if EF_STAGGER
-  // (only grids that put two workgroups on a CU: 256 CUs on this part; a B = 200 launch has a few workgroups and would just wait)
-  if (gridDim.x > 256 && blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
-#endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
   __syncthreads();
@@ -1048,7 +1034,6 @@ __device__ __forceinline__ void ef_db_write(const float (&bsum)[2], float* dst /
 
 template <int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */, bool DW /* weight gradients inside */>
 __global__ void __launch_bounds__(EF_THREADS, DW ? 1 : EF_WG_PER_CU) k_encoder_bwd_ffn(const EbArgs a_) {
-  constexpr bool EF_SERIAL_HERE = !(DW && EF_DW_UNSERIAL);          // the DW variant runs one workgroup per CU
   EbArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1074,10 +1059,6 @@ __global__ void __launch_bounds__(EF_THREADS, DW ? 1 : EF_WG_PER_CU) k_encoder_b
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
-#if EF_STAGGER
-  // (only grids that put two workgroups on a CU: 256 CUs on this part; a B = 200 launch has a few workgroups and would just wait)
-  if (gridDim.x > 256 && blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
-#endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
   __syncthreads();
@@ -1362,7 +1343,6 @@ __device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* b
 
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
 __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(const EaArgs a_) {
-  constexpr bool EF_SERIAL_HERE = true;
   EaArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1379,10 +1359,6 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_bwd_attn(c
   const long long n_wt = (a.R + RW - 1) / RW;
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
-#if EF_STAGGER
-  // (only grids that put two workgroups on a CU: 256 CUs on this part; a B = 200 launch has a few workgroups and would just wait)
-  if (gridDim.x > 256 && blockIdx.x >= gridDim.x / 2) { _Pragma("unroll") for (int sl = 0; sl < EF_STAGGER; ++sl) __builtin_amdgcn_s_sleep(127); }
-#endif
   if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
   EF_DMA_LANDED();
   __syncthreads();

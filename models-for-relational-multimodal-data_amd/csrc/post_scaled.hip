@@ -63,12 +63,14 @@ struct PsArgs {
 
 // LDS-DMA pieces of a stage.  M0 (the LDS base) is written once per GROUP of pieces whose LDS destinations are 1 KiB
 // apart; piece i of a group goes to M0 + 1024 (i - MID) through the instruction's immediate offset, which the hardware
-// adds to the global address too — the piece's scalar base is moved back by the same amount.  A `global_load_lds` may read
-// M0 some cycles after it has been issued (encoder_fused.hip:ef_dma, round 4: rounds 2-3 wrote and restored M0 around
-// every piece and now and then a piece landed at the wrong LDS address), so PS_M0_SETTLE() stands between the last DMA of
-// one group and the M0 write of the next.  hipcc does not use M0 in this file (checked by tests/test_cabi_and_host.py).
+// adds to the global address too — the piece's scalar base is moved back by the same amount.  M0 is read when a
+// `global_load_lds` ISSUES (tools/hwtests/lds_dma_race.hip part B: M0 rewritten 0 wait states behind a DMA under full
+// load, 5.2e8 pieces, none lands at the new value), so the next group's M0 write needs no distance from the previous
+// group's last DMA.  (Rounds 2-4 suspected a late M0 read behind the column-transformer kernels' wrong tiles and kept 32
+// wait states here; that defect was LDS reads in flight across a raw s_barrier — encoder_fused.hip:EF_WAIT_VM —, which
+// this kernel's stage boundary excludes the same way: PS_STAGE_BODY waits lgkmcnt(0) in front of its barrier.)
+// hipcc does not use M0 in this file (checked by tests/test_cabi_and_host.py).
 #define PS_M0_SET(ADDR) asm volatile("s_mov_b32 m0, %0\n\ts_nop 4" ::"s"(ADDR) : "memory")
-#define PS_M0_SETTLE() asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory")
 template <int OFF>
 __device__ __forceinline__ void ps_dma(unsigned voff, const char* sbase) {
   // (s_nop 4: a v_readlane reload of the address pair right in front needs 5 wait states before a VMEM read; see ef_dma)
@@ -128,7 +130,6 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
     PS_X_PIECE(0) PS_X_PIECE(1) PS_X_PIECE(2) PS_X_PIECE(3)
 #undef PS_X_PIECE
     const unsigned ldw = tail ? 2u * PS_F : 6u * (unsigned)a.K;
-    PS_M0_SETTLE();
     PS_M0_SET(sb + (unsigned)PS_XB + 1024u * (unsigned)(6 * wave + 3));
 #define PS_W_PIECE(Q)                                                                                 \
     {                                                  /* W: 3 sets x 16 instructions, wave w takes i = 6w .. 6w+5 */ \
@@ -155,7 +156,9 @@ __global__ void __launch_bounds__(PS_THREADS, 1) k_pna_post_fwd(const PsArgs a) 
   // buffer), issue the next stage into that buffer, then the MFMAs.  NSET = 3 on the agg stages, 1 on the x Wx^T stages.
 #define PS_STAGE_BODY(NSET)                                                                           \
   {                                                                                                   \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+    /* this wave's pieces of the stage have landed (vmcnt) AND its fragment reads of the other buffer have returned   \
+       (lgkmcnt): the barrier hands that buffer to the DMA issued right behind it */                                    \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                       \
     if (!(PS_ABL & 4)) __builtin_amdgcn_s_barrier();                                                  \
     asm volatile("" ::: "memory");                                                                    \
     if (!(PS_ABL & 2) && tt + 1 < TT) issue(tt + 1);                                                  \

@@ -172,7 +172,12 @@ def prepare_sample(eid, edge_index, nodes, y, n_seed, key=None):
     its slot): no intermediate tensors, no torch dispatch — on a loaded host a ``torch.cat`` of 30 k ids cost milliseconds
     (round 3: 5.7-8 ms per batch and thread, more than the 3 ms GPU step; now the index pass itself, < 1.5 ms).  Pure host
     work that releases the GIL in its heavy part: run it in the sampler thread."""
-    as_np = lambda t, dt: np.ascontiguousarray(t.numpy() if isinstance(t, torch.Tensor) else np.asarray(t), dtype=dt)
+    def as_np(t, dt):
+        if isinstance(t, torch.Tensor):
+            if t.is_cuda:        # (a device-resident sample: tabgnn_amd.device_sampler.prepare_sample_device builds the arena on the GPU)
+                raise ValueError("prepare_sample takes host tensors; use prepare_sample_device for a DeviceNeighborSampler batch")
+            t = t.detach().numpy()
+        return np.ascontiguousarray(np.asarray(t), dtype=dt)
     eid, nodes, y = as_np(eid, np.int64).reshape(-1), as_np(nodes, np.int64).reshape(-1), as_np(y, np.int64).reshape(-1)
     ei_in = as_np(edge_index, np.int64)
     E, N = int(eid.shape[0]), int(nodes.shape[0])

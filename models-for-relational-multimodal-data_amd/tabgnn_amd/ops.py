@@ -527,6 +527,11 @@ def head_mlp_ok(mlp, h):
     l0, l3, l6 = mlp[0], mlp[3], mlp[6]
     if l0.bias is None or l3.bias is None or l6.bias is None or h.data_ptr() % 16:
         return False
+    # the kernels read W3 and the three biases as fp32 and W1 / W2 as fp32 masters (their shadows carry h's type): a head
+    # cast with .half() / .to(bfloat16), or one holding non-contiguous views, takes the op-by-op path instead
+    for t in (l0.weight, l3.weight, l6.weight, l0.bias, l3.bias, l6.bias):
+        if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+            return False
     return bool(L.load().tg_head_mlp_supported(h.shape[1], l0.out_features, l3.out_features, l6.out_features))
 
 

@@ -163,7 +163,7 @@ def test_gemm_nt_ln_equals_gemm_then_layernorm(R, K, p):
     assert (dp1 - dp2).abs().max().item() < 0.02 * max(1.0, dp2.abs().max().item())
 
 
-@pytest.mark.parametrize("N,E", [(1000, 3000), (4099, 20000), (128, 50)])
+@pytest.mark.parametrize("N,E", [(1000, 3000), (4099, 20000), (128, 50), (515080, 438354)])      # (last: the bench graph)
 def test_pna_post_projection_with_scalers_inside_the_gemms(N, E):
     """tg_gemm_nt_scaled_bf16 / tg_gemm_tn_scaled_bf16 (+ tg_pna_degree_scalers) against the unfused composition
     G = agg w_st^T, out = x w_x^T + b + G0 + amp*G1 + att*G2 in fp32: output and every gradient.  Isolated nodes (amp = 0),
