@@ -319,7 +319,12 @@ __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], const EfLa
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (!(EF_ABL & 2))
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, rv[p]), dst, la.go + (unsigned)(2048 * p), 128 * half, 0);   // (row in voffset: range-checked)
+        // soffset stays the IMMEDIATE 0 (the half-row offset rides in the instruction's offset field; the range check adds
+        // it to voffset, and row * 256 + 128 + 16 c + 16 <= (row + 1) * 256 keeps the verdict per row): with a REGISTER
+        // soffset hipcc does not pad the store-data hazard of a 128-bit store, and the VALU instruction behind the last
+        // store of the second half overwrote its third data register before the store had read it (z2 rows 25 / 27 / 29
+        // of a tile, channels 100-125; tools/hwtests/store_data_hazard.hip, tools/store_hazard_audit.py)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, rv[p]), dst, la.go + (unsigned)(2048 * p + 128 * half), 0, 0);
     }
   }
 }
@@ -1337,7 +1342,7 @@ __device__ __forceinline__ void ef_store_block32(ef_v8bf f0, ef_v8bf f1, char* b
 #pragma unroll
   for (int p = 0; p < 2; ++p) {      // br = tile + 80 * (lane >> 2) + 16 * (lane & 3): rows (lane >> 2) + 16 p
     const uint4 v = *reinterpret_cast<const uint4*>(br + 16 * p * EF_T_ROWB);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, v), rs, go + (unsigned)(16 * p * ld2), col2, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, v), rs, go + (unsigned)(16 * p * ld2 + col2), 0, 0);   // (immediate soffset: see ef_store_rows)
   }
 }
 

@@ -184,3 +184,20 @@ def test_every_barrier_of_the_lds_dma_kernels_waits_for_the_waves_own_lds_operat
                     bad.append((body[0], body[max(i - 4, 0):i + 1]))
         assert nker >= 2 and nbar >= 8 * nker // 2, (name, nker, nbar)
         assert not bad, (name, len(bad), bad[:3])
+
+
+def test_no_wide_buffer_store_with_a_register_soffset():
+    """Round 5 (store-data hazard): hipcc pads "128-bit store -> write of its data registers" only for stores
+    without a register soffset; with one, the VALU instruction behind `buffer_store_dwordx4 v[44:47], ..., s94 offen`
+    replaced the store's third dword on loaded CUs (the wrong z1 / z2 rows of rounds 3-4).  The translation units that
+    call the raw buffer-store builtin must not produce such a store at all."""
+    import re
+    csrc = os.path.join(ROOT, "models-for-relational-multimodal-data_amd", "csrc")
+    users = [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip") and "raw_buffer_store_b" in open(os.path.join(csrc, f)).read()]
+    assert "encoder_fused.hip" in users
+    for name in users:
+        code = [ln for ln in _gfx950_assembly(name) if ln and not ln.startswith(";")]
+        wide = [ln for ln in code if re.match(r"buffer_store_dwordx[34] ", ln)]
+        assert len(wide) >= 8, (name, len(wide))
+        reg = [ln for ln in wide if re.match(r"buffer_store_dwordx[34] v\[\d+:\d+\], \w+, s\[\d+:\d+\], (s\d+|vcc_lo|vcc_hi|m0|ttmp\d+)\b", ln)]
+        assert not reg, (name, len(reg), reg[:3])
