@@ -313,9 +313,9 @@ __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], const EfLa
       *reinterpret_cast<uint2*>(la.sw + 32 * ff) = make_uint2(v.x, v.y);
       *reinterpret_cast<uint2*>(la.sw + 32 * ff + 16) = make_uint2(v.z, v.w);
     }
-    uint4 rv[4];
+    ef_u4 rv[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) rv[p] = *reinterpret_cast<const uint4*>(la.sr + 8 * p * EF_STG_ROWB);
+    for (int p = 0; p < 4; ++p) rv[p] = __builtin_bit_cast(ef_u4, *reinterpret_cast<const uint4*>(la.sr + 8 * p * EF_STG_ROWB));
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       if (!(EF_ABL & 2))
@@ -324,8 +324,10 @@ __device__ __forceinline__ void ef_store_rows(const ef_v8bf (&zp)[8], const EfLa
         // soffset hipcc does not pad the store-data hazard of a 128-bit store, and the VALU instruction behind the last
         // store of the second half overwrote its third data register before the store had read it (z2 rows 25 / 27 / 29
         // of a tile, channels 100-125; tools/hwtests/store_data_hazard.hip, tools/store_hazard_audit.py)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ef_u4, rv[p]), dst, la.go + (unsigned)(2048 * p + 128 * half), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(rv[p], dst, la.go + (unsigned)(2048 * p + 128 * half), 0, 0);
     }
+    // (belt: four more wait states before anything may redefine the stored registers — the statement "writes" them)
+    asm volatile("s_nop 3" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]));
   }
 }
 

@@ -14,7 +14,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // VAR 0: register soffset, overwrite directly behind the store      VAR 4 / 1: s_nop 0 / s_nop 1 in between
 // VAR 2: soffset = 0 (immediate), overwrite directly behind          VAR 3: s_nop 1 in between
-template <int VAR>
+template <int VAR, int NF>
 __global__ void __launch_bounds__(256, 2) k_haz(unsigned* __restrict__ out, int n_it, unsigned bytes_per_block) {
   const unsigned tid = threadIdx.x;
   __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)blockIdx.x * (bytes_per_block / 4), 0, (int)bytes_per_block, 0x00020000);
@@ -34,6 +34,11 @@ __global__ void __launch_bounds__(256, 2) k_haz(unsigned* __restrict__ out, int 
                    "v_mov_b32 v22, 0\n\tv_mov_b32 v23, 0"                                              \
                    :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(w), "v"(voff), "v"(voffi), "s"(rs), "s"(soff), "v"(vfill)   \
                    : "memory", "v20", "v21", "v22", "v23")
+    // NF more filler stores in front (the product's row store is the eighth wide store of its wave in a row)
+    for (int f = 0; f < NF; ++f) {
+      if constexpr (VAR == 2 || VAR == 3) asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen offset:1024" :: "v"(w), "v"(vfill), "s"(rs) : "memory");
+      else asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:1024" :: "v"(w), "v"(vfill), "s"(rs), "s"(soff) : "memory");
+    }
     if constexpr (VAR == 0) HAZ("%8", "%5", "");
     else if constexpr (VAR == 4) HAZ("%8", "%5", "s_nop 0\n\t");
     else if constexpr (VAR == 1) HAZ("%8", "%5", "s_nop 1\n\t");
@@ -43,14 +48,14 @@ __global__ void __launch_bounds__(256, 2) k_haz(unsigned* __restrict__ out, int 
   }
 }
 
-template <int VAR>
+template <int VAR, int NF = 0>
 static void run(unsigned* out, std::vector<unsigned>& h, int grid, int launches, const char* what) {
   const unsigned bpb = 4 * 16384u + 16384u;     // four 16 KiB windows of checked rows (+128 B), filler windows behind
   size_t words = (size_t)grid * bpb / 4;
   unsigned long long bad = 0, seen = 0, badreg[4] = {0, 0, 0, 0}, badlane[64] = {0};
   for (int l = 0; l < launches; ++l) {
     CK(hipMemsetAsync(out, 0, words * 4));
-    hipLaunchKernelGGL((k_haz<VAR>), dim3(grid), dim3(256), 0, 0, out, 64, bpb);
+    hipLaunchKernelGGL((k_haz<VAR, NF>), dim3(grid), dim3(256), 0, 0, out, 64, bpb);
     CK(hipMemcpy(h.data(), out, words * 4, hipMemcpyDeviceToHost));
     for (int b = 0; b < grid; ++b)
       for (int w = 0; w < 4; ++w)
@@ -82,5 +87,11 @@ int main(int argc, char** argv) {
   run<1>(out, h, grid, launches, "register soffset, s_nop 1 in between");
   run<2>(out, h, grid, launches, "immediate soffset, data overwritten directly behind");
   run<3>(out, h, grid, launches, "immediate soffset, s_nop 1 in between");
+  run<0, 4>(out, h, grid, launches, "register soffset, directly behind, 7 stores in front");
+  run<4, 4>(out, h, grid, launches, "register soffset, s_nop 0, 7 stores in front");
+  run<1, 4>(out, h, grid, launches, "register soffset, s_nop 1, 7 stores in front");
+  run<3, 4>(out, h, grid, launches, "immediate soffset, s_nop 1, 7 stores in front");
+  run<0, 12>(out, h, grid, launches, "register soffset, directly behind, 15 stores in front");
+  run<3, 12>(out, h, grid, launches, "immediate soffset, s_nop 1, 15 stores in front");
   return 0;
 }
