@@ -758,6 +758,10 @@ def main():
     flat = T.FlatParams(model, shadow_dtype=cdt)
     opt = T.FusedAdam(flat, lr=cfg["lr"])
     ddp = T.DataParallel(model, flat) if use_dist else None
+    if ddp is not None and os.environ.get("TABGNN_NO_ALLREDUCE_OVERLAP") != "1":
+        # bucket-ready exchange: the head's and the later layers' gradient ranges go out from autograd pre-hooks while the
+        # earlier layers' backward still runs (train.DataParallel.enable_overlap); layer 0 + encoders after the backward
+        ddp.enable_overlap(list(model.model.backbone) + [model.decoder])
     loss_w = torch.tensor(cfg["loss_weights"], device=dev)
 
     batches = [S.make_batch(args.batch_size, seed=42 + rank * 1000 + i, device=dev)
@@ -769,11 +773,15 @@ def main():
     E_mean = sum(b[1].shape[1] for b in batches) / len(batches)
     N_mean = sum(b[0].num_rows for b in batches) / len(batches)
 
+    loss_log = [] if os.environ.get("TABGNN_BENCH_LOSSES") == "1" else None      # (tests: the loss trajectory, read AFTER the timed region)
+
     def run(n, first):
         edges = 0
         for i in range(n):
             b = batches[(first + i) % len(batches)]
-            T.train_step(model, flat, opt, b, loss_w, ddp)
+            loss, _ = T.train_step(model, flat, opt, b, loss_w, ddp)
+            if loss_log is not None:
+                loss_log.append(loss)
             edges += b[1].shape[1]
         return edges
 
@@ -839,10 +847,15 @@ def main():
                      "launches_timed": timer.count("tg_pna_aggregate_fwd"),
                      "bwd_avg_launch_ms": timer.mean_ms("tg_pna_aggregate_bwd")},
     }
+    if loss_log is not None:
+        out["losses"] = [float(v) for v in loss_log]
     if use_dist:
         out["collective"] = {"backend": backend, "world": world, "all_reduce_calls": ddp.calls,
                              "bytes_per_step": ddp.bytes / max(1, args.steps + args.warmup), "bucket_MiB": 32,
-                             "what": "flat fp32 gradient buffer, bucketed async all_reduce(SUM), 1/world folded into Adam"}
+                             "overlapped": bool(getattr(ddp, "overlapped_bytes", 0)),
+                             "overlapped_bytes_per_step": getattr(ddp, "overlapped_bytes", 0) / max(1, args.steps + args.warmup),
+                             "what": "flat fp32 gradient buffer, bucketed async all_reduce(SUM), 1/world folded into Adam; "
+                                     "later stages' ranges issued from autograd pre-hooks during the backward"}
     extras = not args.no_extras and world == 1
     if extras:
         out["roofline"].update(measured_copy_GBs=copy_rate_gbs(dev), measured_stream_GBs=stream_rate_gbs(dev))

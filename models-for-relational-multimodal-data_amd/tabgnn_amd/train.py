@@ -153,17 +153,101 @@ class DataParallel:
                 if isinstance(m, BatchNorm):
                     m.sync_group = dist.group.WORLD
 
+    # ---- bucket-ready exchange ("overlapped with backward")
+    def enable_overlap(self, stages):
+        """``stages``: modules in FORWARD order (e.g. the backbone layers, then the head).  The gradient ranges of stage
+        i+1 .. are exchanged as soon as the backward reaches the output of stage i, while the earlier stages' backward
+        kernels still run; everything else (stage 0, parameters outside the stages) goes after the backward as before.
+
+        Why "the backward reached stage i's output" means "the later stages' gradients are final": the autograd engine
+        pops the ready node with the HIGHEST sequence number, and a node is only ready once every node that consumes
+        its outputs has run — so when a node created in stage i is popped, every live node created after it (all of
+        stages i+1 .., the head, the loss) has already run, including the ones that only write parameter gradients
+        (weight folds, the in-place weight-gradient GEMMs of the composite nodes).  The all-reduce is issued from the
+        node's pre-hook on the stream the node runs on, so the collective stream waits for exactly the kernels queued
+        so far.  ``tests/test_ddp_gloo.py`` holds the result against the post-backward exchange bit for bit."""
+        stages = list(stages)
+        index = {id(p): i for i, p in enumerate(self.flat.params)}
+        self._stage_ranges = []
+        for m in stages:
+            ids = sorted({index[id(p)] for p in m.parameters() if id(p) in index})
+            ranges = []
+            for i in ids:                               # contiguous runs of the flat buffer
+                lo, hi = self.flat.offsets[i], self.flat.offsets[i + 1]
+                if ranges and ranges[-1][1] == lo:
+                    ranges[-1][1] = hi
+                else:
+                    ranges.append([lo, hi])
+            self._stage_ranges.append([tuple(r) for r in ranges])
+        seen = set()
+        for rs in self._stage_ranges:                   # a parameter shared by two stages is final with the EARLIER one only
+            for r in rs:
+                if r in seen:
+                    raise ValueError("stages share parameters: exchange them after the backward instead")
+                seen.add(r)
+        self._hooks = [m.register_forward_hook(self._make_forward_hook(i)) for i, m in enumerate(stages[:-1])]
+        self._works, self._done_from = [], len(stages)
+        self.overlapped_bytes = 0
+
+    def disable_overlap(self):
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks, self._stage_ranges = [], None
+
+    def _make_forward_hook(self, i):
+        def hook(module, inputs, output):
+            if not (self.active and torch.is_grad_enabled()):
+                return
+            outs = output if isinstance(output, (tuple, list)) else (output,)
+            fired = []
+
+            def ready(_grads):
+                if not fired:                            # once per forward, whichever output's node is reached first
+                    fired.append(True)
+                    self._exchange_stages_from(i + 1)
+            for t in outs:
+                if isinstance(t, torch.Tensor) and t.grad_fn is not None:
+                    t.grad_fn.register_prehook(ready)
+        return hook
+
+    def _issue(self, lo, hi):
+        g = self.flat.grad
+        for a in range(lo, hi, self.bucket):
+            b = min(a + self.bucket, hi)
+            self._works.append(dist.all_reduce(g[a:b], op=dist.ReduceOp.SUM, async_op=True))
+            self.bytes += 4 * (b - a)
+
+    def _exchange_stages_from(self, first):
+        """Stages ``first`` .. (not yet exchanged in this step) are final: start their all-reduces."""
+        before = self.bytes
+        for s in range(first, self._done_from):
+            for lo, hi in self._stage_ranges[s]:
+                self._issue(lo, hi)
+        self._done_from = min(self._done_from, first)
+        self.overlapped_bytes += self.bytes - before
+
     def all_reduce_grads(self):
-        """Sum over ranks, bucketed (async, in flight together); the 1/world factor is folded into the optimiser."""
+        """Sum over ranks, bucketed (async, in flight together); the 1/world factor is folded into the optimiser.  With
+        ``enable_overlap`` the ranges already in flight are only waited for; the rest is exchanged here."""
         if not self.active:
             return 1.0
         g = self.flat.grad
-        works = [dist.all_reduce(g[i:i + self.bucket], op=dist.ReduceOp.SUM, async_op=True)
-                 for i in range(0, g.numel(), self.bucket)]
-        for w in works:
+        stage_ranges = getattr(self, "_stage_ranges", None)
+        if stage_ranges is None:
+            self._works = []
+            self._issue(0, g.numel())
+        else:
+            done = sorted(r for s in range(self._done_from, len(stage_ranges)) for r in stage_ranges[s])
+            pos = 0
+            for lo, hi in done + [(g.numel(), g.numel())]:      # the complement of what is in flight
+                if lo > pos:
+                    self._issue(pos, lo)
+                pos = max(pos, hi)
+            self._done_from = len(stage_ranges)                 # (armed for the next step)
+        for w in self._works:
             w.wait()
-        self.calls += len(works)
-        self.bytes += 4 * g.numel()
+        self.calls += len(self._works)
+        self._works = []
         return 1.0 / self.world
 
     def sync_buffers(self):

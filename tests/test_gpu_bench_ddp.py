@@ -30,6 +30,8 @@ def test_bench_two_ranks_one_json_line():
     # whole-job aggregate: both ranks' edges over the max-over-ranks time
     assert abs(d["value"] - 2 * d["config"]["edges_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
     assert "cpu_baseline" not in d and "end_to_end" not in d            # rank 0 at N = 1 only
+    # bucket-ready exchange: the head's and layer 1's gradient ranges left from autograd pre-hooks during the backward
+    assert d["collective"]["overlapped"] and 0 < d["collective"]["overlapped_bytes_per_step"] < d["collective"]["bytes_per_step"]
 
 
 def test_bench_world1_rccl_allreduce_runs_on_hardware():
@@ -50,3 +52,23 @@ def test_bench_world1_rccl_allreduce_runs_on_hardware():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert d["collective"]["backend"] == "nccl" and d["collective"]["all_reduce_calls"] >= 3       # one per step
     assert d["collective"]["bytes_per_step"] > 30e6                                               # 8.2 M fp32 parameters
+    assert d["collective"]["overlapped"]                                                          # (RCCL calls issued inside the backward)
+
+
+def test_overlapped_exchange_trains_like_the_post_backward_exchange():
+    """Two ranks (gloo, one card), three steps of bench.py's model at B = 256 with TABGNN_NO_ALLREDUCE_OVERLAP=1 and
+    without: the loss trajectories agree bit for bit (same sums in the same order; only WHEN a range is exchanged moves)."""
+    res = []
+    for off in ("1", "0"):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        env = dict(os.environ, TABGNN_DIST_BACKEND="gloo", TABGNN_ONE_DEVICE="1", TABGNN_NO_ALLREDUCE_OVERLAP=off,
+                   TABGNN_BENCH_LOSSES="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+               "--warmup", "1", "--batch-size", "256"]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        res.append(d)
+    assert not res[0]["collective"]["overlapped"] and res[1]["collective"]["overlapped"]
+    assert res[0]["losses"] == res[1]["losses"] and len(res[0]["losses"]) == 4, (res[0]["losses"], res[1]["losses"])
