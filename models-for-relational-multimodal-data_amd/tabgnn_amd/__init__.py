@@ -19,3 +19,5 @@ from .models import (CPNA, PNAS, TABGNN, GINe, FTTransformerLayer, FTTransformer
 from .train import DataParallel, FlatParams, FusedAdam, IndexGuard, train_step  # noqa: E402
 from .graph_step import GraphedTrainStep, StepState, bucket_size, prepare as prepare_batch  # noqa: E402
 from .wrappers import GNN, TABGNNFusedS, TABGNNS, degree_histogram  # noqa: E402
+from .device_sampler import (DeviceBatchLoader, DeviceNeighborSampler, device_batch_index,  # noqa: E402
+                             prepare_sample_device)
