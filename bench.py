@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed oracle steps per thread count (median reported)")
     ap.add_argument("--no-extras", action="store_true", help="skip every extra object (reference_batch, eval, "
                     "other_workloads, roofline_gemm, cpu_baseline, end_to_end): the bare contract line, for profiling")
-    ap.add_argument("--workload", default="aml-fused", choices=["aml-fused", "tabgnn-arxiv", "wide64-c256", "reference-batch-graph"],
+    ap.add_argument("--workload", default="aml-fused", choices=["aml-fused", "tabgnn-arxiv", "wide64-c256", "wide64-graph", "reference-batch-graph"],
                     help="aml-fused = the headline (BASELINE configs[1]); the other two run ONE extra leg alone "
                          "(configs[3] / configs[4] shapes) and print its object — for profiling, never the headline")
     ap.add_argument("--reverse-mp", action="store_true", help="PNAConvHetero (forward + reverse message passing); "
@@ -183,26 +183,33 @@ def end_to_end(model, flat, opt, loss_w, batch_size, steps, dev):
     T.ops.KernelTimer.active = None
     # The same loop with the DEVICE sampler (csrc/sampler_gpu.hip): seeds -> k-hop draw + relabel on the GPU over the
     # HBM-resident CSC -> train step with the batch's CSRs built on the device; no host thread, no upload.
-    from tabgnn_amd.device_sampler import DeviceNeighborSampler
+    from tabgnn_amd import DeviceBatchLoader, DeviceNeighborSampler
     dsmp = DeviceNeighborSampler(ei, N, (100, 100), dev)
+    loader = DeviceBatchLoader(dsmp, store, [seeds[i] for i in range(total)], mode="index", rng_seed=0)
     d_edges, d_ev = 0, []
-    for i in range(total):
+    for i, batch in enumerate(loader):
         if i == warm:
             torch.cuda.synchronize(); t1 = time.perf_counter(); d_edges = 0
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-        d_eid, d_lei, d_nodes = dsmp.sample(torch.from_numpy(seeds[i]), i)
+        T.train_step(model, flat, opt, batch, loss_w)
         ev[1].record()
-        T.train_step(model, flat, opt, store.batch(d_eid, d_lei, d_nodes, batch_size), loss_w)
         if i >= warm:
             d_ev.append(ev)
-        d_edges += d_eid.numel()
+        d_edges += batch[1].edge_index.shape[1]
     torch.cuda.synchronize()
     d_dt = time.perf_counter() - t1
+    # the sampler alone, synchronously (what the side stream hides): draw + emit of one batch
+    torch.cuda.synchronize(); ts0 = time.perf_counter()
+    for i in range(5):
+        dsmp.sample(seeds[i], 1000 + i)
+    torch.cuda.synchronize()
     device_sampler = dict(value=d_edges / d_dt, unit="edges/s", ms_per_step=1e3 * d_dt / steps, steps=steps,
-                          edges_per_step=d_edges / steps, sampler_ms_per_batch=sum(a.elapsed_time(b) for a, b in d_ev) / len(d_ev),
-                          what="DeviceNeighborSampler (k-hop draw + relabel on the GPU, one size read-back per batch) -> train "
-                               "step with the CSRs built on the device; no sampler threads")
+                          edges_per_step=d_edges / steps,
+                          model_only_ms_per_step=sum(a.elapsed_time(b) for a, b in d_ev) / len(d_ev),
+                          sampler_ms_per_batch=1e3 * (time.perf_counter() - ts0) / 5, sampler_threads=0,
+                          what="DeviceBatchLoader: k-hop draw + relabel + the batch's CSRs on the GPU, one batch ahead on a side "
+                               "stream (no size wait, no CSR kernel on the training stream) -> train step; no sampler threads")
     F, b_act = model.config["n_hidden"], 2
     agg_bytes = (edges / steps - batch_size) * (F * b_act + 4) + (n_nodes / steps) * 4 * F * b_act
     agg_ms = timer.mean_ms("tg_pna_aggregate_fwd")
@@ -355,6 +362,19 @@ def reference_batch(args, cdt, dev):
     return out
 
 
+def _child_leg(extra_args, timeout=420):
+    """One leg in a child process -> its JSON object (or {"error": ...})."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(extra_args)
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=_child_env())
+        if r.returncode != 0:
+            return {"error": (r.stderr or "child failed")[-300:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001 - reported, never fatal for the bench line
+        return {"error": repr(e)[:200]}
+
+
 def reference_batch_sampled_loop(cfg, cdt, dev, B, steps=120, warm=60):
     """The reference's loop at its default batch END TO END as graph replays: native sampler threads ->
     ``graph_step.prepare_sample`` (pad to the bucket, all index parts, one pinned arena of ids) -> one upload -> replay;
@@ -438,7 +458,29 @@ def reference_batch_sampled_loop(cfg, cdt, dev, B, steps=120, warm=60):
             loss, _ = step(prep, frames)
     torch.cuda.synchronize()
     replay_only = 1e3 * (time.perf_counter() - t1) / (5 * len(kept))
+    # The same loop on the DEVICE sampler: seeds -> k-hop draw + relabel + padding + index parts on the GPU, one batch
+    # ahead on a side stream (tabgnn_amd.DeviceBatchLoader, mode "bucket") -> device-to-device copy -> replay.  No sampler
+    # thread, no upload, no size wait; the buckets captured above are reused (same model, same GraphedTrainStep).
+    from tabgnn_amd import DeviceBatchLoader, DeviceNeighborSampler
+    dsmp = DeviceNeighborSampler(ei, N, (100, 100), dev)
+    d_total = steps + 20
+    loader = DeviceBatchLoader(dsmp, store, [rs.choice(E, B, replace=False) for _ in range(d_total)], mode="bucket", rng_seed=7)
+    d_edges = d_new = 0
+    for i, prep in enumerate(loader):
+        if i == 20:
+            torch.cuda.synchronize(); t2 = time.perf_counter(); d_edges = 0
+        nb = len(step.buckets)
+        step(prep, frames)
+        d_new += int(i >= 20 and len(step.buckets) > nb)
+        d_edges += prep.e_real
+    torch.cuda.synchronize()
+    d_dt = time.perf_counter() - t2
+    device_loop = dict(ms_per_step=1e3 * d_dt / steps, value=d_edges / d_dt, unit="edges/s", steps=steps,
+                       edges_per_step=d_edges / steps, sampler_threads=0, buckets_captured_inside_the_timed_steps=d_new,
+                       what="DeviceBatchLoader(mode=bucket): draw + relabel + pad + index parts on the GPU one batch ahead on a "
+                            "side stream -> device-to-device copy -> graph replay; no sampler threads, no upload")
     return dict(ms_per_step=1e3 * dt / steps, value=edges / dt, unit="edges/s", steps=steps, edges_per_step=edges / steps,
+                device_sampler=device_loop,
                 buckets=len(step.buckets), buckets_captured_inside_the_timed_steps=new_after_warm,
                 host_ms_per_batch=1e3 * float(np.mean(t_host[warm:])), sampler_threads=n_workers, final_loss=float(loss),
                 upload_and_replay_only_ms_per_step=replay_only,
@@ -631,6 +673,48 @@ def leg_wide64(cdt, dev, steps=5, warmup=2, B=512):
                 attention_tokens_per_step=65 * (edges // steps), dtype="bf16" if cdt == torch.bfloat16 else "fp32")
 
 
+def leg_wide64_graph(cdt, dev, steps=6, warmup=3, B=512, N=10_000_000, E=100_000_000, fanout=(10, 5)):
+    """BASELINE configs[4] ON ITS GRAPH: the synthetic 10 M-node / 100 M-edge graph and its 64-column raw
+    table (80 GB) generated and kept in ONE GPU's HBM (``ColumnStore``), the device sampler drawing B seed edges' 2-hop
+    neighbourhoods from the CSC (0.8 GB) one batch ahead on a side stream (``DeviceBatchLoader``), the fused model at
+    d = 256 training on those batches — ids only, the stype encoders read the raw rows from the resident table."""
+    import tabgnn_amd as T
+    from tabgnn_amd import synthetic as S
+    from tabgnn_amd import DeviceBatchLoader, DeviceNeighborSampler
+    t0 = time.perf_counter()
+    ei = S.powerlaw_graph_on_device(N, E, dev)
+    store = S.wide64_store_on_device(N, E, dev)
+    deg = torch.bincount(ei[1], minlength=N).cpu()
+    smp = DeviceNeighborSampler(ei, N, fanout, dev)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t0
+    resident_gb = torch.cuda.memory_allocated(dev) / 1e9
+    torch.manual_seed(9)
+    model = T.TABGNNFusedS(S.wide64_config(B, deg, cdt)).to(dev).train()
+    flat = T.FlatParams(model, shadow_dtype=cdt)
+    opt = T.FusedAdam(flat, lr=6e-4)
+    lw = torch.tensor([1.0, 9.23], device=dev)
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    total = steps + warmup
+    seeds = [torch.randint(0, E, (B,), generator=g) for _ in range(total)]
+    loader = DeviceBatchLoader(smp, store, seeds, mode="index", rng_seed=1)
+    edges = nodes = 0
+    for i, batch in enumerate(loader):
+        if i == warmup:
+            torch.cuda.synchronize(); t1 = time.perf_counter(); edges = nodes = 0
+        loss, _ = T.train_step(model, flat, opt, batch, lw)
+        edges += batch[1].edge_index.shape[1]
+        nodes += batch[0].num_rows
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t1
+    return dict(graph="10M/100M", nodes=N, edges=E, fanout=list(fanout), B=B, value=edges / dt, unit="edges/s",
+                ms_per_step=1e3 * dt / steps, steps=steps, edges_per_step=edges // steps, nodes_per_step=nodes // steps,
+                resident_table_and_graph_GB=resident_gb, peak_hbm_GB=torch.cuda.max_memory_allocated(dev) / 1e9,
+                build_s=t_build, final_loss=float(loss), sampler_threads=0,
+                what="configs[4] on its graph: 10 M nodes / 100 M edges, 64-column raw table (800 B/row) resident in one "
+                     "GPU's HBM, DeviceBatchLoader -> fused d=256 train step")
+
+
 # ----------------------------------------------------------------------------------------------- step roofline (8d)
 
 MFMA_PEAK_TFLOPS = 2500.0      # bf16 dense (MI355X_MICROARCH.md)
@@ -748,7 +832,7 @@ def main():
         print(json.dumps(reference_batch_graph(args, cdt, dev)))
         return
     if args.workload != "aml-fused":          # one extra leg alone (profiling aid): prints that leg's object
-        leg = leg_tabgnn_arxiv if args.workload == "tabgnn-arxiv" else leg_wide64
+        leg = {"tabgnn-arxiv": leg_tabgnn_arxiv, "wide64-c256": leg_wide64, "wide64-graph": leg_wide64_graph}[args.workload]
         print(json.dumps(leg(cdt, dev, steps=args.steps, warmup=args.warmup)))
         return
     torch.manual_seed(1234)
@@ -828,16 +912,17 @@ def main():
         "value": edges / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"HI-Small-shaped AML sampled subgraphs, fused supervised (configs[1]): d={args.hidden}, "
-                               f"{args.nhead}-head FT-Transformer + {args.layers}-layer PNA, B={args.batch_size} seed "
-                               f"edges/step/GPU, E={int(E_mean)} sampled edges, N={int(N_mean)} nodes, 5 edge columns "
-                               f"(3 cat, 1 num, 1 ts), dropout 0.5/0.083, Adam" + (", reverse_mp" if args.reverse_mp else ""),
+        # (the driver keeps `config` whole but cuts every string at 120 characters: facts travel as short strings and numbers)
+        "config": {"workload": f"configs[1] HI-Small-shaped AML, fused supervised, d={args.hidden} {args.nhead}-head + "
+                               f"{args.layers}-layer PNA, B={args.batch_size}" + (", reverse_mp" if args.reverse_mp else ""),
+                   "columns": "5 edge columns (3 cat, 1 num, 1 ts), 1 node column", "dropout": [0.5, 0.083], "optimizer": "Adam",
+                   "hidden": args.hidden, "nhead": args.nhead, "layers": args.layers,
                    "batch_size": args.batch_size, "edges_per_step": int(E_mean), "nodes_per_step": int(N_mean),
+                   "spmm_frac_synthetic": achieved / HBM_PEAK_GBS,
                    "rows_per_sec": rows * args.steps * world / elapsed, "parallelism": f"dp{world}",
                    "peak_hbm_gb": peak_hbm_gb,
-                   "index": ("CSR-by-destination/by-source of the batch built by the sampler side on the host "
-                             "(tg_host_csr) and resident in HBM with the batch" if args.index == "sampler" else
-                             "CSRs rebuilt from edge_index on the device inside every forward (tg_csr_build)")},
+                   "index": ("batch CSRs built by the sampler side (host), resident with the batch" if args.index == "sampler"
+                             else "batch CSRs rebuilt on the device inside every forward (tg_csr_build)")},
         "roofline": {"kernel": "k_pna_aggregate_fwd", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": (f"{pmc_path}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -929,6 +1014,9 @@ def main():
         out["reference_batch"] = reference_batch(args, cdt, dev)
         if args.dtype == "bf16":
             out["other_workloads"] = {"tabgnn-arxiv": leg_tabgnn_arxiv(cdt, dev), "wide64-c256": leg_wide64(cdt, dev)}
+            # configs[4] on its 10 M-node / 100 M-edge graph with the 80 GB raw table resident: a CHILD process (its 85 GB
+            # must not sit beside this process's allocations, and a failure there must not take the bench line down)
+            out["other_workloads"]["wide64-c256"]["on_graph"] = _child_leg(["--workload", "wide64-graph", "--steps", "6", "--warmup", "3"])
     if extras and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model.state_dict(), args.nhead, args.cpu_batch_size, args.cpu_steps,
                                            cfg["lr"], cfg["loss_weights"])
@@ -936,11 +1024,10 @@ def main():
         out["end_to_end"] = end_to_end(model, flat, opt, loss_w, args.batch_size, args.e2e_steps, dev)
         out["roofline_sampled"] = out["end_to_end"].pop("roofline_sampled")
         # (the driver keeps `config` whole but only the key names of extra objects: the aggregation's fraction on the
-        # batch the package's own sampler draws — fewer, denser destination rows — travels in the workload text)
+        # batch the package's own sampler draws — fewer, denser destination rows — travels as a numeric config key)
         rsf = out["roofline_sampled"].get("frac")
         if rsf is not None:
-            out["config"]["workload"] += (f"; SpMM roofline frac {out['roofline']['frac']:.3f} on this synthetic batch, "
-                                          f"{rsf:.3f} on the sampler-drawn batch (roofline_sampled)")
+            out["config"]["spmm_frac_sampled"] = rsf       # the named kernel on the batch the package's own sampler draws
     if extras and args.dtype == "bf16":
         out["fp32_twin"] = fp32_twin(args)
     print(json.dumps(out))

@@ -89,3 +89,72 @@ def make_config(n_hidden=128, n_layers=2, nhead=4, batch_size=200, backbone_drop
                 reverse_mp=False, load_model=None, checkpoint=False, loss_weights=[1.0, 9.23], lr=0.0006116418,
                 node_encoder=StypeWiseFeatureEncoder(n_hidden, {}, NODE_COLS, compute_dtype),
                 edge_encoder=StypeWiseFeatureEncoder(n_hidden, EDGE_STATS, EDGE_COLS, compute_dtype))
+
+
+# ---- BASELINE configs[4]: synthetic 10 M-node / 100 M-edge table + graph, 64 mixed stype columns -----------
+WIDE_CARDS_SEED = 5
+
+
+def wide64_columns():
+    """(names, stats, cardinalities) of the 64-column edge table: 32 categorical (cardinalities log-uniform 2 .. 10^4),
+    24 numerical, 8 timestamp."""
+    rs = np.random.RandomState(WIDE_CARDS_SEED)
+    cards = [int(c) for c in np.exp(rs.uniform(np.log(2), np.log(1e4), 32))]
+    names = {stype.numerical: [f"n{i}" for i in range(24)], stype.categorical: [f"c{i}" for i in range(32)],
+             stype.timestamp: [f"t{i}" for i in range(8)]}
+    stats = {**{f"n{i}": dict(mean=0.0, std=1.0) for i in range(24)},
+             **{f"c{i}": dict(cardinality=cards[i]) for i in range(32)}, **{f"t{i}": dict(min_year=2015) for i in range(8)}}
+    return names, stats, cards
+
+
+def wide64_config(batch_size, in_degrees, compute_dtype, n_hidden=256):
+    from .encoders import StypeWiseFeatureEncoder
+    names, stats, _ = wide64_columns()
+    return dict(model="tabgnnfused", task="edge_classification", batch_size=batch_size, n_hidden=n_hidden, n_gnn_layers=2,
+                n_classes=2, dropout=0.083, backbone_dropout=0.5, nhead=8, num_node_features=1, num_edge_features=64,
+                in_degrees=in_degrees, reverse_mp=False, load_model=None, checkpoint=False,
+                node_encoder=StypeWiseFeatureEncoder(n_hidden, {}, NODE_COLS, compute_dtype),
+                edge_encoder=StypeWiseFeatureEncoder(n_hidden, stats, names, compute_dtype))
+
+
+def powerlaw_graph_on_device(num_nodes, num_edges, device, seed=11):
+    """edge_index int64 [2, E] generated ON the GPU: uniform sources, destinations ~ N * u^2 (density ~ x^-1/2: node 0
+    collects ~E / sqrt(N) in-edges, the median node E / N / 2)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    ei = torch.empty(2, num_edges, dtype=torch.int64, device=device)
+    chunk = 1 << 24
+    for a in range(0, num_edges, chunk):
+        b = min(a + chunk, num_edges)
+        ei[0, a:b] = torch.randint(0, num_nodes, (b - a,), device=device, generator=g)
+        u = torch.rand(b - a, device=device, generator=g)
+        ei[1, a:b] = (u * u * num_nodes).long().clamp_(max=num_nodes - 1)
+    return ei
+
+
+def wide64_store_on_device(num_nodes, num_edges, device, seed=12, p_pos=0.05):
+    """The raw 64-column edge table (800 B per row: 32 int64 categories, 24 fp32 values, 8 x 7 int64 calendar fields) and
+    its labels generated ON the GPU in chunks, as a ``ColumnStore`` (the table stays resident in HBM; a batch is a list
+    of row ids).  100 M rows = 80 GB."""
+    from .sampler import ColumnStore
+    names, _, cards = wide64_columns()
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    E = int(num_edges)
+    cat = torch.empty(E, 32, dtype=torch.int64, device=device)
+    num = torch.empty(E, 24, dtype=torch.float32, device=device)
+    ts = torch.empty(E, 8, 7, dtype=torch.int64, device=device)
+    labels = torch.empty(E, dtype=torch.int64, device=device)
+    hi = (2024, 12, 28, 7, 24, 60, 60)
+    chunk = 1 << 22
+    for a in range(0, E, chunk):
+        b = min(a + chunk, E)
+        n = b - a
+        for j, c in enumerate(cards):
+            cat[a:b, j] = torch.randint(0, c, (n,), device=device, generator=g)
+        num[a:b] = torch.randn(n, 24, device=device, generator=g)
+        for k in range(7):
+            ts[a:b, :, k] = torch.randint(2015 if k == 0 else 0, hi[k], (n, 8), device=device, generator=g)
+        labels[a:b] = (torch.rand(n, device=device, generator=g) < p_pos).long()
+    return ColumnStore({stype.numerical: num, stype.categorical: cat, stype.timestamp: ts}, names,
+                       {stype.relation: torch.ones(int(num_nodes), 1, device=device)}, NODE_COLS, labels)
