@@ -29,7 +29,7 @@ struct SgWs {            // carved out of the caller's workspace (all 16-byte al
   int *wcnt, *wpre;      // [nw + 1] popcounts of a node bitmap and their exclusive prefix
   int *flist, *fcnt, *foff;          // frontier nodes [N], draws per node [N + 1], exclusive prefix [N + 1]
   int *e_src, *e_dst, *e_eid, *keep, *koff;     // staging [cap] (+1 for koff)
-  int *tops;             // block totals of the scans [<= 1024 + 1]
+  int *tops;             // block totals of the scans [<= 1024 * SG_TOPS_PT + 1]
   long long* counts;     // [4]: staged edges, kept edges, nodes, error flag
 };
 
@@ -39,7 +39,7 @@ __device__ __forceinline__ unsigned long long sg_mix(unsigned long long z) {
   return z ^ (z >> 31);
 }
 
-// ------------------------------------------------------------------ two-level exclusive scan of int32 (n <= 4 Mi)
+// ------------------------------------------------------------------ two-level exclusive scan of int32 (n <= 67 M)
 // n_dev (optional): the live length sits in device memory (the staged-edge count); entries at or past it read as zero
 __device__ __forceinline__ int sg_len(int n, const long long* n_dev) {
   if (!n_dev) return n;
@@ -81,10 +81,15 @@ __global__ void __launch_bounds__(1024) k_sg_scan_block(const int* __restrict__ 
     ex += v[j];
   }
 }
-// exclusive scan of the block totals in place (nb <= 1024), grand total to tops[nb] and to *total_out (optional)
+// exclusive scan of the block totals in place (nb <= 1024 * SG_TOPS_PT: eight consecutive totals per thread), grand total
+// to tops[nb] and to *total_out (optional)
+constexpr int SG_TOPS_PT = 8;            // -> scans of up to 8192 * 8192 = 67 M elements (the 10 M-node graph of configs[4])
 __global__ void __launch_bounds__(1024) k_sg_scan_tops(int* __restrict__ tops, int nb, long long* __restrict__ total_out) {
   __shared__ int wsum[16];
-  const int v = (int)threadIdx.x < nb ? tops[threadIdx.x] : 0;
+  const int b0 = (int)threadIdx.x * SG_TOPS_PT;
+  int tv[SG_TOPS_PT], v = 0;
+#pragma unroll
+  for (int j = 0; j < SG_TOPS_PT; ++j) { tv[j] = b0 + j < nb ? tops[b0 + j] : 0; v += tv[j]; }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int inc = v;
 #pragma unroll
@@ -105,7 +110,12 @@ __global__ void __launch_bounds__(1024) k_sg_scan_tops(int* __restrict__ tops, i
     if (lane == 15) { tops[nb] = winc; if (total_out) *total_out = winc; }
   }
   __syncthreads();
-  if ((int)threadIdx.x < nb) tops[threadIdx.x] = wsum[wave] + inc - v;
+  int ex = wsum[wave] + inc - v;
+#pragma unroll
+  for (int j = 0; j < SG_TOPS_PT; ++j) {
+    if (b0 + j < nb) tops[b0 + j] = ex;
+    ex += tv[j];
+  }
 }
 __global__ void __launch_bounds__(1024) k_sg_scan_add(int* __restrict__ out, int n_, const long long* __restrict__ n_dev,
                                                       const int* __restrict__ tops, int nb) {
@@ -117,7 +127,7 @@ __global__ void __launch_bounds__(1024) k_sg_scan_add(int* __restrict__ out, int
     if (base + j < n) out[base + j] += add;
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tops[nb];       // out has n + 1 entries: the total closes it
 }
-// out[0..n] = exclusive prefix of in[0..n) (out[n] = total); tops: >= nb + 1 ints; n <= 1024 * SG_SCAN_ELEMS
+// out[0..n] = exclusive prefix of in[0..n) (out[n] = total); tops: >= nb + 1 ints; n <= 1024 * SG_TOPS_PT * SG_SCAN_ELEMS
 static int sg_scan(const int* in, int* out, int n, const long long* n_dev, int* tops, long long* total_out, hipStream_t st) {
   const int nb = n > 0 ? (n + SG_SCAN_ELEMS - 1) / SG_SCAN_ELEMS : 1;
   hipLaunchKernelGGL(k_sg_scan_block, dim3(nb), dim3(1024), 0, st, in, out, n, n_dev, tops);
@@ -286,7 +296,7 @@ static size_t sg_carve(char* base, int32_t N, int64_t cap, SgWs* w) {
   int* ee = (int*)take((size_t)cap * 4);
   int* kp = (int*)take((size_t)cap * 4);
   int* ko = (int*)take(((size_t)cap + 1) * 4);
-  int* tops = (int*)take(1026 * 4);
+  int* tops = (int*)take((1024 * SG_TOPS_PT + 2) * 4);
   long long* counts = (long long*)take(4 * 8);
   if (w) {
     w->visited = vis; w->frontier = fro; w->next = nxt; w->wcnt = wcnt; w->wpre = wpre; w->flist = flist; w->fcnt = fcnt;
@@ -315,7 +325,7 @@ extern "C" int tg_gsampler_draw(const int64_t* seeds, int64_t B, const int64_t* 
            "tg_gsampler_draw: null operand");
   TG_CHECK(B > 0 && B <= cap && N > 0 && E > 0 && E < 2147483647LL && hops >= 1 && hops <= 8 && cap <= 1024LL * SG_SCAN_ELEMS,
            "tg_gsampler_draw: bad sizes (B=%lld N=%d E=%lld cap=%lld hops=%d)", (long long)B, N, (long long)E, (long long)cap, hops);
-  TG_CHECK((size_t)N <= 1024ull * SG_SCAN_ELEMS, "tg_gsampler_draw: N above the scan limit");
+  TG_CHECK((size_t)N <= 1024ull * SG_TOPS_PT * SG_SCAN_ELEMS, "tg_gsampler_draw: N above the scan limit (%d M nodes)", 8 * SG_TOPS_PT);
   for (int h = 0; h < hops; ++h)
     TG_CHECK(fanout[h] < 0 || fanout[h] <= SG_MAX_FAN, "tg_gsampler_draw: fan-out %d above %d", fanout[h], SG_MAX_FAN);
   hipStream_t st = (hipStream_t)stream;
