@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=10, help="timed oracle steps per thread count (median reported)")
     ap.add_argument("--no-extras", action="store_true", help="skip every extra object (reference_batch, eval, "
                     "other_workloads, roofline_gemm, cpu_baseline, end_to_end): the bare contract line, for profiling")
-    ap.add_argument("--workload", default="aml-fused", choices=["aml-fused", "tabgnn-arxiv", "wide64-c256", "wide64-graph", "reference-batch-graph"],
+    ap.add_argument("--workload", default="aml-fused", choices=["aml-fused", "tabgnn-arxiv", "wide64-c256", "wide64-graph", "reference-batch-graph", "reference-sampled-loop"],
                     help="aml-fused = the headline (BASELINE configs[1]); the other two run ONE extra leg alone "
                          "(configs[3] / configs[4] shapes) and print its object — for profiling, never the headline")
     ap.add_argument("--reverse-mp", action="store_true", help="PNAConvHetero (forward + reverse message passing); "
@@ -463,15 +463,15 @@ def reference_batch_sampled_loop(cfg, cdt, dev, B, steps=120, warm=60):
     # thread, no upload, no size wait; the buckets captured above are reused (same model, same GraphedTrainStep).
     from tabgnn_amd import DeviceBatchLoader, DeviceNeighborSampler
     dsmp = DeviceNeighborSampler(ei, N, (100, 100), dev)
-    d_total = steps + 20
+    d_total = steps + warm       # (its own warm-up: the device sampler's draws differ from the host's, so may the buckets)
     loader = DeviceBatchLoader(dsmp, store, [rs.choice(E, B, replace=False) for _ in range(d_total)], mode="bucket", rng_seed=7)
     d_edges = d_new = 0
     for i, prep in enumerate(loader):
-        if i == 20:
+        if i == warm:
             torch.cuda.synchronize(); t2 = time.perf_counter(); d_edges = 0
         nb = len(step.buckets)
         step(prep, frames)
-        d_new += int(i >= 20 and len(step.buckets) > nb)
+        d_new += int(i >= warm and len(step.buckets) > nb)
         d_edges += prep.e_real
     torch.cuda.synchronize()
     d_dt = time.perf_counter() - t2
@@ -830,6 +830,10 @@ def main():
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     if args.workload == "reference-batch-graph":
         print(json.dumps(reference_batch_graph(args, cdt, dev)))
+        return
+    if args.workload == "reference-sampled-loop":
+        cfg = S.make_config(args.hidden, args.layers, args.nhead, 200, compute_dtype=cdt)
+        print(json.dumps(reference_batch_sampled_loop(cfg, cdt, dev, 200)))
         return
     if args.workload != "aml-fused":          # one extra leg alone (profiling aid): prints that leg's object
         leg = {"tabgnn-arxiv": leg_tabgnn_arxiv, "wide64-c256": leg_wide64, "wide64-graph": leg_wide64_graph}[args.workload]
