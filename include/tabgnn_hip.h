@@ -18,7 +18,7 @@
 #define TABGNN_HIP_H_
 #include <stdint.h>
 
-#define TABGNN_HIP_ABI_VERSION 6
+#define TABGNN_HIP_ABI_VERSION 7
 
 /* The `uint64_t seed` argument of every entry point that draws dropout masks is either the seed itself (bit 63 clear)
  * or TG_SEED_DEVICE(p): the device address p of a 64-bit seed word that the kernel reads when it RUNS (word 0 of a
@@ -113,6 +113,15 @@ int tg_encode_ts_features(const int64_t* ts, int32_t nt, int32_t src_col, const 
  * the device = (destination float* as integer, offset into src, length).  Used by the encoder backward so that no
  * per-parameter zero-fill / slice copy / autograd add runs. */
 int tg_scatter_add_segments(const float* src, const int64_t* table, int32_t nseg, int64_t max_len, void* stream);
+/* Gradient of embedding tables too large for tg_encode_bwd's LDS accumulators (torch nn.Embedding inside the fork's
+ * EmbeddingEncoder; reference call site src/datasets/ibm_transactions_for_aml.py:283-319), in a FIXED order: the caller
+ * sorts keys[slot * R + r] = base[slot] + clamp(category(r, slot) + 1, 0, rows[slot] - 1) with tg_csr_build (buckets =
+ * sum of the tables' rows) and one wave per (column, category) bucket sums rows of g [R, gstride] in that order into
+ * dst[category, :C] (fp32; added when accumulate != 0).  cols: device int64 [ncol][4] = (base, out_col, dst pointer,
+ * rows).  tg_encode_bwd with big_table_grad == NULL leaves these tables alone (non-NULL: the old atomicAdd path). */
+int tg_embed_grad_sorted(const void* g, int64_t gstride, const int32_t* rowptr, const int32_t* perm, int64_t R,
+                         const int64_t* cols, int32_t ncol, int32_t max_rows, int32_t C, int32_t accumulate, int32_t dt,
+                         void* stream);
 
 /* ---- column self-attention core (torch nn.MultiheadAttention inside nn.TransformerEncoderLayer;
  *      src/nn/models/fused.py:83-92,160,164,187-196,249; src/nn/models/tabgnn.py:199-208,219) ---------- */

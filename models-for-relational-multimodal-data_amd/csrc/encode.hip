@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_encode_bwd(EncDesc d, EncPtrs p, const 
             a.x += on ? gv[rr][0] : 0.f; a.y += on ? gv[rr][1] : 0.f; a.z += on ? gv[rr][2] : 0.f; a.w += on ? gv[rr][3] : 0.f;
             *a4 = a;
           }
-        } else {
+        } else if (big_table_grad) {      // (NULL: the caller reduces the big tables by tg_embed_grad_sorted, in a fixed order)
 #pragma unroll
           for (int rr = 0; rr < ENC_RCH; ++rr)
             if (rowi[rr] != 0)
@@ -544,6 +544,71 @@ extern "C" int tg_encode_ts_features(const int64_t* ts, int32_t nt, int32_t src_
   hipLaunchKernelGGL(k_encode_ts_feats, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const long long*)ts, nt, src_col,
                      min_year + src_col, (const long long*)row_ids, (unsigned short*)feats, (long long)R, w, b,
                      (unsigned short*)wext, C);
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------ big embedding tables, deterministic (round 5)
+// Tables with more rows than the LDS accumulators hold (> tg_encode_small_table_rows) used float atomicAdd: the order of
+// the additions — hence the last bits of the gradient — changed from run to run.  Here the batch's (column, category)
+// pairs are counting-sorted first (tg_csr_build over keys = bucket base of the column + clamped category, key index
+// i = column slot * R + row: a stable sort, rows ascending inside a bucket) and ONE wave sums a bucket's gradient rows in
+// that order into the table's gradient row: every element has exactly one writer and one order.
+// cols: int64 [ncol][4] on the device = (first bucket of the column, out_col of the column in g's rows, destination
+// float* of the column's table gradient (row 0), table rows).  Bucket 0 of a column is padding_idx: no gradient.
+struct EmbCol { long long base, out_col, dst, rows; };
+template <typename T>
+__global__ void __launch_bounds__(256) k_embed_grad_sorted(const T* __restrict__ g, long long gstride, const int* __restrict__ rowptr,
+                                                          const int* __restrict__ perm, long long R, const EmbCol* __restrict__ cols,
+                                                          int C, int accumulate) {
+  const EmbCol c = cols[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* dst = reinterpret_cast<float*>(c.dst);
+  const long long slot_base = (long long)blockIdx.y * R;          // key index of row r of this column = slot_base + r
+  for (long long cat = 1 + (long long)blockIdx.x * 4 + wave; cat < c.rows; cat += (long long)gridDim.x * 4) {
+    const int b0 = rowptr[c.base + cat], b1 = rowptr[c.base + cat + 1];
+    for (int ch = 2 * lane; ch < C; ch += 128) {                   // two channels per lane and pass (C = 128: one pass)
+      float a0 = 0.f, a1 = 0.f;
+      int k = b0;
+      for (; k + 4 <= b1; k += 4) {                                // four rows in flight; summed in order
+        float v[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long r = (long long)perm[k + u] - slot_base;
+          float t[2];
+          loadv<T, 2>(g + r * gstride + c.out_col * C + ch, t);
+          v[u][0] = t[0]; v[u][1] = t[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a0 += v[u][0]; a1 += v[u][1]; }
+      }
+      for (; k < b1; ++k) {
+        const long long r = (long long)perm[k] - slot_base;
+        float t[2];
+        loadv<T, 2>(g + r * gstride + c.out_col * C + ch, t);
+        a0 += t[0]; a1 += t[1];
+      }
+      float* o = dst + cat * C + ch;
+      if (accumulate) { o[0] += a0; o[1] += a1; }
+      else { o[0] = a0; o[1] = a1; }
+    }
+  }
+}
+
+extern "C" int tg_embed_grad_sorted(const void* g, int64_t gstride, const int32_t* rowptr, const int32_t* perm, int64_t R,
+                                    const int64_t* cols, int32_t ncol, int32_t max_rows, int32_t C, int32_t accumulate,
+                                    int32_t dt, void* stream) {
+  if (ncol <= 0 || R <= 0) return 0;
+  TG_CHECK(g && rowptr && perm && cols && C > 0 && C % 2 == 0 && max_rows > 0, "tg_embed_grad_sorted: bad argument");
+  TG_CHECK((long long)ncol * R <= 2147483647LL, "tg_embed_grad_sorted: %d columns x %lld rows exceed the int32 key index", ncol, (long long)R);
+  int bx = (max_rows + 3) / 4;
+  if (bx > 2048) bx = 2048;
+  if (dt == F32)
+    hipLaunchKernelGGL((k_embed_grad_sorted<float>), dim3(bx, ncol), dim3(256), 0, (hipStream_t)stream, (const float*)g,
+                       (long long)gstride, rowptr, perm, (long long)R, (const EmbCol*)cols, C, accumulate);
+  else
+    hipLaunchKernelGGL((k_embed_grad_sorted<bf16_t>), dim3(bx, ncol), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g,
+                       (long long)gstride, rowptr, perm, (long long)R, (const EmbCol*)cols, C, accumulate);
   TG_LAUNCH_CHECK();
   return 0;
 }

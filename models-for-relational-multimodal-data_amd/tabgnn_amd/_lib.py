@@ -12,7 +12,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TABGNN_LIB_PATH") or os.path.join(_HERE, "libtabgnn_hip.so")     # (override: kernel A/B builds)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i32, _i64, _f32, _u32, _u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_uint64
 
@@ -30,6 +30,7 @@ SIGNATURES = {
     "tg_encode_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "tg_encode_bwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp],
     "tg_scatter_add_segments": [_vp, _vp, _i32, _i64, _vp],
+    "tg_embed_grad_sorted": [_vp, _i64, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "tg_attn_fwd": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u64, _u32, _i32, _vp],
     "tg_ln_partials_floats": [_i64, _i32],

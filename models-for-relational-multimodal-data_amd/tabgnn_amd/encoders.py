@@ -163,6 +163,31 @@ class _Encode(torch.autograd.Function):
                        row_cols * Cc, 128, 0, L.stream())
                 dflat[off:off + 57 * Cc].view(57, Cc).copy_(dw[:, :57].t())
 
+        big = plan["big"]                 # categorical columns whose table exceeds the LDS accumulators
+
+        def big_tables(dst_of):
+            """Their gradients in a fixed order (tg_embed_grad_sorted): counting sort of the batch's (column, category)
+            pairs, one wave per bucket.  ``dst_of(src_col)`` = fp32 gradient tensor [rows, C] of that column's table."""
+            if not big or R == 0:
+                return
+            cat = feats[stype.categorical]
+            rows_sel = cat if ctx.row_ids is None else cat.index_select(0, ctx.row_ids)
+            cols_t = torch.tensor([c["src_col"] for c in big], dtype=torch.int64, device=dev)
+            lim = torch.tensor([c["rows"] - 1 for c in big], dtype=torch.int64, device=dev)
+            base = torch.tensor([c["base"] for c in big], dtype=torch.int64, device=dev)
+            idx = (rows_sel.index_select(1, cols_t) + 1).clamp_(min=0)
+            keys = (torch.minimum(idx, lim) + base).t().contiguous().to(torch.int32).reshape(-1)       # [nbig * R], slot-major
+            nb = big[-1]["base"] + big[-1]["rows"]
+            rowptr = torch.empty(nb + 1, dtype=torch.int32, device=dev)
+            perm = torch.empty(keys.numel(), dtype=torch.int32, device=dev)
+            work = torch.empty(L.load().tg_csr_workspace_ints(keys.numel(), nb), dtype=torch.int32, device=dev)
+            L.call("tg_csr_build", L.ptr(keys), keys.numel(), nb, L.ptr(rowptr), L.ptr(perm), L.ptr(work), L.stream())
+            dsts = [dst_of(c["src_col"]) for c in big]
+            table = torch.tensor([[c["base"], c["out_col"], d.data_ptr(), c["rows"]] for c, d in zip(big, dsts)],
+                                 dtype=torch.int64, device=dev)
+            L.call("tg_embed_grad_sorted", g.data_ptr(), row_cols * Cc, L.ptr(rowptr), L.ptr(perm), R, L.ptr(table), len(big),
+                   max(c["rows"] for c in big), Cc, 1, L.dt(g), L.stream())
+
         seg_tables = enc._grad_segment_tables(dev)
         if seg_tables is not None:
             # every encoder parameter already owns a gradient buffer: the reduced vector of each column group is
@@ -172,12 +197,14 @@ class _Encode(torch.autograd.Function):
                 partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
                 run_group(gi, desc, acc_floats, dflat, partials, None)
                 L.call("tg_scatter_add_segments", L.ptr(dflat), L.ptr(table), nseg, max_len, L.stream())
+            embs = enc.encoder_dict["categorical"].embs if big else None
+            big_tables(lambda j: embs[j].weight.grad)          # added straight into the parameters' gradient buffers
             return (None,) * (4 + len(params))
         grads = [None if p is None else torch.zeros_like(p) for p in params]
         for gi, (desc, acc_floats, segs) in enumerate(zip(plan["descs"], plan["acc_floats"], plan["segments"])):
             dflat = torch.empty(max(acc_floats, 1), dtype=torch.float32, device=dev)
             partials = torch.empty(nblk * max(acc_floats, 1), dtype=torch.float32, device=dev)
-            run_group(gi, desc, acc_floats, dflat, partials, L.ptr(grads[2]))
+            run_group(gi, desc, acc_floats, dflat, partials, None)
             for kind, src_col, off, rows, tab_off in segs:
                 if kind == 0:
                     grads[0][src_col] = dflat[off:off + Cc]; grads[1][src_col] = dflat[off + Cc:off + 2 * Cc]
@@ -188,6 +215,9 @@ class _Encode(torch.autograd.Function):
                     grads[4][src_col] = dflat[off + 56 * Cc:off + 57 * Cc]
                 elif off >= 0:
                     grads[2][tab_off:tab_off + rows] = dflat[off:off + rows * Cc].view(rows, Cc)
+        tab = {c["src_col"]: c["tab_off"] for c in big}
+        rws = {c["src_col"]: c["rows"] for c in big}
+        big_tables(lambda j: grads[2][tab[j]:tab[j] + rws[j]])     # (grads[2] starts zeroed: contiguous row slices of it)
         return (None, None, None, None, *grads)
 
 
@@ -271,12 +301,17 @@ class StypeWiseFeatureEncoder(nn.Module):
             dn.ncol, dn.nts = len(grp) - nts, 0
             ts_cols = [(c["src_col"], c["out_col"], d.col[j].acc_off) for j, c in enumerate(grp) if c["kind"] == 2]
             nots.append((dn, min([t[2] for t in ts_cols], default=off), ts_cols))
-        return dict(ncols=out_col, descs=descs, acc_floats=accs, segments=segments, nots=nots)
+        big, base = [], 0
+        for c in cols:
+            if c["kind"] == 1 and c["rows"] > small:
+                big.append(dict(src_col=c["src_col"], out_col=c["out_col"], rows=c["rows"], tab_off=c["tab_off"], base=base))
+                base += c["rows"]
+        return dict(ncols=out_col, descs=descs, acc_floats=accs, segments=segments, nots=nots, big=big)
 
     def _grad_segment_tables(self, dev):
         """Per column group: (device int64 table [nseg,3] = (gradient-buffer address, offset in the group's reduced
-        vector, length), nseg, longest segment) — or None when some parameter has no gradient buffer yet, or a
-        categorical table is too large for the LDS accumulators (its gradient then goes through atomics)."""
+        vector, length), nseg, longest segment) — or None when some parameter has no gradient buffer yet.  Categorical
+        tables too large for the LDS accumulators are not listed: ``tg_embed_grad_sorted`` adds their gradients."""
         ed, Cc = self.encoder_dict, self.out_channels
 
         def grad_of(p):
@@ -308,9 +343,7 @@ class StypeWiseFeatureEncoder(nn.Module):
                     rows_ += [(w[src_col].data_ptr(), off, 56 * Cc), (b[src_col].data_ptr(), off + 56 * Cc, Cc)]
                 elif off >= 0:
                     rows_.append((embs[src_col].data_ptr(), off, rows * Cc))
-                else:
-                    cache[key] = None
-                    return None
+                # (off < 0: a table too large for the LDS accumulators — reduced by tg_embed_grad_sorted, not listed here)
             table = torch.tensor(rows_, dtype=torch.int64, device=dev).reshape(-1, 3) if rows_ else \
                 torch.zeros(0, 3, dtype=torch.int64, device=dev)
             tables.append((table, len(rows_), max([r[2] for r in rows_], default=1)))

@@ -252,6 +252,61 @@ def test_stype_encoder_matches_oracle(T, C):
         close(p.grad, sd[k].grad, 2e-5, k)
 
 
+@pytest.mark.parametrize("C,flat,lazy,dtype", [(128, False, False, torch.float32), (128, True, True, torch.bfloat16),
+                                                (256, True, False, torch.bfloat16), (32, True, True, torch.float32)])
+def test_big_embedding_tables_gradient_in_a_fixed_order(T, C, flat, lazy, dtype):
+    """Embedding tables above tg_encode_small_table_rows (64) — configs[4] has 19 of them — reduced by a counting sort of the
+    (column, category) pairs + one wave per bucket (tg_embed_grad_sorted) instead of float atomicAdd: equal to torch's
+    embedding autograd on the same upstream gradient, with and without FlatParams gradient buffers and row ids, missing
+    categories (-1 -> padding row) included, and bit-identical when repeated."""
+    st = T.stype
+    g = torch.Generator().manual_seed(C)
+    Rtab, R = 5000, 3001
+    cards = [5, 100, 3000, 70]
+    cat = torch.stack([torch.randint(0, c, (Rtab,), generator=g) for c in cards], dim=1)
+    cat[7, 2] = -1
+    cat[8, 1] = -1
+    num = torch.rand(Rtab, 1, generator=g)
+    names = {st.numerical: ["n0"], st.categorical: [f"c{i}" for i in range(4)]}
+    stats = {"n0": dict(mean=0.4, std=0.3), **{f"c{i}": dict(cardinality=c) for i, c in enumerate(cards)}}
+    enc = T.StypeWiseFeatureEncoder(C, stats, names, dtype).to(DEV)
+    assert len(enc._plan["big"]) == 3
+    if flat:
+        fp = T.FlatParams(enc, shadow_dtype=None if dtype == torch.float32 else dtype)
+    ids = torch.randperm(Rtab, generator=g)[:R]
+    ids[:20] = torch.tensor([7, 8] * 10)                        # the rows with missing categories, several times
+    feats = {st.numerical: num.to(DEV), st.categorical: cat.to(DEV)}
+    if lazy:
+        tf = T.TensorFrame(feats, names, None, ids.to(DEV))
+    else:
+        tf = T.TensorFrame({k: v[ids.to(DEV)] for k, v in feats.items()}, names)
+    go = torch.randn(R, 5, C, generator=g).to(dtype)
+    grads = []
+    for rep in range(2):
+        for p_ in enc.parameters():
+            if flat:
+                p_.grad.zero_()
+            else:
+                p_.grad = None
+        out, _ = enc(tf)
+        assert out.dtype == dtype
+        out.backward(go.to(DEV))
+        grads.append([e.weight.grad.clone() for e in enc.encoder_dict["categorical"].embs])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)                                 # fixed order: repeats bit for bit
+    sel = cat[ids]
+    for j, c in enumerate(cards):
+        w = torch.zeros(c + 1, C, requires_grad=True)
+        idx = (sel[:, j] + 1).clamp(min=0)
+        y = torch.nn.functional.embedding(idx, w, padding_idx=0)
+        y.backward(go[:, 1 + j].float())
+        got = grads[0][j].cpu()
+        assert got.shape == w.grad.shape
+        tol = 1e-5 if dtype == torch.float32 else 1e-5
+        assert (got - w.grad).abs().max().item() <= tol * max(1.0, w.grad.abs().max().item()), (j, c)
+        assert float(got[0].abs().max()) == 0.0                  # the padding row takes no gradient
+
+
 def test_stype_encoder_nan_inputs_become_zero(T):
     from oracle.encoders import stypewise_encode
     from detparams import fill_state_dict
