@@ -26,6 +26,19 @@ _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B
 _FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
 _DW_FFN = os.environ.get("TABGNN_NO_DW_FFN") != "1"      # A/B: feed-forward weight gradients inside the chained backward kernel
 _DX_FOLD = os.environ.get("TABGNN_NO_DX_FOLD") != "1"    # A/B: d_x += d_qkv W_in inside the attention-half backward kernel
+_LONG_FFN = os.environ.get("TABGNN_NO_LONG_ROW_FFN") != "1"   # A/B: fused feed-forward-half backward for rows of more than 32 tokens
+
+
+def token_group(S):
+    """Rows of more than 32 tokens (S = 65, 130: the tabgnn path and the 64-column table) cannot take the one-kernel layer
+    — its attention runs on a wave's 32 token slots — but everything behind the attention is token-wise.  The fused
+    feed-forward-half backward then runs on the flat token stream cut into pseudo rows of d tokens, d a divisor of S that
+    fills the 32 slots best (S = 130 -> 2: 16 pseudo rows per tile; S = 65 -> 5: 30 of 32 slots).  None: no such divisor."""
+    best = None
+    for d in range(2, 33):
+        if S % d == 0 and (best is None or (32 // d) * d > (32 // best) * best):
+            best = d
+    return best
 
 
 
@@ -171,8 +184,9 @@ class _EncoderLayerFn(torch.autograd.Function):
                               g1, g2, gt)
         ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
         ctx.nt = nt
+        ctx.prm_args = (lw_in, lw_o, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None, bt if tail else None)
         isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
-        ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2))   # weight gradients accumulate in place
+        ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2))   # weight gradients accumulate in place
         ctx.ln_params = ((g1, be1, b_o), (g2, be2, b2), (gt, bt, None))               # LayerNorm gradients too
         return out.view(R, S, C)
 
@@ -183,12 +197,25 @@ class _EncoderLayerFn(torch.autograd.Function):
         (x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2, g1, g2,
          gt) = ctx.saved_tensors
         R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
-        p_in, pb_in, p_o, p_1, pb_1, p_2 = ctx.params
+        p_in, pb_in, p_o, p_1, pb_1, p_2, pb_2 = ctx.params
         T = R * S
         g = g.contiguous().view(T, C)
         dgt = dbt = None
         d_x = None
         tg1, tg2 = ops.ln_grad_targets(*ctx.ln_params[0]), ops.ln_grad_targets(*ctx.ln_params[1])
+        grp = token_group(S) if (_LONG_FFN and _DW_FFN and ctx.nt and S > 32 and g.dtype == torch.bfloat16
+                                 and lw1.shape == (128, 128)) else None
+        if grp is not None:
+            # long rows: the whole feed-forward half (tail LN, LN2, FFN, its weight / bias / LayerNorm gradients) in the
+            # chained kernel of the one-kernel layer, on the token stream as pseudo rows of `grp` tokens; recomputes x1 and
+            # h from (z1 = y, z2 = y2) on the forward's dropout streams (element index = token * 128 + channel in both paths)
+            d_x1, (dw1, db1, dw2, db2), (dg2, dbe2, dgt, dbt) = _ffn_half_backward(
+                g, y, y2, (lw1, lw2), (p_1, pb_1, p_2, pb_2), ctx.ln_params, T // grp, grp, tail, beta_c, p, seed, rs,
+                ctx.prm_args)
+            dp2 = (dg2, dbe2, db2)
+            if tail and alpha != 0.0:
+                d_x = g * alpha                      # the residual branch of out = alpha x + beta_c LN_t(.)
+            return _attention_half_backward(ctx, d_x, d_x1, dw1, db1, dw2, dp2, dgt, dbt)
         d_x1 = torch.empty_like(x1)
         if tail and ctx.nt and _FUSED_TAIL:
             # out = alpha*x + beta_c*LN_t(x2), x2 = LN2(z2): both LayerNorm backwards in one kernel, the gradient of x2
@@ -246,31 +273,43 @@ class _EncoderLayerFn(torch.autograd.Function):
         else:
             d_x1.addmm_(d_hpre, lw1)
         del d_hpre
-        # x1 = LN1(x + drop(y + b_o))
-        acc_dx = d_x is not None
-        if d_x is None:
-            d_x = torch.empty_like(x1)
-        if ctx.nt:
-            d_y, dp1 = _ln_bwd(y, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
-        else:
-            d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
-        del d_x1
-        dwo, _ = ops.weight_grad(d_y, o, False, p_o)
-        d_o = ops.gemm_nt(d_y, ops.wt(lw_o, p_o)) if nt else d_y @ lw_o
-        del d_y
-        d_qkv = torch.empty_like(qkv)
-        L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
-               L.dt(qkv), L.stream())
-        del d_o
-        dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
-        if dbin is None and dwin is not None:
-            dbin = d_qkv.sum(0, dtype=torch.float32)
-        if nt:                                           # third consumer of x
-            ops.gemm_nt(d_qkv, ops.wt(lw_in, p_in), None, ops.NT_ACCUM, out=d_x)
-        else:
-            d_x.addmm_(d_qkv, lw_in)
-        return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],
-                dp1[0], dp1[1], dp2[0], dp2[1], dgt, dbt, None)
+        return _attention_half_backward(ctx, d_x, d_x1, dw1, db1, dw2, dp2, dgt, dbt)
+
+
+def _attention_half_backward(ctx, d_x, d_x1, dw1, db1, dw2, dp2, dgt, dbt):
+    """Op-by-op backward from d_x1 (gradient of the LN1 output) to d_x: LN1, out-proj, attention, in-proj."""
+    (x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2, g1, g2,
+     gt) = ctx.saved_tensors
+    R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
+    p_in, pb_in, p_o = ctx.params[:3]
+    T = R * S
+    nt = ctx.nt
+    tg1 = ops.ln_grad_targets(*ctx.ln_params[0])
+    # x1 = LN1(x + drop(y + b_o))
+    acc_dx = d_x is not None
+    if d_x is None:
+        d_x = torch.empty_like(x1)
+    if ctx.nt:
+        d_y, dp1 = _ln_bwd(y, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
+    else:
+        d_y, dp1 = _ln_bwd(x2d, y, b_o, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
+    del d_x1
+    dwo, _ = ops.weight_grad(d_y, o, False, p_o)
+    d_o = ops.gemm_nt(d_y, ops.wt(lw_o, p_o)) if nt else d_y @ lw_o
+    del d_y
+    d_qkv = torch.empty_like(qkv)
+    L.call("tg_attn_bwd", L.ptr(qkv), L.ptr(o), L.ptr(d_o), L.ptr(lse), L.ptr(d_qkv), R, S, C, H, p, seed, rs[0],
+           L.dt(qkv), L.stream())
+    del d_o
+    dwin, dbin = ops.weight_grad(d_qkv, x2d, True, p_in, pb_in)
+    if dbin is None and dwin is not None:
+        dbin = d_qkv.sum(0, dtype=torch.float32)
+    if nt:                                           # third consumer of x
+        ops.gemm_nt(d_qkv, ops.wt(lw_in, p_in), None, ops.NT_ACCUM, out=d_x)
+    else:
+        d_x.addmm_(d_qkv, lw_in)
+    return (d_x.view(R, S, C), None, None, None, None, None, dwin, dbin, dwo, dp1[2], dw1, db1, dw2, dp2[2],
+            dp1[0], dp1[1], dp2[0], dp2[1], dgt, dbt, None)
 
 
 def _grad_ptrs(params):
@@ -320,6 +359,40 @@ def _dw_reduce(dwp, dbp, nblk, pairs):
     for w, b in zip(tw, tb):
         out += [None, None] if acc else [w, b]
     return out
+
+
+def _ffn_half_backward(g, z1, z2, lws, params, ln_params, R, S, tail, beta_c, p, seed, rs, prm_args=None, prm=None):
+    """tg_encoder_bwd_ffn_dw_bf16 + its two ordered reductions: -> d_x1, (dW1, db1, dW2, db2), (dg2, dbe2, dgt, dbt);
+    gradients of parameters that own a gradient buffer are ADDED there and come back as None."""
+    lw1, lw2 = lws
+    p_1, pb_1, p_2, pb_2 = params
+    T, C = g.shape
+    dev = g.device
+    lib = L.load()
+    if prm is None:
+        lw_in, lw_o, b_in, b_o, g1, be1, b1, b2, g2, be2, gt, bt = prm_args
+        _, prm = pack_layer(lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, b1, b2, g2, be2, gt, bt)
+    rs_arr = (ctypes.c_uint32 * 4)(*rs)
+    stage = lib.tg_encoder_stage_bytes()
+    tiles = [lw1.contiguous(), ops.wt(lw2, p_2).contiguous(), ops.wt(lw1, p_1).contiguous()]      # W1, W2^T, W1^T
+    wpack_b = torch.empty(3 * stage, dtype=torch.uint8, device=dev)
+    tp = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in tiles])
+    ld = (ctypes.c_int32 * 3)(*[t.stride(0) for t in tiles])
+    L.call("tg_encoder_pack_tiles", ctypes.addressof(tp), ctypes.addressof(ld), 3, L.ptr(wpack_b), L.stream())
+    gg2, gb2, ggt, gbt = ln_params[1][0], ln_params[1][1], ln_params[2][0], ln_params[2][1]
+    nblk = lib.tg_encoder_dw_blocks(R, S)
+    d_x1 = torch.empty(T, C, dtype=g.dtype, device=dev)
+    lnp = torch.empty(nblk * 512, dtype=torch.float32, device=dev)
+    dwp = torch.empty(nblk * 2 * 128 * 128, dtype=torch.float32, device=dev)
+    dbp = torch.empty(nblk * 2 * 128, dtype=torch.float32, device=dev)
+    ops._launch("tg_encoder_bwd_ffn_dw_bf16", L.ptr(g), L.ptr(z1), L.ptr(z2), L.ptr(d_x1), L.ptr(wpack_b), L.ptr(prm), R, S,
+                int(tail), float(beta_c), 1e-5, float(p), int(seed), ctypes.addressof(rs_arr), L.ptr(lnp), L.ptr(dwp),
+                L.ptr(dbp), L.stream(), nbytes=2 * T * C * 4, units=wave_tiles(R, S))
+    STATS["fused_bwd"] += 1
+    STATS["fused_bwd_dw"] = STATS.get("fused_bwd_dw", 0) + 1
+    ln = _ln_reduce(lnp, nblk, (gg2, gb2, ggt if tail else None, gbt if tail else None))
+    dw = _dw_reduce(dwp, dbp, nblk, ((p_1, pb_1), (p_2, pb_2)))
+    return d_x1, tuple(dw), tuple(ln)
 
 
 def _fused_backward(ctx, g):

@@ -177,3 +177,38 @@ def test_fused_training_gradients_match_torch_fp32_autograd(S, H, R):
     worst = sorted(((_relerr(got[k].cpu(), want[k]), k) for k in want), reverse=True)
     print("fused layer vs fp32 autograd, worst:", worst[:4])
     assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
+
+
+@pytest.mark.parametrize("p", [0.0, 0.5])
+@pytest.mark.parametrize("S,H,R,use_tail,alpha,beta_c", [(130, 8, 300, True, 0.5, 0.5), (65, 4, 257, True, 0.0, 1.0),
+                                                         (130, 4, 64, False, 0.0, 1.0), (33, 8, 500, True, 1.0, 0.5)])
+def test_long_row_feed_forward_half_on_the_chained_kernel(S, H, R, use_tail, alpha, beta_c, p):
+    """Rows of more than 32 tokens (tabgnn.py:127-129,219: S = 130; the 64-column table: S = 65) run the attention op by op,
+    but their feed-forward half backward — tail LN, LN2, FFN, W1 / W2 / bias / LayerNorm gradients — goes through
+    tg_encoder_bwd_ffn_dw_bf16 on the flat token stream (pseudo rows of a divisor of S).  Against the op-by-op backward on
+    the same dropout streams: d_x and every parameter gradient."""
+    import tabgnn_amd.encoder_layer as EL
+    layer, tail = _layer(H, seed=13)
+    layer.to(DEV); tail.to(DEV)
+    x = (torch.randn(R, S, 128, device=DEV) * 1.2).to(torch.bfloat16)
+    co = torch.randn(R, S, 128, device=DEV)
+    assert EL.token_group(S) is not None and S % EL.token_group(S) == 0
+    n0 = dict(EL.STATS)
+    EL._LONG_FFN = True
+    out_f, g_f = _grads(layer, tail, x, p, use_tail, alpha, beta_c, co)
+    assert EL.STATS["fused_fwd"] == n0["fused_fwd"]                               # the forward stays op by op
+    assert EL.STATS.get("fused_bwd_dw", 0) == n0.get("fused_bwd_dw", 0) + 1       # the chained feed-forward kernel ran
+    EL._LONG_FFN = False
+    try:
+        out_u, g_u = _grads(layer, tail, x, p, use_tail, alpha, beta_c, co)
+    finally:
+        EL._LONG_FFN = True
+    assert torch.equal(out_f, out_u)                                              # same forward
+    worst = []
+    for k in g_u:
+        if g_u[k] is None or (not use_tail and k.startswith("tail.")):
+            continue
+        assert g_f[k] is not None, k
+        worst.append((_relerr(g_f[k], g_u[k]), k))
+    worst.sort(reverse=True)
+    assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
