@@ -362,6 +362,14 @@ int tg_gemm_nt_ln_bf16(const void* X, const void* W, const float* bias, const vo
  *      backward needs; qkv, scores, attention output, x1 and the hidden activation never reach memory.
  *      rs[4]: dropout streams (attention, norm1, ffn, norm2), the same element indexing as the unfused kernels. ---- */
 int64_t tg_encoder_pack_bytes(void);
+/* Everything BEHIND the attention of the layer above, for token rows of any length (the tabgnn path's S = 130,
+ * src/nn/models/tabgnn.py:127-129,219; the 64-column table's S = 65): z1 = x + drop(o Wo^T + b_o), x1 = LN1(z1),
+ * z2 = x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2), out = LN2(z2) (+ tail LayerNorm and alpha x + beta_c (.)), on the flat
+ * token stream as R pseudo rows of S tokens (2 <= S <= 32).  o = the attention output computed elsewhere; z1 / z2 / st1
+ * optional (st1 [T][2] = LayerNorm-1 mean, rstd).  Same weight pack, dropout streams and masks as tg_encoder_fwd_bf16. */
+int tg_encoder_ffn_fwd_bf16(const void* x, const void* o, void* out, void* z1, void* z2, float* st1, const void* wpack,
+                            const float* prm, int64_t R, int32_t S, int32_t tail, float alpha, float beta_c, float eps,
+                            float p_drop, uint64_t seed, const uint32_t* rs, void* stream);
 int64_t tg_encoder_stage_bytes(void);   /* bytes of ONE LDS weight image (a [128,128] tile): the backward packs are n of them */
 int64_t tg_encoder_prm_floats(void);
 int32_t tg_encoder_fused_supported(int32_t S, int32_t C, int32_t H, int32_t FF);

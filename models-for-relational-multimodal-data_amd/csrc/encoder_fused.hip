@@ -387,6 +387,8 @@ struct EfArgs {
   unsigned long long seed;
   unsigned rs0, rs1, rs2, rs3;    // attention, norm1, ffn, norm2 dropout streams
   int small_idx;                  // 1: every dropout element index of the call is below 2^32 (one RNG key per site)
+  const unsigned short* o_in;     // ATT = false: the attention output o [T,128] computed elsewhere (rows of more than 32 tokens)
+  float* st1;                     // ATT = false, optional: LayerNorm-1 statistics [T][2] = (mean, rstd) for an op-by-op backward
 };
 
 // Forward.  HD = head dim (16 or 32).  One workgroup = EF_WAVES wave tiles of 32 token slots per iteration.
@@ -426,8 +428,12 @@ struct EfArgs {
     EF_STAMP(14)                                                                                      \
   }
 #define EF_UNIT_NEXT(U, VALID, U2, BYTES) EF_UNIT_NEXT_K(U, VALID, U2, BYTES, EF_WAIT_VM(0))
-template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */>
+// ATT = false (round 5): everything BEHIND the attention — out-proj + dropout + residual + LN1, FFN, LN2, tail — for token
+// rows whose attention ran elsewhere (rows of more than 32 tokens: tabgnn.py:127-129,219 S = 130; the 64-column table):
+// the attention output arrives in `o_in`, units 0..7 (the QKV weights) are never fetched, the tile loop starts at unit 8.
+template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */, bool ATT = true>
 __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const EfArgs a_) {
+  constexpr int U0 = ATT ? 0 : 8;             // first weight unit of a tile
   EfArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -446,10 +452,13 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
   const long long n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
 
   for (int i = tid; i < EF_P_FLOATS; i += EF_THREADS) prm[i] = a.prm[i];
-  if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack, smem, wave, lane16);
+  if (blockIdx.x < n_it) ef_dma<EF_UNIT_BYTES>(a.wpack + (size_t)U0 * EF_UNIT_BYTES, smem, wave, lane16);
   EF_DMA_LANDED();
   __syncthreads();
-  if (blockIdx.x < n_it) ef_dma<EF_PART_BYTES>(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, wave, lane16);
+  if (blockIdx.x < n_it) {
+    if constexpr (ATT) ef_dma<EF_PART_BYTES>(a.wpack + EF_UNIT_BYTES, smem + EF_UNIT_BYTES, wave, lane16);
+    else ef_dma<EF_UNIT_BYTES>(a.wpack + (size_t)(U0 + 1) * EF_UNIT_BYTES, smem + EF_UNIT_BYTES, wave, lane16);
+  }
 
   // lane-constant addresses: every LDS access below is one of these bases + an immediate
   const int fb = EF_ROWB * tl + 16 * h;                          // weight fragment of row tl (+ 32 ks + 272 * row block)
@@ -489,10 +498,15 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
     const int NVALID = (int)rh_##ROW0 * S;                                                            \
     const long long TOK0 = ROW0 * S;
   ef_v8bf xn[8];                // x of the NEXT tile, loaded while this tile's feed-forward runs
+  ef_v8bf on[ATT ? 1 : 8];      // ATT = false: its attention output too
   if (blockIdx.x < n_it) {
     EF_TILE_GEOM((long long)blockIdx.x, row0p, nvalidp, tok0p)
     const __amdgpu_buffer_rsrc_t xrs0 = ef_tile_rsrc(a.x, tok0p, nvalidp);
     EF_LOAD_X(xn, xrs0)
+    if constexpr (!ATT) {
+      const __amdgpu_buffer_rsrc_t ors0 = ef_tile_rsrc(a.o_in, tok0p, nvalidp);
+      EF_LOAD_X(on, ors0)
+    }
   }
 
 #if EF_ABL & 1024
@@ -530,8 +544,12 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
     // wave-uniform 64-bit part (scalar) + lane part (32 bits)
     const unsigned long long att_u = (unsigned long long)row0 * (unsigned long long)(NH * S * S);
     const unsigned att_l = (unsigned)(q_row * NH * S * S + (tl - row_lo) * S + h4 - row_lo);   // head 0, this query, register 0's key
+    if constexpr (!ATT) {
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
+      for (int ks = 0; ks < 8; ++ks) of[ks] = on[ks];
+    }
+#pragma unroll
+    for (int blk = 0; blk < (ATT ? 4 : 0); ++blk) {
       const char* wu = EF_UBUF(2 * blk);            // unit 2 blk: Wq rows | Wk rows
       ef_f32x16 acc;
       // K^T and Q^T blocks [32 d, 32 tokens]
@@ -664,7 +682,15 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
         ef_f32x16 acc;
         EF_ACC_BIAS(acc, EF_P_BO + 32 * m)
         EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), of)
-        if (m & 1) { EF_UNIT_NEXT(8 + (m >> 1), true, 10 + (m >> 1), EF_UNIT_BYTES) }      // Wo unit done -> W1 units
+        if (m & 1) {                                                                       // Wo unit done -> W1 units
+          if (!ATT && m == 1) {
+            // (this tile's first boundary: issued since the DMA of unit 9 at the end of the previous tile: its out / z2 stores)
+            if (a.z2) { EF_UNIT_NEXT_K(8, true, 10, EF_UNIT_BYTES, EF_WAIT_VM(16)) }
+            else { EF_UNIT_NEXT_K(8, true, 10, EF_UNIT_BYTES, EF_WAIT_VM(8)) }
+          } else {
+            EF_UNIT_NEXT(8 + (m >> 1), true, 10 + (m >> 1), EF_UNIT_BYTES)
+          }
+        }
         ef_drop_tile<DROP>(acc, dkey, e_lo + 32u * m, h4, a.thresh);
         uint4 o0, o1;
 #pragma unroll
@@ -683,6 +709,9 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
       EF_STAMP(3)
       float mu, rstd;
       ef_row_stats(zp, a.eps, mu, rstd);
+      if constexpr (!ATT) {
+        if (a.st1 && h == 0 && tl < nvalid) *reinterpret_cast<float2*>(a.st1 + 2 * (tok0 + tl)) = make_float2(mu, rstd);
+      }
       const float nmr = -mu * rstd;
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
@@ -718,10 +747,14 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
             EF_TILE_GEOM(it + gridDim.x, row0n, nvalidn, tok0n)
             const __amdgpu_buffer_rsrc_t xrsn = ef_tile_rsrc(a.x, tok0n, nvalidn);
             EF_LOAD_X(xn, xrsn)
+            if constexpr (!ATT) {
+              const __amdgpu_buffer_rsrc_t orsn = ef_tile_rsrc(a.o_in, tok0n, nvalidn);
+              EF_LOAD_X(on, orsn)
+            }
           }
         } else if (m == 3) {
-          // issued since the DMA of unit 12: the 16 x loads above (when there is a next tile)
-          if (has_next) { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(16)) }
+          // issued since the DMA of unit 12: the 16 x loads above (when there is a next tile; 32 with the o loads)
+          if (has_next) { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(ATT ? 16 : 32)) }
           else { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
         }
 #pragma unroll
@@ -754,12 +787,17 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
         EF_ACC_BIAS(acc, EF_P_B2 + 32 * m)
         EF_CHAIN(acc, wu, EF_PART_BYTES * (m & 1), hf)
         if (m == 1) {                                // W2 units done -> the next iteration's first units
-          EF_UNIT_NEXT(12, has_next, 0, EF_UNIT_BYTES)
+          EF_UNIT_NEXT(12, has_next, U0, EF_UNIT_BYTES)
           // this tile's x again for the tail combine (L2-hot): 16 loads the next boundary must not wait for
           if (reload_x) { EF_LOAD_X(xf, xrs) }
         } else if (m == 3) {
-          if (reload_x) { EF_UNIT_NEXT_K(13, has_next, 1, EF_PART_BYTES, EF_WAIT_VM(16)) }
-          else { EF_UNIT_NEXT_K(13, has_next, 1, EF_PART_BYTES, EF_WAIT_VM(0)) }
+          if constexpr (ATT) {
+            if (reload_x) { EF_UNIT_NEXT_K(13, has_next, 1, EF_PART_BYTES, EF_WAIT_VM(16)) }
+            else { EF_UNIT_NEXT_K(13, has_next, 1, EF_PART_BYTES, EF_WAIT_VM(0)) }
+          } else {
+            if (reload_x) { EF_UNIT_NEXT_K(13, has_next, U0 + 1, EF_UNIT_BYTES, EF_WAIT_VM(16)) }
+            else { EF_UNIT_NEXT_K(13, has_next, U0 + 1, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
+          }
         }
         const uint4 r0 = *reinterpret_cast<const uint4*>(park + 1024 * (2 * m));
         const uint4 r1 = *reinterpret_cast<const uint4*>(park + 1024 * (2 * m + 1));
@@ -1940,6 +1978,7 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
   if (R <= 0) return 0;
   EfArgs a;
   a.x = (const unsigned short*)x; a.out = (unsigned short*)out; a.z1 = (unsigned short*)z1; a.z2 = (unsigned short*)z2;
+  a.o_in = nullptr; a.st1 = nullptr;
   a.wpack = (const char*)wpack; a.prm = prm; a.R = R; a.S = S; a.tail = tail; a.alpha = alpha; a.beta_c = beta_c; a.eps = eps;
   a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
   a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
@@ -1976,6 +2015,57 @@ extern "C" int tg_encoder_fwd_bf16(const void* x, void* out, void* z1, void* z2,
     if (drop == 0) EF_LAUNCH_FWD(16, 0) else if (drop == 1) EF_LAUNCH_FWD(16, 1) else if (drop == 8) EF_LAUNCH_FWD(16, 8) else EF_LAUNCH_FWD(16, 16)
   }
 #undef EF_LAUNCH_FWD
+  TG_LAUNCH_CHECK();
+  return 0;
+}
+
+// Everything behind the attention for token rows of ANY length (k_encoder_fwd<., ., ATT = false>): x, o [T,128] ->
+//     z1 = x + drop(o Wo^T + b_o), x1 = LN1(z1), z2 = x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2), out = (tail) LN2(z2)
+// on the flat token stream cut into R pseudo rows of S tokens (2 <= S <= 32, R * S = T): out, optional z1 / z2 and the
+// LayerNorm-1 statistics st1 [T][2] (mean, rstd) that the op-by-op attention-half backward reads.  rs[1..3] = the norm1 /
+// ffn / norm2 dropout streams (rs[0], the attention's, is not used).  wpack / prm: tg_encoder_pack.
+extern "C" int tg_encoder_ffn_fwd_bf16(const void* x, const void* o, void* out, void* z1, void* z2, float* st1, const void* wpack,
+                                       const float* prm, int64_t R, int32_t S, int32_t tail, float alpha, float beta_c,
+                                       float eps, float p_drop, uint64_t seed, const uint32_t* rs, void* stream) {
+  TG_CHECK(S >= 2 && S <= 32, "tg_encoder_ffn_fwd_bf16: unsupported S=%d", S);
+  TG_CHECK(x && o && out && wpack && prm && rs, "tg_encoder_ffn_fwd_bf16: null operand");
+  TG_CHECK(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(out) |
+             reinterpret_cast<uintptr_t>(z1) | reinterpret_cast<uintptr_t>(z2) | reinterpret_cast<uintptr_t>(wpack)) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(st1) & 7) == 0, "tg_encoder_ffn_fwd_bf16: operands must be 16-byte aligned");
+  if (R <= 0) return 0;
+  EfArgs a;
+  a.x = (const unsigned short*)x; a.out = (unsigned short*)out; a.z1 = (unsigned short*)z1; a.z2 = (unsigned short*)z2;
+  a.o_in = (const unsigned short*)o; a.st1 = st1;
+  a.wpack = (const char*)wpack; a.prm = prm; a.R = R; a.S = S; a.tail = tail; a.alpha = alpha; a.beta_c = beta_c; a.eps = eps;
+  a.thresh = p_drop > 0.f ? drop_threshold(p_drop) : 0u;
+  a.inv_keep = p_drop < 1.f ? 1.f / (1.f - p_drop) : 0.f;
+  a.seed = seed; a.rs0 = rs[0]; a.rs1 = rs[1]; a.rs2 = rs[2]; a.rs3 = rs[3];
+  a.small_idx = ((double)(R + 32) * S * 128.0 < 4294967296.0) ? 1 : 0;
+  const int RW = 32 / S;
+  const long long n_wt = (R + RW - 1) / RW, n_it = (n_wt + EF_WAVES - 1) / EF_WAVES;
+  static int n_cu = 0;
+  if (!n_cu) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    n_cu = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  const long long slots = (long long)n_cu * (EF_WAVES >= 8 ? 1 : EF_WG_PER_CU);
+  const unsigned grid = (unsigned)(n_it < slots ? n_it : slots);
+  const size_t lds = 2 * EF_UNIT_BYTES + EF_P_FLOATS * 4 + EF_WAVES * 8192;
+  const int drop = drop_mode(a.thresh);
+#define EF_LAUNCH_FFN(DR_)                                                                                     \
+  {                                                                                                            \
+    static bool attr_done = false;                                                                             \
+    if (!attr_done) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_encoder_fwd<32, DR_, false>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+      attr_done = true;                                                                                        \
+    }                                                                                                          \
+    hipLaunchKernelGGL((k_encoder_fwd<32, DR_, false>), dim3(grid), dim3(EF_THREADS), lds, (hipStream_t)stream, a); \
+  }
+  if (drop == 0) EF_LAUNCH_FFN(0) else if (drop == 1) EF_LAUNCH_FFN(1) else if (drop == 8) EF_LAUNCH_FFN(8) else EF_LAUNCH_FFN(16)
+#undef EF_LAUNCH_FFN
   TG_LAUNCH_CHECK();
   return 0;
 }

@@ -109,6 +109,7 @@ SIGNATURES = {
     "tg_encoder_dw_reduce": [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "tg_encoder_ln_reduce": [_vp, _i64, _vp, _i32, _vp],
     "tg_encoder_fwd_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _u64, _vp, _vp],
+    "tg_encoder_ffn_fwd_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _f32, _f32, _f32, _u64, _vp, _vp],
     "tg_weighted_ce_fwd": [_vp, _vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp],
     "tg_weighted_ce_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i32, _vp],
     "tg_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _i32, _vp],

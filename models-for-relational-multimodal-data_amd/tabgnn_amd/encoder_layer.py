@@ -159,6 +159,32 @@ class _EncoderLayerFn(torch.autograd.Function):
         o = torch.empty(T, C, dtype=dt, device=x.device)
         lse = torch.empty(R, nhead, S, dtype=torch.float32, device=x.device)
         L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, nhead, p, seed, rs[0], L.dt(x), L.stream())
+        grp = token_group(S) if (_LONG_FFN and _DW_FFN and nt and S > 32 and dt == torch.bfloat16
+                                 and lw1.shape == (128, 128)) else None
+        if grp is not None:
+            # rows of more than 32 tokens: everything behind the attention — out-proj + LN1, FFN, LN2, tail — in the one-kernel
+            # layer's attention-free variant (tg_encoder_ffn_fwd_bf16) on the token stream as pseudo rows of `grp` tokens;
+            # the backward (feed-forward half: chained kernel; attention half: op by op) needs z1, z2 and the LN1 statistics
+            wpack, prm = pack_layer(lw_in, lw_o, lw1, lw2, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None,
+                                    bt if tail else None)
+            out = torch.empty_like(x2d)
+            y = torch.empty_like(x2d) if needs_grad else None
+            y2 = torch.empty_like(x2d) if needs_grad else None
+            st1 = torch.empty(T, 2, dtype=torch.float32, device=x.device) if needs_grad else None
+            rs_arr = (ctypes.c_uint32 * 4)(*rs)
+            ops._launch("tg_encoder_ffn_fwd_bf16", L.ptr(x2d), L.ptr(o), L.ptr(out), L.ptr(y), L.ptr(y2), L.ptr(st1), L.ptr(wpack),
+                        L.ptr(prm), T // grp, grp, int(tail), float(alpha), float(beta_c), 1e-5, float(p), int(seed),
+                        ctypes.addressof(rs_arr), L.stream(), nbytes=2 * T * C * (3 + 2 * int(needs_grad)), units=wave_tiles(T // grp, grp))
+            STATS["fused_ffn_fwd"] = STATS.get("fused_ffn_fwd", 0) + 1
+            ctx.save_for_backward(x2d, qkv, o, lse, y, None, st1, None, None, y2, None, None, None, lw_in, lw_o, lw1, lw2, b_o, b2,
+                                  g1, g2, gt)
+            ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
+            ctx.nt = nt
+            ctx.prm_args, ctx.prm = None, prm
+            isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
+            ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2))
+            ctx.ln_params = ((g1, be1, b_o), (g2, be2, b2), (gt, bt, None))
+            return out.view(R, S, C)
         if nt:      # out_proj + bias + dropout + residual + LayerNorm in one kernel; y := z1 (the pre-norm sum) is kept
             y, x1, st1 = ops.gemm_nt_ln(o, lw_o, b_o.detach(), x2d, g1.detach(), be1.detach(), p, seed, rs[1])
         else:
@@ -184,7 +210,7 @@ class _EncoderLayerFn(torch.autograd.Function):
                               g1, g2, gt)
         ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
         ctx.nt = nt
-        ctx.prm_args = (lw_in, lw_o, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None, bt if tail else None)
+        ctx.prm_args, ctx.prm = (lw_in, lw_o, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None, bt if tail else None), None
         isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
         ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2))   # weight gradients accumulate in place
         ctx.ln_params = ((g1, be1, b_o), (g2, be2, b2), (gt, bt, None))               # LayerNorm gradients too
@@ -203,7 +229,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         dgt = dbt = None
         d_x = None
         tg1, tg2 = ops.ln_grad_targets(*ctx.ln_params[0]), ops.ln_grad_targets(*ctx.ln_params[1])
-        grp = token_group(S) if (_LONG_FFN and _DW_FFN and ctx.nt and S > 32 and g.dtype == torch.bfloat16
+        grp = token_group(S) if ((_LONG_FFN or x1 is None) and _DW_FFN and ctx.nt and S > 32 and g.dtype == torch.bfloat16
                                  and lw1.shape == (128, 128)) else None
         if grp is not None:
             # long rows: the whole feed-forward half (tail LN, LN2, FFN, its weight / bias / LayerNorm gradients) in the
@@ -211,7 +237,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             # h from (z1 = y, z2 = y2) on the forward's dropout streams (element index = token * 128 + channel in both paths)
             d_x1, (dw1, db1, dw2, db2), (dg2, dbe2, dgt, dbt) = _ffn_half_backward(
                 g, y, y2, (lw1, lw2), (p_1, pb_1, p_2, pb_2), ctx.ln_params, T // grp, grp, tail, beta_c, p, seed, rs,
-                ctx.prm_args)
+                ctx.prm_args, ctx.prm)
             dp2 = (dg2, dbe2, db2)
             if tail and alpha != 0.0:
                 d_x = g * alpha                      # the residual branch of out = alpha x + beta_c LN_t(.)
@@ -288,7 +314,7 @@ def _attention_half_backward(ctx, d_x, d_x1, dw1, db1, dw2, dp2, dgt, dbt):
     # x1 = LN1(x + drop(y + b_o))
     acc_dx = d_x is not None
     if d_x is None:
-        d_x = torch.empty_like(x1)
+        d_x = torch.empty_like(y)
     if ctx.nt:
         d_y, dp1 = _ln_bwd(y, None, None, g1, st1, d_x1, d_x, True, None, 0.0, 1.0, p, seed, rs[1], acc_dx, tg1)
     else:
