@@ -431,9 +431,13 @@ struct EfArgs {
 // ATT = false (round 5): everything BEHIND the attention — out-proj + dropout + residual + LN1, FFN, LN2, tail — for token
 // rows whose attention ran elsewhere (rows of more than 32 tokens: tabgnn.py:127-129,219 S = 130; the 64-column table):
 // the attention output arrives in `o_in`, units 0..7 (the QKV weights) are never fetched, the tile loop starts at unit 8.
+#ifndef EF_FFN_X_LATE
+#define EF_FFN_X_LATE 1      // ATT = false: 1 = only o is prefetched a tile ahead, x is loaded at the tile's top (it is first needed
+#endif                       // behind the first out-proj chain); 0 = both prefetched (64 staging registers: 49 spilled)
 template <int HD, int DROP /* 0 = off, else hash bits per element: 1 | 8 | 16 (common.hpp) */, bool ATT = true>
 __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const EfArgs a_) {
   constexpr int U0 = ATT ? 0 : 8;             // first weight unit of a tile
+  constexpr bool X_LATE = !ATT && EF_FFN_X_LATE;
   EfArgs a = a_;
   a.seed = live_seed(a_.seed);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -502,7 +506,7 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
   if (blockIdx.x < n_it) {
     EF_TILE_GEOM((long long)blockIdx.x, row0p, nvalidp, tok0p)
     const __amdgpu_buffer_rsrc_t xrs0 = ef_tile_rsrc(a.x, tok0p, nvalidp);
-    EF_LOAD_X(xn, xrs0)
+    if constexpr (!X_LATE) { EF_LOAD_X(xn, xrs0) }
     if constexpr (!ATT) {
       const __amdgpu_buffer_rsrc_t ors0 = ef_tile_rsrc(a.o_in, tok0p, nvalidp);
       EF_LOAD_X(on, ors0)
@@ -519,8 +523,13 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
     EF_TILE_GEOM(it, row0, nvalid, tok0)
     const bool has_next = it + gridDim.x < n_it;
     ef_v8bf xf[8];
+    if constexpr (X_LATE) {
+      const __amdgpu_buffer_rsrc_t xrs_top = ef_tile_rsrc(a.x, tok0, nvalid);
+      EF_LOAD_X(xf, xrs_top)
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) xf[ks] = xn[ks];
+      for (int ks = 0; ks < 8; ++ks) xf[ks] = xn[ks];
+    }
 
     // accumulator initialised with a per-row bias (float4 per register group, straight from LDS: no VALU)
 #define EF_ACC_BIAS(ACC, POFF)                                                                        \
@@ -746,7 +755,7 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
           if (has_next) {
             EF_TILE_GEOM(it + gridDim.x, row0n, nvalidn, tok0n)
             const __amdgpu_buffer_rsrc_t xrsn = ef_tile_rsrc(a.x, tok0n, nvalidn);
-            EF_LOAD_X(xn, xrsn)
+            if constexpr (!X_LATE) { EF_LOAD_X(xn, xrsn) }
             if constexpr (!ATT) {
               const __amdgpu_buffer_rsrc_t orsn = ef_tile_rsrc(a.o_in, tok0n, nvalidn);
               EF_LOAD_X(on, orsn)
@@ -754,7 +763,7 @@ __global__ void __launch_bounds__(EF_THREADS, EF_WG_PER_CU) k_encoder_fwd(const 
           }
         } else if (m == 3) {
           // issued since the DMA of unit 12: the 16 x loads above (when there is a next tile; 32 with the o loads)
-          if (has_next) { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(ATT ? 16 : 32)) }
+          if (has_next) { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(ATT || X_LATE ? 16 : 32)) }
           else { EF_UNIT_NEXT_K(11, true, 13, EF_UNIT_BYTES, EF_WAIT_VM(0)) }
         }
 #pragma unroll
