@@ -243,6 +243,10 @@ class GraphedTrainStep:
     def __init__(self, model, flat, opt, loss_weight, n_seed, ddp=None, state=None, warmup=2, index=True):
         self.model, self.flat, self.opt, self.loss_weight = model, flat, opt, loss_weight
         self.n_seed, self.ddp, self.warmup = int(n_seed), ddp, int(warmup)
+        if ddp is not None and getattr(ddp, "_stage_ranges", None):
+            # a replayed graph runs no autograd, so no pre-hook can announce a finished stage — and hooks fired by the
+            # warm-up / capture passes would leave ranges marked "in flight" for a step that never exchanged them
+            ddp.disable_overlap()
         # index=False: hand the wrapper the plain int64 edge_index (GNN / TABGNNS of utils.py take nothing else): the batch's
         # CSRs are then built by the index kernels INSIDE the graph, from the bucket's static edge_index
         self.index = bool(index)
