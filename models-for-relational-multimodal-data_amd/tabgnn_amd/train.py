@@ -165,7 +165,9 @@ class DataParallel:
         stages i+1 .., the head, the loss) has already run, including the ones that only write parameter gradients
         (weight folds, the in-place weight-gradient GEMMs of the composite nodes).  The all-reduce is issued from the
         node's pre-hook on the stream the node runs on, so the collective stream waits for exactly the kernels queued
-        so far.  ``tests/test_ddp_gloo.py`` holds the result against the post-backward exchange bit for bit."""
+        so far.  ``tests/test_ddp_gloo.py`` holds the result against the post-backward exchange bit for bit.  Every backward
+        must be followed by ``all_reduce_grads()`` (``train_step`` does); ``GraphedTrainStep`` switches the overlap off (a
+        replayed graph runs no autograd hooks)."""
         stages = list(stages)
         index = {id(p): i for i, p in enumerate(self.flat.params)}
         self._stage_ranges = []
@@ -196,7 +198,7 @@ class DataParallel:
 
     def _make_forward_hook(self, i):
         def hook(module, inputs, output):
-            if not (self.active and torch.is_grad_enabled()):
+            if not (self.active and torch.is_grad_enabled()) or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
                 return
             outs = output if isinstance(output, (tuple, list)) else (output,)
             fired = []
