@@ -181,7 +181,8 @@ def test_fused_training_gradients_match_torch_fp32_autograd(S, H, R):
 
 @pytest.mark.parametrize("p", [0.0, 0.5])
 @pytest.mark.parametrize("S,H,R,use_tail,alpha,beta_c", [(130, 8, 300, True, 0.5, 0.5), (65, 4, 257, True, 0.0, 1.0),
-                                                         (130, 4, 64, False, 0.0, 1.0), (33, 8, 500, True, 1.0, 0.5)])
+                                                         (130, 4, 64, False, 0.0, 1.0), (33, 8, 500, True, 1.0, 0.5),
+                                                         (130, 8, 29903, True, 0.5, 0.5)])       # (last: configs[3]'s node rows)
 def test_long_row_feed_forward_half_on_the_chained_kernel(S, H, R, use_tail, alpha, beta_c, p):
     """Rows of more than 32 tokens (tabgnn.py:127-129,219: S = 130; the 64-column table: S = 65) run the attention op by op,
     but everything behind it is token-wise: forward in tg_encoder_ffn_fwd_bf16 (out-proj + LN1, FFN, LN2, tail), backward of
