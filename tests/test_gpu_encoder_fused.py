@@ -240,3 +240,7 @@ def test_long_row_layer_matches_torch_fp32_autograd(S, H, R):
     assert (out.cpu() - y.detach()).abs().max().item() <= BF16_TOL
     worst = sorted(((_relerr(got[k].cpu(), want[k]), k) for k in want), reverse=True)
     assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
+    # inference (no_grad: nothing saved, z1 / z2 / statistics not written) gives the training forward's output at p = 0
+    with torch.no_grad():
+        inf = EL.encoder_layer(x.to(DEV), layer, 0.0, tail, 0.5, 0.5)
+    assert EL.STATS.get("fused_ffn_fwd", 0) == n0 + 2 and torch.equal(inf.float(), out)
