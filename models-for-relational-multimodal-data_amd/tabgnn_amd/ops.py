@@ -1364,8 +1364,9 @@ def post_scaled_ok(x, agg, agg_width=None):
     if agg is not None and (agg.dtype != torch.bfloat16 or not agg.is_cuda or agg.shape[0] != x.shape[0]):
         return False
     K = agg.shape[1] if agg is not None else agg_width
-    return (_FUSED_POST and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and nt_ok(x, x.shape[1], x.shape[1])
-            and K % 128 == 0)
+    # (F == 128 spelled out: nt_ok's old "N == 128 or K == 128" policy used to imply it; the kernels are built for F = 128)
+    return (_FUSED_POST and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == 128
+            and nt_ok(x, 128, 128) and K % 128 == 0)
 
 
 class _PNAPostScaled(torch.autograd.Function):
