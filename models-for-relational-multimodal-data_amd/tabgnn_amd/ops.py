@@ -258,15 +258,17 @@ def _sink_target(sink, shape, dtype, device):
 NT_RELU, NT_DROPOUT, NT_ACCUM, NT_GATE, NT_LEAKY = 1, 2, 4, 8, 16
 
 
-# every N, K multiple of 128 runs on the hand-written kernel, the C = 256 projections of configs[4] included (round 5: same
-# box 34.0-34.6 ms/step on the library vs 34.4-34.7 on tg_gemm_nt_bf16 — a wash; TABGNN_NT_LIBRARY=1 sends N, K > 128 back)
-_NT_ANY = os.environ.get("TABGNN_NT_LIBRARY") != "1"
+# A/B: every N, K multiple of 128 on the hand-written kernel.  Measured in round 5 on configs[4]'s batch shape (same box, after
+# post_scaled_ok stopped leaning on this policy): 34.3-34.4 ms/step against 33.5-33.8 with N, K > 128 on hipBLASLt's 256 x 256
+# tiles — and the large C = 256 products (QKV, out-proj, FFN of the op-by-op column transformer) do not come through nt_ok
+# at all (encoder_layer takes its hand-written route at C = 128 only), so the default stays with the faster library there.
+_NT_ANY = os.environ.get("TABGNN_NT_ANY") == "1"
 
 
 def nt_ok(x2, N, K):
     """Shapes the hand-written MFMA GEMM (tg_gemm_nt_bf16) takes: bf16 rows, N and K multiples of 128; measured at or
-    above the library GEMM for N == 128 (any K) and for K == 128 (any N: the QKV projection, edge_emb's dX), on par for
-    N, K = 256 .. 768."""
+    above the library GEMM for N == 128 (any K) and for K == 128 (any N: the QKV projection, edge_emb's dX); 2 % behind it
+    on configs[4]'s step for N, K = 256 .. 768 (TABGNN_NT_ANY=1 routes those here too)."""
     return (x2.dtype == torch.bfloat16 and x2.is_cuda and N % 128 == 0 and K % 128 == 0 and x2.shape[0] > 0
             and (N == 128 or K == 128 or _NT_ANY) and x2.stride(1) == 1 and x2.stride(0) % 8 == 0
             and x2.data_ptr() % 16 == 0)
