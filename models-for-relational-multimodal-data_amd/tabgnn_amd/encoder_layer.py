@@ -26,6 +26,7 @@ _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B
 _FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
 _DW_FFN = os.environ.get("TABGNN_NO_DW_FFN") != "1"      # A/B: feed-forward weight gradients inside the chained backward kernel
 _DX_FOLD = os.environ.get("TABGNN_NO_DX_FOLD") != "1"    # A/B: d_x += d_qkv W_in inside the attention-half backward kernel
+_NT_WIDE = os.environ.get("TABGNN_NO_WIDE_NT") != "1"      # A/B: C > 128 layers: projections on tg_gemm_nt_bf16 (fused epilogues)
 _LONG_FFN = os.environ.get("TABGNN_NO_LONG_ROW_FFN") != "1"   # A/B: fused feed-forward-half backward for rows of more than 32 tokens
 
 
@@ -155,7 +156,11 @@ class _EncoderLayerFn(torch.autograd.Function):
         # projections on the hand-written MFMA kernel when the shapes allow (bf16, d_model = feed-forward = 128);
         # its epilogue applies bias and, for linear1, ReLU + dropout, so the pre-activation never exists
         nt = C == 128 and lw1.shape[0] == 128 and ops.nt_ok(x2d, 3 * C, C)     # every GEMM of the layer qualifies
-        qkv = ops.gemm_nt(x2d, lw_in, b_in.detach()) if nt else torch.addmm(lb_in, x2d, lw_in.t())
+        # wider layers (C = 256: the 64-column table of configs[4]): the GEMMs alone on the hand-written kernel, with linear1's
+        # ReLU + dropout and the gate of its backward in the epilogues; the GEMM + LayerNorm kernel is built for 128 channels
+        ntg = (not nt) and _NT_WIDE and dt == torch.bfloat16 and x2d.is_cuda and C % 128 == 0 and lw1.shape[0] % 128 == 0 \
+            and T > 0 and x2d.data_ptr() % 16 == 0
+        qkv = ops.gemm_nt(x2d, lw_in, b_in.detach()) if (nt or ntg) else torch.addmm(lb_in, x2d, lw_in.t())
         o = torch.empty(T, C, dtype=dt, device=x.device)
         lse = torch.empty(R, nhead, S, dtype=torch.float32, device=x.device)
         L.call("tg_attn_fwd", L.ptr(qkv), L.ptr(o), L.ptr(lse), R, S, C, nhead, p, seed, rs[0], L.dt(x), L.stream())
@@ -179,7 +184,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             ctx.save_for_backward(x2d, qkv, o, lse, y, None, st1, None, None, y2, None, None, None, lw_in, lw_o, lw1, lw2, b_o, b2,
                                   g1, g2, gt)
             ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
-            ctx.nt = nt
+            ctx.nt, ctx.ntg = nt, False
             ctx.prm_args, ctx.prm = None, prm
             isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
             ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2))
@@ -188,9 +193,9 @@ class _EncoderLayerFn(torch.autograd.Function):
         if nt:      # out_proj + bias + dropout + residual + LayerNorm in one kernel; y := z1 (the pre-norm sum) is kept
             y, x1, st1 = ops.gemm_nt_ln(o, lw_o, b_o.detach(), x2d, g1.detach(), be1.detach(), p, seed, rs[1])
         else:
-            y = o @ lw_o.t()
+            y = ops.gemm_nt(o, lw_o) if ntg else o @ lw_o.t()
             x1, st1 = _ln_fwd(x2d, y, b_o, g1, be1, None, 0.0, 1.0, p, seed, rs[1])
-        if nt:      # h = drop(relu(x1 W1^T + b1)) in one pass; the backward gates on h > 0 (kept AND active)
+        if nt or ntg:      # h = drop(relu(x1 W1^T + b1)) in one pass; the backward gates on h > 0 (kept AND active)
             h = ops.gemm_nt(x1, lw1, b1.detach(), ops.NT_RELU | ops.NT_DROPOUT, p, seed, rs[2])
             hpre = h
         else:
@@ -200,7 +205,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         if nt:
             y2, x2, st2 = ops.gemm_nt_ln(h, lw2, b2.detach(), x1, g2.detach(), be2.detach(), p, seed, rs[3])
         else:
-            y2 = h @ lw2.t()
+            y2 = ops.gemm_nt(h, lw2) if ntg else h @ lw2.t()
             x2, st2 = _ln_fwd(x1, y2, b2, g2, be2, None, 0.0, 1.0, p, seed, rs[3])
         if tail:
             out, st3 = _ln_fwd(x2, None, None, gt, bt, x2d if alpha != 0.0 else None, alpha, beta_c, 0.0, 0, 0)
@@ -209,7 +214,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2d, qkv, o, lse, y, x1, st1, hpre, h, y2, x2, st2, st3, lw_in, lw_o, lw1, lw2, b_o, b2,
                               g1, g2, gt)
         ctx.cfg = (R, S, C, nhead, p, tail, alpha, beta_c, seed, rs)
-        ctx.nt = nt
+        ctx.nt, ctx.ntg = nt, ntg
         ctx.prm_args, ctx.prm = (lw_in, lw_o, b_in, b_o, g1, be1, b1, b2, g2, be2, gt if tail else None, bt if tail else None), None
         isp = lambda t: t if isinstance(t, torch.nn.Parameter) else None
         ctx.params = (isp(w_in), isp(b_in), isp(w_o), isp(w1), isp(b1), isp(w2), isp(b2))   # weight gradients accumulate in place
@@ -280,7 +285,7 @@ class _EncoderLayerFn(torch.autograd.Function):
                 d_y2, dp2 = _ln_bwd(x1, y2, b2, g2, st2, d_x2, d_x1, True, None, 0.0, 1.0, p, seed, rs[3], False, tg2)
         del d_x2
         dw2, _ = ops.weight_grad(d_y2, h, False, p_2)
-        nt = ctx.nt
+        nt = ctx.nt or ctx.ntg
         if nt:      # dX GEMM with the backward of drop(relu(.)) in its epilogue: d_h never exists
             d_hpre = ops.gemm_nt(d_y2, ops.wt(lw2, p_2), None, ops.NT_GATE, p, gate=h)
             del d_y2
@@ -309,7 +314,7 @@ def _attention_half_backward(ctx, d_x, d_x1, dw1, db1, dw2, dp2, dgt, dbt):
     R, S, C, H, p, tail, alpha, beta_c, seed, rs = ctx.cfg
     p_in, pb_in, p_o = ctx.params[:3]
     T = R * S
-    nt = ctx.nt
+    nt = ctx.nt or ctx.ntg
     tg1 = ops.ln_grad_targets(*ctx.ln_params[0])
     # x1 = LN1(x + drop(y + b_o))
     acc_dx = d_x is not None
