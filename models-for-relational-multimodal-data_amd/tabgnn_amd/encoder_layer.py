@@ -26,7 +26,11 @@ _FUSED_LAYER = os.environ.get("TABGNN_NO_FUSED_ENCODER") != "1"   # same-box A/B
 _FUSED_TRAIN = os.environ.get("TABGNN_NO_FUSED_ENCODER_TRAIN") != "1"   # ... in training (fused backward kernels)
 _DW_FFN = os.environ.get("TABGNN_NO_DW_FFN") != "1"      # A/B: feed-forward weight gradients inside the chained backward kernel
 _DX_FOLD = os.environ.get("TABGNN_NO_DX_FOLD") != "1"    # A/B: d_x += d_qkv W_in inside the attention-half backward kernel
-_NT_WIDE = os.environ.get("TABGNN_NO_WIDE_NT") != "1"      # A/B: C > 128 layers: projections on tg_gemm_nt_bf16 (fused epilogues)
+# opt-in: layers wider than 128 channels (C = 256, configs[4]) with their projections on tg_gemm_nt_bf16 (ReLU + dropout / gate
+# epilogues) instead of hipBLASLt + separate activation kernels.  Measured in round 5, same box: 35.7-37.3 ms/step against
+# 34.4-35.1 on the library — its 256 x 256 tiles beat the 128 x 128-tile kernel on K = 256 products by more than the fused
+# epilogues give back — so the default stays with the library until a 256-wide tile exists.
+_NT_WIDE = os.environ.get("TABGNN_WIDE_NT") == "1"
 _LONG_FFN = os.environ.get("TABGNN_NO_LONG_ROW_FFN") != "1"   # A/B: fused feed-forward-half backward for rows of more than 32 tokens
 
 

@@ -244,3 +244,31 @@ def test_long_row_layer_matches_torch_fp32_autograd(S, H, R):
     with torch.no_grad():
         inf = EL.encoder_layer(x.to(DEV), layer, 0.0, tail, 0.5, 0.5)
     assert EL.STATS.get("fused_ffn_fwd", 0) == n0 + 2 and torch.equal(inf.float(), out)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_wide_layer_on_the_hand_written_gemms_matches_the_library_route(p):
+    """C = 256 (configs[4]): the op-by-op layer with its projections on tg_gemm_nt_bf16 (opt-in, TABGNN_WIDE_NT=1) against the
+    default route (library GEMMs + separate activation kernels) on the same dropout streams."""
+    import tabgnn_amd.encoder_layer as EL
+    from tabgnn_amd.layers import ColumnTransformerLayer
+    torch.manual_seed(3)
+    layer = ColumnTransformerLayer(256, 8, 256, dropout=0.0).to(DEV)
+    tail = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        for q in list(layer.parameters()) + list(tail.parameters()):
+            q.copy_(q.to(torch.bfloat16).float())
+    R, S = 300, 10
+    x = (torch.randn(R, S, 256, device=DEV) * 1.2).to(torch.bfloat16)
+    co = torch.randn(R, S, 256, device=DEV)
+    res = {}
+    for wide in (True, False):
+        EL._NT_WIDE = wide
+        try:
+            res[wide] = _grads(layer, tail, x, p, True, 0.5, 0.5, co)
+        finally:
+            EL._NT_WIDE = False
+    (out_w, g_w), (out_l, g_l) = res[True], res[False]
+    assert _relerr(out_w, out_l) <= 0.01
+    worst = sorted(((_relerr(g_w[k], g_l[k]), k) for k in g_l if g_l[k] is not None), reverse=True)
+    assert all(r <= (0.06 if k.startswith("linear1") else 0.03) for r, k in worst), worst[:4]
